@@ -1,0 +1,451 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference's
+Python hot path (/root/reference/autosmoothquant/layers/nn/linear.py and
+layers/functional/quantization.py) in the build container.
+
+Runs ONLY where /root/reference exists (never on the GPU box).  What is committed is
+data: inputs + the reference's outputs (+ the int8 activations / int32 accumulators that
+crossed its native boundary).  No reference source or bytecode is copied.
+
+The reference's native module `autosmoothquant._CUDA` (cuBLASLt, CUDA-only) is replaced
+by a recording stub whose `linear_a8_w8_o32_` is an exact integer matmul -- bit-identical
+to CUBLAS_COMPUTE_32I with alpha=1, beta=0 (cublasINT8MMWrapper.cc:231,276-277).
+
+While generating, every case is also pushed through oracle/w8a8.py and must agree
+bit-for-bit; a mismatch aborts generation.  Usage:
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# ---- recording stub for the native boundary -------------------------------------
+REC = {}
+stub = types.ModuleType("autosmoothquant._CUDA")
+
+
+class I8CUGEMM:  # same ctor + method name as csrc/int8gemm/bindings.cpp:145-155
+    def linear_a8_w8_o32_(self, x, w, out):
+        assert x.dtype == torch.int8 and w.dtype == torch.int8 and out.dtype == torch.int32
+        out.copy_(x.to(torch.int32) @ w.to(torch.int32).t())
+        REC["xq"] = x.clone()
+        REC["acc"] = out.clone()
+
+
+stub.I8CUGEMM = I8CUGEMM
+sys.modules["autosmoothquant._CUDA"] = stub
+torch.cuda.current_device = lambda: torch.device("cpu")  # linear.py:101 hard-codes it
+sys.path.insert(0, "/root/reference")
+import autosmoothquant.layers.nn.linear as RL  # noqa: E402
+import autosmoothquant.layers.functional.quantization as RQ  # noqa: E402
+
+from oracle import w8a8 as O  # noqa: E402
+import detrng  # noqa: E402
+
+TDT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+def t2n(t):
+    """torch float tensor (any float dtype) -> float32 numpy, exact"""
+    return t.detach().to(torch.float32).cpu().numpy().copy()
+
+
+def n2t(a, dt):
+    t = torch.from_numpy(np.array(a, dtype=np.float32, copy=True)).to(TDT[dt])
+    assert np.array_equal(t2n(t), np.asarray(a, np.float32), equal_nan=True), "input not representable"
+    return t
+
+
+def same(a, b, what):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    if a.shape != b.shape or not np.array_equal(a, b, equal_nan=True):
+        bad = np.argwhere(~((a == b) | (np.isnan(a.astype(np.float64)) & np.isnan(b.astype(np.float64)))))
+        raise SystemExit(f"ORACLE != REFERENCE for {what}: {len(bad)} mismatches, first at {bad[:3].tolist()}")
+
+
+def make_x(seed, stream, shape, dt, scale=48.0):
+    x = detrng.act_like(seed, stream, shape, scale=scale)
+    return t2n(torch.from_numpy(x).to(TDT[dt]))  # snapped to dt
+
+
+def make_w(seed, stream, N, K):
+    return (detrng.normal(seed, stream, (N, K)) * np.float32(0.02)).astype(np.float32)
+
+
+def build_module(kind, Wf, bias, input_scale, act_quant, qkv_size=None):
+    lin = torch.nn.Linear(Wf.shape[1], Wf.shape[0], bias=bias is not None)
+    lin.weight.data = torch.from_numpy(Wf.copy())
+    if bias is not None:
+        lin.bias.data = torch.from_numpy(bias.copy())
+    if kind == "linear":
+        m = RL.W8A8BFP32OFP32Linear.from_float(lin, input_scale, act_quant=act_quant)
+    elif kind == "quantscale":
+        m = RL.W8A8BFP32OFP32LinearWithQuantScale.from_float(lin, input_scale, act_quant=act_quant)
+    elif kind == "qkv":
+        m = RL.W8A8BFP32OFP32QKVLinear.from_float(lin, input_scale, qkv_size, act_quant=act_quant)
+    else:
+        raise ValueError(kind)
+    return m
+
+
+def module_params(kind, m):
+    p = {"wq": m.weight.numpy().copy()}
+    if kind == "qkv":
+        p["qkv_scales"] = np.array([m.q_dequant_scale.item(), m.k_dequant_scale.item(),
+                                    m.v_dequant_scale.item()], np.float32)
+    else:
+        p["dequant_scale"] = np.float32(m.dequant_scale.item())
+    if kind == "quantscale" and m.act_quant == "per-tensor":
+        p["quant_scale"] = np.float32(m.quant_scale.item())
+    return p
+
+
+def oracle_forward(kind, x, dt, p, bias, act_quant, qkv_size=None):
+    if kind == "linear":
+        return O.linear_forward(x, dt, p["wq"], p["dequant_scale"], bias, act_quant, True)
+    if kind == "quantscale":
+        return O.linear_with_quant_scale_forward(x, dt, p["wq"], p["dequant_scale"], p.get("quant_scale"),
+                                                 bias, act_quant, True)
+    return O.qkv_linear_forward(x, dt, p["wq"], p["qkv_scales"], qkv_size, bias, act_quant, True)
+
+
+def run_case(kind, x, dt, Wf, bias, input_scale, act_quant, qkv_size=None, tag=""):
+    m = build_module(kind, Wf, bias, input_scale, act_quant, qkv_size)
+    p = module_params(kind, m)
+    REC.clear()
+    out = m(n2t(x, dt))
+    assert out.dtype == TDT[dt]
+    ref = {"out": t2n(out), "xq": REC["xq"].numpy().copy(), "acc": REC["acc"].numpy().copy()}
+    o_out, o_xq, o_qs, o_acc = oracle_forward(kind, x, dt, p, bias, act_quant, qkv_size)
+    same(o_xq.reshape(ref["xq"].shape), ref["xq"], f"{tag} xq")
+    same(o_acc, ref["acc"], f"{tag} acc")
+    same(o_out, ref["out"], f"{tag} out")
+    return p, ref
+
+
+# ---------------------------------------------------------------------------------
+def gen_g1():
+    """G1: {Linear, WithQuantScale, QKV} x {per-tensor, per-token} x {bias, no bias}
+    x {f32, f16, bf16} at small full sizes."""
+    shapes = [(1, 64, 48), (4, 256, 256), (33, 320, 48), (33, 64, 256)]
+    store, index = {}, []
+    cid = 0
+    for si, (M, K, N) in enumerate(shapes):
+        Wf = make_w(11, si, N, K)
+        b = (detrng.normal(12, si, (N,)) * np.float32(0.5)).astype(np.float32)
+        store[f"W{si}"] = Wf
+        store[f"b{si}"] = b
+        qkv_size = [N // 2, N // 4, N - N // 2 - N // 4]
+        for dt in ("f32", "f16", "bf16"):
+            for kind in ("linear", "quantscale", "qkv"):
+                for aq in ("per-tensor", "per-token"):
+                    for use_bias in (False, True):
+                        xraw = make_x(13, cid, (M, K), dt, scale=48.0)
+                        input_scale = float(np.float32(np.abs(xraw).max() / 127.0))
+                        if kind in ("linear", "qkv") and aq == "per-tensor":
+                            # scale already folded upstream: feed x in int8 units
+                            x = t2n(torch.from_numpy(xraw / np.float32(input_scale)).to(TDT[dt]))
+                        else:
+                            x = xraw
+                        p, ref = run_case(kind, x, dt, Wf, b if use_bias else None, input_scale, aq,
+                                          qkv_size if kind == "qkv" else None, tag=f"G1#{cid}")
+                        key = f"c{cid}"
+                        store[key + "_x"] = x
+                        store[key + "_out"] = ref["out"]
+                        store[key + "_xq"] = ref["xq"]
+                        store[key + "_acc"] = ref["acc"]
+                        for k, v in p.items():
+                            if k != "wq":
+                                store[key + "_" + k] = np.asarray(v)
+                        store[key + "_wq"] = p["wq"]
+                        index.append(f"{cid}|{si}|{M}|{K}|{N}|{dt}|{kind}|{aq}|{int(use_bias)}|{input_scale!r}|"
+                                     + ",".join(map(str, qkv_size)))
+                        cid += 1
+    # wq is identical for cases sharing (shape, kind-segmentation); np.savez_compressed dedups poorly,
+    # so keep one copy per (si, kind in {plain, qkv})
+    seen = {}
+    for line in index:
+        f = line.split("|")
+        cid_, si, kind = f[0], f[1], f[6]
+        k2 = (si, "qkv" if kind == "qkv" else "plain")
+        key = f"c{cid_}_wq"
+        if k2 in seen:
+            assert np.array_equal(store[key], store[seen[k2]])
+            del store[key]
+        else:
+            seen[k2] = f"wq_{k2[0]}_{k2[1]}"
+            store[seen[k2]] = store.pop(key)
+    store["index"] = np.array(index)
+    np.savez_compressed(os.path.join(HERE, "g1_matrix.npz"), **store)
+    print(f"G1: {cid} cases")
+
+
+def gen_g2():
+    """G2: edge cases."""
+    store, index = {}, []
+    K, N = 64, 32
+    Wf = make_w(21, 0, N, K)
+    b = (detrng.normal(22, 0, (N,)) * np.float32(0.5)).astype(np.float32)
+    store["W"] = Wf
+    store["b"] = b
+
+    def add(name, kind, x, dt, aq, bias, input_scale=0.37, shape3d=None):
+        xin = x if shape3d is None else x.reshape(shape3d)
+        p, ref = run_case(kind, xin, dt, Wf, bias, input_scale, aq, tag=f"G2 {name}")
+        store[name + "_x"] = xin
+        store[name + "_out"] = ref["out"]
+        store[name + "_xq"] = ref["xq"]
+        store[name + "_acc"] = ref["acc"]
+        store[name + "_wq"] = p["wq"]
+        store[name + "_dequant_scale"] = np.float32(p["dequant_scale"])
+        if "quant_scale" in p:
+            store[name + "_quant_scale"] = np.float32(p["quant_scale"])
+        index.append(f"{name}|{dt}|{kind}|{aq}|{int(bias is not None)}|{input_scale!r}")
+
+    for dt in ("f32", "f16", "bf16"):
+        # ties (half-even), negative ties, clamp on both sides, +-inf, NaN, +-0
+        row = np.array([0.5, 1.5, 2.5, 3.5, -0.5, -1.5, -2.5, -3.5, 126.5, 127.5, 128.5, -127.5, -128.5,
+                        -129.5, 300.0, -300.0, 1e4, -1e4, np.inf, -np.inf, np.nan, 0.0, -0.0, 0.49, -0.49,
+                        63.5, 64.5, -63.5, -64.5, 1.0, -1.0, 127.0], np.float32)
+        x = np.stack([np.resize(row, K), np.resize(row[::-1], K), np.resize(row * 0.5, K)]).astype(np.float32)
+        x = t2n(torch.from_numpy(x).to(TDT[dt]))
+        add(f"ties_{dt}", "linear", x, dt, "per-tensor", None)
+        add(f"ties_bias_{dt}", "linear", x, dt, "per-tensor", b)
+        # finite-only version through the dividing per-tensor path and per-token path
+        xf = np.where(np.isfinite(x), x, np.float32(7.0)).astype(np.float32)
+        add(f"tiesdiv_{dt}", "quantscale", xf, dt, "per-tensor", b, input_scale=0.5)
+        add(f"tiestok_{dt}", "quantscale", xf, dt, "per-token", b)
+        # a row of zeros (and an all-zero tensor) in per-token mode
+        xz = make_x(23, 1, (5, K), dt)
+        xz[1] = 0.0
+        xz[3] = -0.0
+        add(f"zerorow_{dt}", "linear", xz, dt, "per-token", None)
+        add(f"zerorow_bias_{dt}", "quantscale", xz, dt, "per-token", b)
+        # per-token with one huge outlier per row (everything else quantises to ~0)
+        xo = make_x(23, 2, (4, K), dt, scale=1.0)
+        xo[:, 5] = np.array([6e4, -6e4, 3e4, 1e3], np.float32)
+        xo = t2n(torch.from_numpy(xo).to(TDT[dt]))
+        add(f"outlier_{dt}", "linear", xo, dt, "per-token", b)
+        # tiny magnitudes: fp16 absmax/127 underflows towards subnormal / zero
+        xt = (make_x(23, 3, (4, K), "f32", scale=1.0) * np.float32(2.0 ** -20)).astype(np.float32)
+        xt = t2n(torch.from_numpy(xt).to(TDT[dt]))
+        add(f"tiny_{dt}", "linear", xt, dt, "per-token", None)
+        # 3-D input [B,S,K]
+        x3 = make_x(23, 4, (6, K), dt)
+        add(f"x3d_{dt}", "quantscale", x3, dt, "per-token", b, shape3d=(2, 3, K))
+    store["index"] = np.array(index)
+    np.savez_compressed(os.path.join(HERE, "g2_edges.npz"), **store)
+    print(f"G2: {len(index)} cases")
+
+    # K = 20480 accumulator magnitude (OPT-13B fc2 depth): saturated operands
+    Kb, Nb, Mb = 20480, 8, 3
+    lin = torch.nn.Linear(Kb, Nb, bias=False)
+    Wb = np.full((Nb, Kb), 0.02, np.float32)
+    Wb[1::2] *= -1
+    Wb[:, ::7] *= 0.5
+    lin.weight.data = torch.from_numpy(Wb.copy())
+    m = RL.W8A8BFP32OFP32Linear.from_float(lin, 1.0, act_quant="per-tensor")
+    xb = np.full((Mb, Kb), 200.0, np.float32)
+    xb[1] = -200.0
+    xb[2, ::2] = -128.0
+    REC.clear()
+    out = m(torch.from_numpy(xb))
+    o_out, o_xq, _, o_acc = O.linear_forward(xb, "f32", m.weight.numpy(), m.dequant_scale.item(), None,
+                                             "per-tensor", True)
+    same(o_acc, REC["acc"].numpy(), "bigK acc")
+    same(o_out, t2n(out), "bigK out")
+    np.savez_compressed(os.path.join(HERE, "g2_bigk.npz"), x=xb.astype(np.float16).astype(np.float32),
+                        wq=m.weight.numpy(), dequant_scale=np.float32(m.dequant_scale.item()),
+                        acc=REC["acc"].numpy(), out=t2n(out))
+    assert np.array_equal(xb.astype(np.float16).astype(np.float32), xb)
+    print("G2 bigK: max|acc| =", int(np.abs(REC['acc'].numpy()).max()))
+
+
+def gen_g3():
+    """G3: from_float conversions (weight dtype f32/f16/bf16): Wq, scales, in-place side effect."""
+    store, index = {}, []
+    N, K = 48, 64
+    qkv_size = [24, 12, 12]
+    for wdt in ("f32", "f16", "bf16"):
+        Wf = t2n(torch.from_numpy(make_w(31, 0, N, K)).to(TDT[wdt]))
+        b = t2n(torch.from_numpy((detrng.normal(32, 0, (N,)) * np.float32(0.5))).to(TDT[wdt]))
+        store[f"W_{wdt}"] = Wf
+        store[f"b_{wdt}"] = b
+        for kind in ("linear", "quantscale", "qkv"):
+            for aq in ("per-tensor", "per-token"):
+                lin = torch.nn.Linear(K, N, bias=True)
+                lin.weight.data = n2t(Wf, wdt)
+                lin.bias.data = n2t(b, wdt)
+                input_scale = 0.4321
+                if kind == "linear":
+                    m = RL.W8A8BFP32OFP32Linear.from_float(lin, input_scale, act_quant=aq)
+                elif kind == "quantscale":
+                    m = RL.W8A8BFP32OFP32LinearWithQuantScale.from_float(lin, input_scale, act_quant=aq)
+                else:
+                    m = RL.W8A8BFP32OFP32QKVLinear.from_float(lin, input_scale, qkv_size, act_quant=aq)
+                name = f"{wdt}_{kind}_{aq}"
+                store[name + "_wq"] = m.weight.numpy().copy()
+                store[name + "_bias"] = m.bias.detach().numpy().copy()
+                assert m.bias.dtype == torch.float32 and m.weight.dtype == torch.int8
+                if kind == "qkv":
+                    sc = np.array([m.q_dequant_scale.item(), m.k_dequant_scale.item(), m.v_dequant_scale.item()],
+                                  np.float32)
+                    store[name + "_qkv_scales"] = sc
+                    owq, osc = O.qkv_from_float(Wf, wdt, input_scale, qkv_size, aq)
+                    same(owq, store[name + "_wq"], name + " wq")
+                    same(np.array(osc, np.float32), sc, name + " scales")
+                else:
+                    store[name + "_dequant_scale"] = np.float32(m.dequant_scale.item())
+                    assert m.dequant_scale.dtype == torch.float32
+                    owq, oal = O.linear_from_float(Wf, wdt, input_scale, aq)
+                    same(owq, store[name + "_wq"], name + " wq")
+                    same(np.float32(oal), store[name + "_dequant_scale"], name + " alpha")
+                    if kind == "quantscale" and aq == "per-tensor":
+                        store[name + "_quant_scale"] = np.float32(m.quant_scale.item())
+                        same(np.float32(input_scale), store[name + "_quant_scale"], name + " quant_scale")
+                # the reference rounds the SOURCE weight in place when it is already fp32 (quantization.py:13-16)
+                store[name + "_src_after"] = t2n(lin.weight.data)
+                index.append(f"{name}|{wdt}|{kind}|{aq}|{input_scale!r}|" + ",".join(map(str, qkv_size)))
+        # functional per-channel weight quantiser + dynamic activation quantisers (a-12)
+        wq, sc = RQ.quantize_weight_per_channel_absmax(n2t(Wf, wdt).clone())
+        store[f"pc_{wdt}_wq"] = wq.numpy().copy()
+        store[f"pc_{wdt}_scales"] = t2n(sc).reshape(-1)
+        owq, osc = O.quantize_weight_per_channel_absmax(Wf, wdt)
+        same(owq, store[f"pc_{wdt}_wq"], "per-channel wq")
+        same(osc, store[f"pc_{wdt}_scales"], "per-channel scales")
+        xa = make_x(33, 0, (7, K), wdt)
+        xa[2] = 0
+        q, mv = RQ.dynamic_quantize_activation_per_token_absmax(n2t(xa, wdt).clone())
+        store[f"dyn_tok_{wdt}_x"] = xa
+        store[f"dyn_tok_{wdt}_q"] = q.numpy().copy()
+        store[f"dyn_tok_{wdt}_s"] = t2n(mv).reshape(-1)
+        oq, omv = O.dynamic_quantize_activation_per_token_absmax(xa, wdt)
+        same(oq, store[f"dyn_tok_{wdt}_q"], "dyn per-token q")
+        same(omv.reshape(-1), store[f"dyn_tok_{wdt}_s"], "dyn per-token s")
+        q, mv = RQ.dynamic_quantize_activation_per_tensor_absmax(n2t(xa, wdt).clone())
+        store[f"dyn_ten_{wdt}_q"] = q.numpy().copy()
+        store[f"dyn_ten_{wdt}_s"] = np.float32(mv.float().item())
+        oq, omv = O.dynamic_quantize_activation_per_tensor_absmax(xa, wdt)
+        same(oq, store[f"dyn_ten_{wdt}_q"], "dyn per-tensor q")
+        same(np.float32(omv), store[f"dyn_ten_{wdt}_s"], "dyn per-tensor s")
+        # functional dequant helpers (per-channel w scales x per-token / per-tensor a scales)
+        acc = detrng.int8_uniform(34, 0, (7, N)).astype(np.int32) * 4099 + 17
+        ws = (np.abs(detrng.normal(35, 0, (N,))) * np.float32(0.01) + np.float32(1e-3)).astype(np.float32)
+        a_tok = t2n(torch.from_numpy(np.abs(detrng.normal(36, 0, (7, 1))).astype(np.float32) + 0.1).to(TDT[wdt]))
+        r = RQ.dequantize_activation_w_per_channel_a_per_token(torch.from_numpy(acc.copy()),
+                                                                torch.from_numpy(ws), n2t(a_tok, wdt))
+        store[f"dq_{wdt}_acc"] = acc
+        store[f"dq_{wdt}_ws"] = ws
+        store[f"dq_{wdt}_atok"] = a_tok.reshape(-1)
+        store[f"dq_{wdt}_tok_out"] = t2n(r)
+        same(O.dequantize_activation_w_per_channel_a_per_token(acc, ws, a_tok, wdt), t2n(r), "dq per-token")
+        a_ten = n2t(a_tok[:1, 0], wdt)
+        r = RQ.dequantize_activation_w_per_channel_a_per_tensor(torch.from_numpy(acc.copy()),
+                                                                 torch.from_numpy(ws), a_ten)
+        store[f"dq_{wdt}_ten_out"] = t2n(r)
+        same(O.dequantize_activation_w_per_channel_a_per_tensor(acc, ws, a_tok[0, 0], wdt), t2n(r), "dq per-tensor")
+    store["index"] = np.array(index)
+    np.savez_compressed(os.path.join(HERE, "g3_from_float.npz"), **store)
+    print(f"G3: {len(index)} conversions")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def gen_g4():
+    """G4: config-shaped cases from the build-owned RNG; store SHA-256 of acc/out + samples."""
+    cfgs = [
+        # name, kind, M, K, N, dt, act_quant, bias
+        ("cfg1_int8linear_4096_m4", "linear", 4, 4096, 4096, "f32", "per-tensor", False),
+        ("llama_qkv_m1", "linear", 1, 4096, 4096, "f16", "per-tensor", False),
+        ("llama_qkv_m32", "linear", 32, 4096, 4096, "f16", "per-tensor", False),
+        ("llama_o_m128", "quantscale", 128, 4096, 4096, "f16", "per-token", False),
+        ("llama_gateup_m32", "linear", 32, 4096, 11008, "bf16", "per-tensor", False),
+        ("llama_down_m32", "quantscale", 32, 11008, 4096, "f16", "per-token", False),
+        ("llama_down_pt_m32", "quantscale", 32, 11008, 4096, "f16", "per-tensor", False),
+        ("opt13b_fc2_m32", "quantscale", 32, 20480, 5120, "f16", "per-token", True),
+        ("mixtral_w1_m32", "linear", 32, 4096, 14336, "bf16", "per-tensor", False),
+        ("mixtral_w2_m32", "quantscale", 32, 14336, 4096, "bf16", "per-token", False),
+        ("mixtral_kv_m32", "linear", 32, 4096, 1024, "f16", "per-tensor", False),
+    ]
+    lines = []
+    for ci, (name, kind, M, K, N, dt, aq, use_bias) in enumerate(cfgs):
+        wq = detrng.int8_uniform(41, ci, (N, K))
+        bias = (detrng.normal(42, ci, (N,)) * np.float32(0.5)).astype(np.float32) if use_bias else None
+        x = make_x(43, ci, (M, K), dt, scale=40.0)
+        dequant_scale = np.float32(1.0 / 8192.0) * np.float32(1.0 + ci / 16.0)
+        quant_scale = np.float32(0.8125)
+        if kind == "linear":
+            m = RL.W8A8BFP32OFP32Linear(K, N, use_bias, aq)
+        else:
+            m = RL.W8A8BFP32OFP32LinearWithQuantScale(K, N, use_bias, aq)
+            if aq == "per-tensor":
+                m.quant_scale = torch.tensor(float(quant_scale), dtype=torch.float32)
+        m.weight = torch.from_numpy(wq.copy())
+        m.dequant_scale = torch.tensor(float(dequant_scale), dtype=torch.float32)
+        if use_bias:
+            m.bias = torch.from_numpy(bias.copy())
+        # fast exact stub for config sizes
+        REC.clear()
+        out = m(n2t(x, dt))
+        ref_out, ref_acc, ref_xq = t2n(out), REC["acc"].numpy(), REC["xq"].numpy()
+        if kind == "linear":
+            o = O.linear_forward(x, dt, wq, dequant_scale, bias, aq, True)
+        else:
+            o = O.linear_with_quant_scale_forward(x, dt, wq, dequant_scale, quant_scale, bias, aq, True)
+        same(o[1], ref_xq, name + " xq")
+        same(o[3], ref_acc, name + " acc")
+        same(o[0], ref_out, name + " out")
+        idx = (detrng.u64(44, ci, 64) % np.uint64(M * N)).astype(np.int64)
+        samples = ";".join(f"{int(i)}:{int(ref_acc.reshape(-1)[i])}:{float(ref_out.reshape(-1)[i])!r}" for i in idx)
+        lines.append("|".join([name, kind, str(M), str(K), str(N), dt, aq, str(int(use_bias)), str(ci),
+                               repr(float(dequant_scale)), repr(float(quant_scale)),
+                               sha(ref_xq), sha(ref_acc), sha(ref_out.astype(np.float32)), samples]))
+        print("G4", name, "ok")
+    with open(os.path.join(HERE, "g4_config_hashes.txt"), "w") as f:
+        f.write("# name|kind|M|K|N|dt|act_quant|bias|stream|dequant_scale|quant_scale|sha256(xq)|sha256(acc i32)|"
+                "sha256(out as f32)|samples flat_index:acc:out\n")
+        f.write("\n".join(lines) + "\n")
+
+
+# fast exact integer matmul for the config-sized cases (bit-identical to the int32 matmul)
+def _fast_mm(self, x, w, out):
+    if x.shape[0] >= 32 and x.shape[0] % 8 == 0:
+        out.copy_(torch._int_mm(x, w.t()))
+    else:
+        out.copy_(torch.from_numpy(O.igemm_numpy(x.numpy(), w.numpy())))
+    REC["xq"] = x.clone()
+    REC["acc"] = out.clone()
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4"]
+    if "g1" in which:
+        gen_g1()
+    if "g2" in which:
+        gen_g2()
+    if "g3" in which:
+        gen_g3()
+    if "g4" in which:
+        # cross-check the fast stub against the plain int32 matmul once, then use it
+        a = torch.from_numpy(detrng.int8_uniform(1, 1, (32, 512)))
+        b = torch.from_numpy(detrng.int8_uniform(1, 2, (64, 512)))
+        o1 = torch.empty(32, 64, dtype=torch.int32)
+        _fast_mm(None, a, b, o1)
+        assert torch.equal(o1, a.to(torch.int32) @ b.to(torch.int32).t())
+        I8CUGEMM.linear_a8_w8_o32_ = _fast_mm
+        gen_g4()
+    print("golden vectors written to", HERE)

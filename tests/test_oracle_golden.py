@@ -1,0 +1,116 @@
+"""CPU: the oracle (oracle/w8a8.py) replayed against the golden vectors captured from
+the reference's own Python hot path (tests/golden/make_golden.py).  Bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import goldenio
+from oracle import w8a8 as O
+
+
+def _fwd(c, with_intermediates=True):
+    if c["kind"] == "linear":
+        return O.linear_forward(c["x"], c["dt"], c["wq"], c["dequant_scale"], c["bias"], c["act_quant"], True)
+    if c["kind"] == "quantscale":
+        return O.linear_with_quant_scale_forward(c["x"], c["dt"], c["wq"], c["dequant_scale"],
+                                                 c.get("quant_scale"), c["bias"], c["act_quant"], True)
+    return O.qkv_linear_forward(c["x"], c["dt"], c["wq"], c["qkv_scales"], c["qkv_size"], c["bias"],
+                                c["act_quant"], True)
+
+
+G1 = goldenio.load_g1()
+G2 = goldenio.load_g2()
+
+
+@pytest.mark.parametrize("c", G1, ids=lambda c: f"g1-{c['id']}-{c['kind']}-{c['act_quant']}-{c['dt']}")
+def test_g1_matrix(c):
+    out, xq, qs, acc = _fwd(c)
+    assert np.array_equal(xq, c["xq"])
+    assert np.array_equal(acc, c["acc"])
+    assert np.array_equal(out, c["out"], equal_nan=True)
+    assert O.is_representable(out, c["dt"])
+
+
+@pytest.mark.parametrize("c", G2, ids=lambda c: f"g2-{c['id']}")
+def test_g2_edges(c):
+    out, xq, qs, acc = _fwd(c)
+    assert out.shape == c["out"].shape
+    assert np.array_equal(xq, c["xq"])
+    assert np.array_equal(acc, c["acc"])
+    assert np.array_equal(out, c["out"], equal_nan=True)
+
+
+def test_g2_bigk_accumulator_magnitude():
+    g = goldenio.load_g2_bigk()
+    out, xq, qs, acc = O.linear_forward(g["x"], "f32", g["wq"], float(g["dequant_scale"]), None, "per-tensor", True)
+    assert np.array_equal(acc, g["acc"]) and np.array_equal(out, g["out"])
+    assert np.abs(acc).max() > 2 ** 28  # well past fp32's 2^24 integer range
+    assert np.array_equal(O.igemm_c(xq, g["wq"]), g["acc"])
+
+
+def test_g3_from_float():
+    z, index = goldenio.load_g3()
+    for name, wdt, kind, aq, iscale, qkv in index:
+        W = z[f"W_{wdt}"]
+        qkv_size = [int(v) for v in qkv.split(",")]
+        if kind == "qkv":
+            wq, sc = O.qkv_from_float(W, wdt, float(iscale), qkv_size, aq)
+            assert np.array_equal(np.array(sc, np.float32), z[name + "_qkv_scales"])
+        else:
+            wq, alpha = O.linear_from_float(W, wdt, float(iscale), aq)
+            assert np.float32(alpha) == z[name + "_dequant_scale"]
+        assert np.array_equal(wq, z[name + "_wq"])
+        assert np.array_equal(z[name + "_bias"], z[f"b_{wdt}"])
+        # reference rounds the fp32 SOURCE weight in place (quantization.py:13-16); other dtypes untouched
+        if wdt == "f32" and kind != "qkv":
+            assert np.array_equal(z[name + "_src_after"], z[name + "_wq"].astype(np.float32))
+        elif wdt != "f32":
+            assert np.array_equal(z[name + "_src_after"], W)
+    for wdt in ("f32", "f16", "bf16"):
+        wq, sc = O.quantize_weight_per_channel_absmax(z[f"W_{wdt}"], wdt)
+        assert np.array_equal(wq, z[f"pc_{wdt}_wq"]) and np.array_equal(sc, z[f"pc_{wdt}_scales"])
+        q, s = O.dynamic_quantize_activation_per_token_absmax(z[f"dyn_tok_{wdt}_x"], wdt)
+        assert np.array_equal(q, z[f"dyn_tok_{wdt}_q"]) and np.array_equal(s.reshape(-1), z[f"dyn_tok_{wdt}_s"])
+        q, s = O.dynamic_quantize_activation_per_tensor_absmax(z[f"dyn_tok_{wdt}_x"], wdt)
+        assert np.array_equal(q, z[f"dyn_ten_{wdt}_q"]) and np.float32(s) == z[f"dyn_ten_{wdt}_s"]
+        r = O.dequantize_activation_w_per_channel_a_per_token(z[f"dq_{wdt}_acc"], z[f"dq_{wdt}_ws"],
+                                                              z[f"dq_{wdt}_atok"], wdt)
+        assert np.array_equal(r, z[f"dq_{wdt}_tok_out"])
+        r = O.dequantize_activation_w_per_channel_a_per_tensor(z[f"dq_{wdt}_acc"], z[f"dq_{wdt}_ws"],
+                                                               z[f"dq_{wdt}_atok"][0], wdt)
+        assert np.array_equal(r, z[f"dq_{wdt}_ten_out"])
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+G4 = goldenio.load_g4()
+
+
+@pytest.mark.parametrize("c", G4, ids=lambda c: c["id"])
+def test_g4_config_shapes(c):
+    """Config-sized cases: inputs regenerate from the build-owned RNG; SHA-256 of the
+    reference's xq / acc / out must match."""
+    x, wq, bias = goldenio.g4_inputs(c)
+    if c["kind"] == "linear":
+        out, xq, qs, acc = O.linear_forward(x, c["dt"], wq, c["dequant_scale"], bias, c["act_quant"], True)
+    else:
+        out, xq, qs, acc = O.linear_with_quant_scale_forward(x, c["dt"], wq, c["dequant_scale"], c["quant_scale"],
+                                                             bias, c["act_quant"], True)
+    assert _sha(xq) == c["sha_xq"]
+    assert _sha(acc) == c["sha_acc"]
+    assert _sha(out.astype(np.float32)) == c["sha_out"]
+    for i, a, o in c["samples"]:
+        assert int(acc.reshape(-1)[i]) == a and float(out.reshape(-1)[i]) == o
+
+
+def test_c_igemm_matches_numpy_igemm():
+    import detrng
+    for (M, N, K) in [(1, 5, 3), (7, 33, 65), (64, 48, 1024 + 17), (130, 16, 4096)]:
+        x = detrng.int8_uniform(5, M, (M, K))
+        w = detrng.int8_uniform(6, N, (N, K))
+        ref = x.astype(np.int64) @ w.astype(np.int64).T
+        assert np.array_equal(O.igemm_numpy(x, w), ref)
+        assert np.array_equal(O.igemm_c(x, w), ref)
