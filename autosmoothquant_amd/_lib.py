@@ -1,0 +1,55 @@
+"""ctypes loader for libasq_hip.so (the C-ABI declared in include/asq_hip.h)."""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libasq_hip.so")
+
+ASQ_F32, ASQ_F16, ASQ_BF16 = 0, 1, 2
+ASQ_ACT_ROUND, ASQ_ACT_DIV, ASQ_ACT_PER_TOKEN = 0, 1, 2
+ASQ_EPI_SCALE_FIRST, ASQ_EPI_ACC_FIRST = 0, 1
+
+_lock = threading.Lock()
+_lib = None
+
+_vp, _i64, _f32, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
+
+# name -> (restype, argtypes): must list every symbol include/asq_hip.h declares
+SIGNATURES = {
+    "asq_version": (_int, []),
+    "asq_last_error": (ctypes.c_char_p, []),
+    "asq_gemm_i8_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "asq_gemm_i8_i8": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _f32, _vp]),
+    "asq_quantize_act": (_int, [_vp, _int, _int, _f32, _vp, _vp, _i64, _i64, _vp]),
+    "asq_linear_w8a8": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _int, _vp]),
+    "asq_linear_w8a8_workspace_bytes": (_sz, [_i64, _i64]),
+    "asq_linear_w8a8_forward": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _int, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
+    "asq_gemm_kernel_name": (ctypes.c_char_p, [_i64, _i64, _i64]),
+}
+
+
+def lib():
+    """Load libasq_hip.so once.  Fails loudly: there is no fallback implementation."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "or `make -C autosmoothquant_amd/csrc`.  autosmoothquant_amd has no CPU/eager fallback.")
+                h = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(h, name)  # AttributeError if the .so lacks a declared symbol
+                    fn.restype, fn.argtypes = res, args
+                _lib = h
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().asq_last_error().decode("utf-8", "replace")
+        if rc < 0:
+            raise ValueError(f"{what or 'libasq_hip'}: {msg} (code {rc})")
+        raise RuntimeError(f"{what or 'libasq_hip'}: {msg} (hipError {rc})")

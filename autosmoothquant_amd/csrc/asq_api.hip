@@ -1,0 +1,53 @@
+// C-ABI plumbing + the whole-module forward (quantise -> GEMM+epilogue on one stream).
+#include "asq_common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void asq_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int asq_debug_sync()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("ASQ_DEBUG_SYNC");
+        v = (e && e[0] && e[0] != '0') ? 1 : 0;
+    }
+    return v;
+}
+
+extern "C" int asq_version(void) { return ASQ_VERSION; }
+extern "C" const char *asq_last_error(void) { return g_err; }
+
+static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// workspace layout: [ xq int8 M*K | pad to 256 | s_row f32 M ]
+extern "C" size_t asq_linear_w8a8_workspace_bytes(int64_t M, int64_t K)
+{
+    if (M < 0 || K < 0) return 0;
+    return round_up((size_t)M * (size_t)K, 256) + round_up((size_t)M * 4, 256);
+}
+
+extern "C" int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t *w, void *out, int64_t M, int64_t N, int64_t K,
+                                       int act_mode, float quant_scale, float s_scalar, const float *s_col, const float *bias,
+                                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    ASQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, ASQ_ERR_DIM, "asq_linear_w8a8_forward: bad dims");
+    if (M == 0 || N == 0) return ASQ_OK;
+    const size_t need = asq_linear_w8a8_workspace_bytes(M, K);
+    ASQ_REQUIRE(workspace != nullptr && workspace_bytes >= need, ASQ_ERR_WORKSPACE,
+                "asq_linear_w8a8_forward: workspace %zu B < required %zu B", workspace_bytes, need);
+    ASQ_REQUIRE(((uintptr_t)workspace & 255) == 0, ASQ_ERR_ALIGN, "asq_linear_w8a8_forward: workspace must be 256-B aligned");
+    int8_t *xq = (int8_t *)workspace;
+    float *s_row = (float *)((char *)workspace + round_up((size_t)M * (size_t)K, 256));
+    int rc = asq_quantize_act(x, x_dtype, act_mode, quant_scale, xq, s_row, M, K, stream);
+    if (rc) return rc;
+    return asq_linear_w8a8(xq, w, out, x_dtype, M, N, K, s_scalar, act_mode == ASQ_ACT_PER_TOKEN ? s_row : nullptr, s_col, bias,
+                           ASQ_EPI_SCALE_FIRST, stream);
+}

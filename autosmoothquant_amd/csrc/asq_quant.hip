@@ -1,0 +1,245 @@
+// Activation quantisers: the GEMM prologue of autosmoothquant/layers/nn/linear.py
+// (reference :88-96, :164-174, :283-292), one memory-bound pass each.
+//
+// HBM traffic per activation element: sizeof(x) read + 1 B written (+4 B per row for the
+// per-token scale).  The reference spends >= 37 B/element on the same work (abs, max, div,
+// cast, div, round, clamp, cast as separate ATen launches).
+#include "asq_common.h"
+
+namespace {
+
+// ---- per-element quantisation cores (bit-exact restatements; see oracle/w8a8.py) -------
+template <int DT> struct QRound {  // x.round().clamp().to(int8)
+    __device__ __forceinline__ int operator()(float x) const { return quant_i8(x); }
+};
+template <int DT> struct QDiv {  // (x / scalar) stays in x's dtype, then round/clamp
+    float s;
+    __device__ __forceinline__ int operator()(float x) const { return quant_i8(ElemT<DT>::round(x / s)); }
+};
+template <int DT> struct QDivF32 {  // x / f32 tensor promotes to fp32
+    float s;
+    __device__ __forceinline__ int operator()(float x) const { return quant_i8(x / s); }
+};
+
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d)
+{
+    return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) | ((uint32_t)(d & 0xFF) << 24);
+}
+
+// quantise one 16-byte vector of DT -> VEC int8 packed in up to 2 dwords
+template <int DT, class Q> __device__ __forceinline__ void quant_vec(const v4i &v, const Q &q, uint32_t (&o)[2])
+{
+    if constexpr (DT == ASQ_F32) {
+        o[0] = pack4(q(__int_as_float(v[0])), q(__int_as_float(v[1])), q(__int_as_float(v[2])), q(__int_as_float(v[3])));
+        o[1] = 0;
+    } else {
+        int r[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t w = (uint32_t)v[i];
+            r[2 * i] = q(ElemT<DT>::load((uint16_t)(w & 0xFFFF)));
+            r[2 * i + 1] = q(ElemT<DT>::load((uint16_t)(w >> 16)));
+        }
+        o[0] = pack4(r[0], r[1], r[2], r[3]);
+        o[1] = pack4(r[4], r[5], r[6], r[7]);
+    }
+}
+
+template <int DT> __device__ __forceinline__ float vec_absmax(const v4i &v)
+{
+    float m = 0.0f;
+    if constexpr (DT == ASQ_F32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float a = fabsf(__int_as_float(v[i]));
+            m = (a != a) ? a : ((m != m) ? m : fmaxf(m, a));  // NaN-propagating max, as torch.max
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t w = (uint32_t)v[i];
+            float a = fabsf(ElemT<DT>::load((uint16_t)(w & 0xFFFF)));
+            float b = fabsf(ElemT<DT>::load((uint16_t)(w >> 16)));
+            m = (a != a) ? a : ((m != m) ? m : fmaxf(m, a));
+            m = (b != b) ? b : ((m != m) ? m : fmaxf(m, b));
+        }
+    }
+    return m;
+}
+
+__device__ __forceinline__ float nanmax(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
+
+__device__ __forceinline__ float block_max_256(float m, float *red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = nanmax(m, __shfl_xor(m, off, 64));
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = m;
+    __syncthreads();
+    return nanmax(nanmax(red[0], red[1]), nanmax(red[2], red[3]));
+}
+
+// ---- per-token: one 256-thread block per row, row cached in registers ---------------
+// K % VEC == 0, K <= 256*VEC*NV, x and xq rows 16-/VEC-byte aligned.
+template <int DT, int NV>
+__global__ void __launch_bounds__(256) quant_per_token_cached(const void *__restrict__ xv, int8_t *__restrict__ xq,
+                                                              float *__restrict__ s_row, int K)
+{
+    constexpr int VEC = ElemT<DT>::VEC;
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const char *xrow = (const char *)xv + row * (int64_t)K * (16 / VEC);
+    const int nvec = K / VEC;
+    v4i v[NV];
+    float m = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = i * 256 + threadIdx.x;
+        if (idx < nvec) {
+            v[i] = *(const v4i *)(xrow + (int64_t)idx * 16);
+            m = nanmax(m, vec_absmax<DT>(v[i]));
+        }
+    }
+    m = block_max_256(m, red);
+    // quant_scale = absmax.div(127.0) in x's dtype, widened to fp32 (linear.py:89-91)
+    const float qs = ElemT<DT>::round(m / 127.0f);
+    if (threadIdx.x == 0) s_row[row] = qs;
+    QDivF32<DT> q{qs};
+    int8_t *orow = xq + row * (int64_t)K;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = i * 256 + threadIdx.x;
+        if (idx < nvec) {
+            uint32_t o[2];
+            quant_vec<DT>(v[i], q, o);
+            if constexpr (DT == ASQ_F32) {
+                *(uint32_t *)(orow + (int64_t)idx * 4) = o[0];
+            } else {
+                *(uint2 *)(orow + (int64_t)idx * 8) = make_uint2(o[0], o[1]);
+            }
+        }
+    }
+}
+
+// ---- per-token, any K / alignment: two passes over the row (second pass hits L1/L2) ----
+template <int DT>
+__global__ void __launch_bounds__(256) quant_per_token_generic(const void *__restrict__ xv, int8_t *__restrict__ xq,
+                                                               float *__restrict__ s_row, int64_t K)
+{
+    using T = typename ElemT<DT>::type;
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const T *xrow = (const T *)xv + row * K;
+    float m = 0.0f;
+    for (int64_t k = threadIdx.x; k < K; k += 256) m = nanmax(m, fabsf(ElemT<DT>::load(xrow[k])));
+    m = block_max_256(m, red);
+    const float qs = ElemT<DT>::round(m / 127.0f);
+    if (threadIdx.x == 0) s_row[row] = qs;
+    int8_t *orow = xq + row * K;
+    for (int64_t k = threadIdx.x; k < K; k += 256) orow[k] = (int8_t)quant_i8(ElemT<DT>::load(xrow[k]) / qs);
+}
+
+// ---- per-tensor (round / div): flat elementwise, 16 elements per thread ------------
+template <int DT, class Q>
+__global__ void __launch_bounds__(256) quant_flat_vec(const void *__restrict__ xv, int8_t *__restrict__ xq, int64_t nchunk, Q q)
+{
+    constexpr int VEC = ElemT<DT>::VEC;
+    constexpr int NL = 16 / VEC;  // 16-byte loads per 16 elements
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < nchunk; c += (int64_t)gridDim.x * 256) {
+        const v4i *src = (const v4i *)xv + c * NL;
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            v4i v = src[i];
+            uint32_t t[2];
+            quant_vec<DT>(v, q, t);
+            if constexpr (DT == ASQ_F32) {
+                o[i] = t[0];
+            } else {
+                o[2 * i] = t[0];
+                o[2 * i + 1] = t[1];
+            }
+        }
+        *((uint4 *)xq + c) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <int DT, class Q>
+__global__ void __launch_bounds__(256) quant_flat_scalar(const void *__restrict__ xv, int8_t *__restrict__ xq, int64_t begin, int64_t n, Q q)
+{
+    using T = typename ElemT<DT>::type;
+    const T *x = (const T *)xv;
+    for (int64_t i = begin + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        xq[i] = (int8_t)q(ElemT<DT>::load(x[i]));
+}
+
+template <int DT, class Q> int launch_flat(const void *x, int8_t *xq, int64_t n, Q q, hipStream_t s)
+{
+    const bool aligned = (((uintptr_t)x | (uintptr_t)xq) & 15) == 0;
+    int64_t done = 0;
+    if (aligned && n >= 16) {
+        const int64_t nchunk = n / 16;
+        int64_t blocks = (nchunk + 255) / 256;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL((quant_flat_vec<DT, Q>), dim3((unsigned)blocks), dim3(256), 0, s, x, xq, nchunk, q);
+        done = nchunk * 16;
+    }
+    if (done < n) {
+        int64_t rem = n - done;
+        int64_t blocks = (rem + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL((quant_flat_scalar<DT, Q>), dim3((unsigned)blocks), dim3(256), 0, s, x, xq, done, n, q);
+    }
+    return asq_after_launch(s, "asq_quantize_act(per-tensor)");
+}
+
+template <int DT> int launch_per_token(const void *x, int8_t *xq, float *s_row, int64_t M, int64_t K, hipStream_t s)
+{
+    constexpr int VEC = ElemT<DT>::VEC;
+    const bool vec_ok = (K % VEC == 0) && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)xq) & (VEC - 1)) == 0);
+    const int64_t nvec = K / VEC;
+    dim3 grid((unsigned)M), block(256);
+#define ASQ_PT(NV)                                                                                          \
+    hipLaunchKernelGGL((quant_per_token_cached<DT, NV>), grid, block, 0, s, x, xq, s_row, (int)K)
+    if (vec_ok && nvec <= 256 * 1) ASQ_PT(1);
+    else if (vec_ok && nvec <= 256 * 2) ASQ_PT(2);
+    else if (vec_ok && nvec <= 256 * 4) ASQ_PT(4);
+    else if (vec_ok && nvec <= 256 * 6) ASQ_PT(6);
+    else if (vec_ok && nvec <= 256 * 8) ASQ_PT(8);
+    else if (vec_ok && nvec <= 256 * 12) ASQ_PT(12);
+    else if (vec_ok && nvec <= 256 * 20) ASQ_PT(20);
+    else hipLaunchKernelGGL((quant_per_token_generic<DT>), grid, block, 0, s, x, xq, s_row, K);
+#undef ASQ_PT
+    return asq_after_launch(s, "asq_quantize_act(per-token)");
+}
+
+template <int DT> int quantize_dt(const void *x, int mode, float quant_scale, int8_t *xq, float *s_row, int64_t M, int64_t K,
+                                  hipStream_t s)
+{
+    switch (mode) {
+    case ASQ_ACT_ROUND: return launch_flat<DT>(x, xq, M * K, QRound<DT>{}, s);
+    case ASQ_ACT_DIV: return launch_flat<DT>(x, xq, M * K, QDiv<DT>{quant_scale}, s);
+    default: return launch_per_token<DT>(x, xq, s_row, M, K, s);
+    }
+}
+
+}  // namespace
+
+extern "C" int asq_quantize_act(const void *x, int x_dtype, int mode, float quant_scale, int8_t *xq, float *s_row,
+                                int64_t M, int64_t K, void *stream)
+{
+    ASQ_REQUIRE(M >= 0 && K >= 0 && M < (1ll << 31), ASQ_ERR_DIM, "asq_quantize_act: bad dims M=%lld K=%lld", (long long)M, (long long)K);
+    ASQ_REQUIRE(x_dtype == ASQ_F32 || x_dtype == ASQ_F16 || x_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_quantize_act: bad x_dtype %d", x_dtype);
+    ASQ_REQUIRE(mode == ASQ_ACT_ROUND || mode == ASQ_ACT_DIV || mode == ASQ_ACT_PER_TOKEN, ASQ_ERR_DTYPE, "asq_quantize_act: bad mode %d", mode);
+    if (M == 0 || (K == 0 && mode != ASQ_ACT_PER_TOKEN)) return ASQ_OK;
+    ASQ_REQUIRE(xq != nullptr && (x != nullptr || K == 0), ASQ_ERR_NULL, "asq_quantize_act: NULL x / xq");
+    ASQ_REQUIRE(mode != ASQ_ACT_PER_TOKEN || s_row != nullptr, ASQ_ERR_NULL, "asq_quantize_act: per-token needs s_row");
+    ASQ_REQUIRE(((uintptr_t)x % asq_dtype_size(x_dtype)) == 0, ASQ_ERR_ALIGN, "asq_quantize_act: x misaligned for its dtype");
+    ASQ_REQUIRE(mode != ASQ_ACT_PER_TOKEN || ((uintptr_t)s_row % 4) == 0, ASQ_ERR_ALIGN, "asq_quantize_act: s_row misaligned");
+    hipStream_t s = (hipStream_t)stream;
+    switch (x_dtype) {
+    case ASQ_F32: return quantize_dt<ASQ_F32>(x, mode, quant_scale, xq, s_row, M, K, s);
+    case ASQ_F16: return quantize_dt<ASQ_F16>(x, mode, quant_scale, xq, s_row, M, K, s);
+    default: return quantize_dt<ASQ_BF16>(x, mode, quant_scale, xq, s_row, M, K, s);
+    }
+}

@@ -1,0 +1,143 @@
+"""Thin torch-tensor wrappers over the C-ABI (device memory + current stream plumbing).
+
+Every function validates dtype / device / contiguity / shape and raises instead of
+falling back: the reference passes raw ``data_ptr`` with no checks (bindings.cpp:73-80)."""
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.ASQ_F32, torch.float16: L.ASQ_F16, torch.bfloat16: L.ASQ_BF16}
+_ACT = {"per-tensor-round": L.ASQ_ACT_ROUND, "per-tensor-div": L.ASQ_ACT_DIV, "per-token": L.ASQ_ACT_PER_TOKEN}
+
+
+def _dev(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: autosmoothquant_amd ops need a HIP (cuda:N) tensor; there is no CPU fallback")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _same_device(*ts):
+    d = None
+    for t in ts:
+        if t is None:
+            continue
+        if d is None:
+            d = t.device
+        elif t.device != d:
+            raise RuntimeError(f"tensors on different devices: {d} vs {t.device}")
+    return d
+
+
+def gemm_i8_i32(x, w, out):
+    """out[M,N] i32 = x[M,K] i8 . w[N,K]^T i8  (K1, bindings.cpp:69-84)."""
+    _dev(x, "input"), _dev(w, "weight"), _dev(out, "out")
+    if x.dtype != torch.int8 or w.dtype != torch.int8 or out.dtype != torch.int32:
+        raise RuntimeError("expected int8 input, int8 weight, int32 out")
+    if x.dim() != 2 or w.dim() != 2 or x.shape[1] != w.shape[1] or tuple(out.shape) != (x.shape[0], w.shape[0]):
+        raise ValueError(f"shape mismatch: input {tuple(x.shape)}, weight {tuple(w.shape)}, out {tuple(out.shape)}")
+    dev = _same_device(x, w, out)
+    with torch.cuda.device(dev):
+        L.check(L.lib().asq_gemm_i8_i32(x.data_ptr(), w.data_ptr(), out.data_ptr(), x.shape[0], w.shape[0], x.shape[1], _stream(x)),
+                "asq_gemm_i8_i32")
+    return out
+
+
+def gemm_i8_i8(x, w, out, alpha, beta=0.0):
+    """out[M,N] i8 = sat(rne(alpha*acc + beta*out))  (K3-K5, bindings.cpp:86-142)."""
+    _dev(x, "input"), _dev(w, "weight"), _dev(out, "out")
+    if x.dtype != torch.int8 or w.dtype != torch.int8 or out.dtype != torch.int8:
+        raise RuntimeError("expected int8 input, weight and out")
+    if x.dim() != 2 or w.dim() != 2 or x.shape[1] != w.shape[1] or tuple(out.shape) != (x.shape[0], w.shape[0]):
+        raise ValueError(f"shape mismatch: input {tuple(x.shape)}, weight {tuple(w.shape)}, out {tuple(out.shape)}")
+    dev = _same_device(x, w, out)
+    with torch.cuda.device(dev):
+        L.check(L.lib().asq_gemm_i8_i8(x.data_ptr(), w.data_ptr(), out.data_ptr(), x.shape[0], w.shape[0], x.shape[1],
+                                       float(alpha), float(beta), _stream(x)), "asq_gemm_i8_i8")
+    return out
+
+
+def quantize_act(x, mode, quant_scale=1.0):
+    """x [M,K] f32/f16/bf16 -> (xq int8 [M,K], s_row f32 [M] or None).  mode in
+    {"per-token", "per-tensor-round", "per-tensor-div"} (linear.py:88-96, 283-292)."""
+    _dev(x, "x")
+    if x.dtype not in _DT or x.dim() != 2:
+        raise ValueError("x must be a 2-D float32/float16/bfloat16 tensor")
+    M, K = x.shape
+    xq = torch.empty((M, K), dtype=torch.int8, device=x.device)
+    s_row = torch.empty((M,), dtype=torch.float32, device=x.device) if mode == "per-token" else None
+    with torch.cuda.device(x.device):
+        L.check(L.lib().asq_quantize_act(x.data_ptr(), _DT[x.dtype], _ACT[mode], float(quant_scale), xq.data_ptr(), _ptr(s_row),
+                                         M, K, _stream(x)), "asq_quantize_act")
+    return xq, s_row
+
+
+def linear_w8a8(xq, w, out_dtype, s_scalar=1.0, s_row=None, s_col=None, bias=None, order="scale_first", out=None):
+    """Fused GEMM + dequant/bias epilogue: out[M,N] = (s_col|s_scalar)[*s_row] * f32(xq.w^T) + bias."""
+    _dev(xq, "xq"), _dev(w, "weight")
+    if xq.dtype != torch.int8 or w.dtype != torch.int8 or xq.dim() != 2 or w.dim() != 2 or xq.shape[1] != w.shape[1]:
+        raise ValueError("xq [M,K] and weight [N,K] must be int8 with equal K")
+    M, K = xq.shape
+    N = w.shape[0]
+    for name, t, n in (("s_row", s_row, M), ("s_col", s_col, N), ("bias", bias, N)):
+        if t is not None:
+            _dev(t, name)
+            if t.dtype != torch.float32 or t.numel() != n:
+                raise ValueError(f"{name} must be float32 with {n} elements")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=xq.device)
+    else:
+        _dev(out, "out")
+        if out.dtype != out_dtype or tuple(out.shape) != (M, N):
+            raise ValueError("out has wrong dtype/shape")
+    dev = _same_device(xq, w, out, s_row, s_col, bias)
+    with torch.cuda.device(dev):
+        L.check(L.lib().asq_linear_w8a8(xq.data_ptr(), w.data_ptr(), out.data_ptr(), _DT[out_dtype], M, N, K, float(s_scalar),
+                                        _ptr(s_row), _ptr(s_col), _ptr(bias),
+                                        L.ASQ_EPI_SCALE_FIRST if order == "scale_first" else L.ASQ_EPI_ACC_FIRST, _stream(xq)),
+                "asq_linear_w8a8")
+    return out
+
+
+def linear_w8a8_forward(x2d, w, act_mode, quant_scale, s_scalar, s_col=None, bias=None):
+    """Whole module forward on a 2-D activation: quantise -> GEMM + epilogue, one stream,
+    no int32 round trip.  Returns out [M,N] in x's dtype."""
+    _dev(x2d, "x"), _dev(w, "weight")
+    if x2d.dtype not in _DT:
+        raise ValueError(f"unsupported activation dtype {x2d.dtype}")
+    if w.dtype != torch.int8 or x2d.dim() != 2 or w.dim() != 2 or x2d.shape[1] != w.shape[1]:
+        raise ValueError(f"shape/dtype mismatch: x {tuple(x2d.shape)} {x2d.dtype}, weight {tuple(w.shape)} {w.dtype}")
+    M, K = x2d.shape
+    N = w.shape[0]
+    for name, t in (("s_col", s_col), ("bias", bias)):
+        if t is not None:
+            _dev(t, name)
+            if t.dtype != torch.float32 or t.numel() != N:
+                raise ValueError(f"{name} must be float32 with {N} elements")
+    dev = _same_device(x2d, w, s_col, bias)
+    out = torch.empty((M, N), dtype=x2d.dtype, device=dev)
+    if M == 0 or N == 0:
+        return out
+    lib = L.lib()
+    nbytes = lib.asq_linear_w8a8_workspace_bytes(M, K)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)  # caching allocator: 512-B aligned, stream-ordered
+    with torch.cuda.device(dev):
+        L.check(lib.asq_linear_w8a8_forward(x2d.data_ptr(), _DT[x2d.dtype], w.data_ptr(), out.data_ptr(), M, N, K,
+                                            _ACT[act_mode], float(quant_scale), float(s_scalar), _ptr(s_col), _ptr(bias),
+                                            ws.data_ptr(), nbytes, _stream(x2d)), "asq_linear_w8a8_forward")
+    return out
+
+
+def gemm_kernel_name(M, N, K):
+    return L.lib().asq_gemm_kernel_name(M, N, K).decode()

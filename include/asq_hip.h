@@ -1,0 +1,115 @@
+/*
+ * asq_hip.h -- C-ABI of libasq_hip.so: the MI355X (gfx950 / CDNA4) implementation of
+ * AutoSmoothQuant's W8A8 linear hot path.
+ *
+ * This is the drop-in boundary.  Each entry point names the reference interface it
+ * replaces (paths are into the upstream AutoSmoothQuant tree):
+ *
+ *   csrc/int8gemm/bindings.cpp:145-155   pybind class I8CUGEMM (5 methods)
+ *   autosmoothquant/layers/nn/linear.py  the eager-PyTorch quantise / dequantise code
+ *                                        around the GEMM (:83-106, :158-208, :278-302)
+ *
+ * Conventions
+ *   - plain pointers + sizes; no torch / pybind types.  All pointers are DEVICE pointers
+ *     on the current HIP device unless stated otherwise.  Tensors are dense row-major.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  The library
+ *     keeps no state: no handle, no lock, no captured stream (the reference captures one
+ *     stream at construction, bindings.cpp:13, and serialises callers on a mutex,
+ *     cublasINT8MMWrapper.cc:228,353 -- deliberately not reproduced).
+ *   - every call returns an int status: 0 = ok, <0 = argument error (ASQ_ERR_*),
+ *     >0 = hipError_t from the launch.  asq_last_error() returns a thread-local message.
+ *   - nothing is allocated inside; calls that need scratch take a caller-owned workspace.
+ *   - env ASQ_DEBUG_SYNC=1: hipStreamSynchronize + error check after every launch (the
+ *     analogue of FT_DEBUG_LEVEL=DEBUG, csrc/int8gemm/cuda_utils.h:88-104).
+ */
+#ifndef ASQ_HIP_H
+#define ASQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASQ_VERSION 100 /* 0.1.0 */
+
+/* element types of floating tensors crossing the boundary */
+#define ASQ_F32 0
+#define ASQ_F16 1
+#define ASQ_BF16 2
+
+/* activation-quantisation mode (the `act_quant` ctor argument + class of the module) */
+#define ASQ_ACT_ROUND 0     /* per-tensor, scale folded upstream: round+clamp only (linear.py:95-96,174) */
+#define ASQ_ACT_DIV 1       /* per-tensor, x / quant_scale in x's dtype (linear.py:289-292)               */
+#define ASQ_ACT_PER_TOKEN 2 /* per-token dynamic absmax/127 (linear.py:88-92,164-168,283-287)            */
+
+/* association order of the dequant epilogue */
+#define ASQ_EPI_SCALE_FIRST 0 /* (s_col*s_row) * float(acc) + bias   -- nn modules, linear.py:93,104,200-206 */
+#define ASQ_EPI_ACC_FIRST 1   /* (float(acc)*s_col) * s_row  + bias  -- functional/quantization.py:103-120   */
+
+/* status codes */
+#define ASQ_OK 0
+#define ASQ_ERR_NULL (-1)      /* required pointer is NULL          */
+#define ASQ_ERR_DIM (-2)       /* negative / overflowing dimension  */
+#define ASQ_ERR_DTYPE (-3)     /* unknown dtype / mode enum         */
+#define ASQ_ERR_ALIGN (-4)     /* pointer not aligned to its element */
+#define ASQ_ERR_WORKSPACE (-5) /* workspace missing or too small    */
+
+int asq_version(void);
+const char *asq_last_error(void);
+
+/* ---- K1: I8CUGEMM::linear_a8_w8_o32_  (bindings.cpp:69-84 -> cublasINT8MMWrapper.cc:224-354)
+ * out[M,N] (int32) = x[M,K] (int8) . w[N,K]^T (int8); alpha=1, beta=0; exact.
+ * Also serves I8CUGEMM::linear_a8_w8_o32 (bindings.cpp:52-67): that flavour differs only in
+ * cuBLASLt's COL32 operand layouts, which have no gfx950 counterpart. */
+int asq_gemm_i8_i32(const int8_t *x, const int8_t *w, int32_t *out,
+                    int64_t M, int64_t N, int64_t K, void *stream);
+
+/* ---- K3/K4/K5: I8CUGEMM::linear_a8_w8_o8 / linear_a8_w8_o8_ / linear_a8_w8_b8_o8_
+ * (bindings.cpp:86-142 -> cublasINT8MMWrapper.cc:360-672)
+ * out[M,N] (int8) = sat_i8(round_half_even(alpha * float(acc) + beta * float(c)))
+ * c = the previous contents of `out` when beta != 0 (cuBLASLt C==D in-place), ignored when beta == 0.
+ * For linear_a8_w8_b8_o8_ the caller pre-fills out with the broadcast int8 bias (bindings.cpp:132). */
+int asq_gemm_i8_i8(const int8_t *x, const int8_t *w, int8_t *out,
+                   int64_t M, int64_t N, int64_t K, float alpha, float beta, void *stream);
+
+/* ---- GEMM prologue: the activation quantisers of layers/nn/linear.py
+ * x is [M,K] of x_dtype.  xq is int8 [M,K].
+ * ASQ_ACT_PER_TOKEN: s_row[m] = (absmax_k x[m,k] / 127 in x_dtype) as f32;
+ *                    xq = int8(clamp(rne(f32(x) / s_row[m]), -128, 127)); s_row required.
+ * ASQ_ACT_ROUND    : xq = int8(clamp(rne(x), -128, 127));           quant_scale, s_row ignored.
+ * ASQ_ACT_DIV      : xq = int8(clamp(rne(x_dtype(f32(x) / quant_scale)), -128, 127)).
+ * NaN quantises to 0 and +-inf saturates, as on the reference's CPU path. */
+int asq_quantize_act(const void *x, int x_dtype, int mode, float quant_scale,
+                     int8_t *xq, float *s_row, int64_t M, int64_t K, void *stream);
+
+/* ---- fused GEMM + dequant/bias epilogue (replaces the i32 round trip of linear.py:97-105;
+ * subsumes csrc/kernels/linear.cu:201-291 `linear_a8_w8_bfp32_ofp32`)
+ * out[M,N] (out_dtype) = epi(acc[m,n]) where acc = xq . w^T (int32, exact)
+ *   ds    = (s_col ? s_col[n] : s_scalar) [* s_row[m] if s_row]
+ *   out   = ds * float(acc) (+ bias[n])         (ASQ_EPI_SCALE_FIRST; two fp32 roundings, no FMA)
+ * s_row f32[M] (per-token) | NULL;  s_col f32[N] (per-channel / QKV segments) | NULL;  bias f32[N] | NULL */
+int asq_linear_w8a8(const int8_t *xq, const int8_t *w, void *out, int out_dtype,
+                    int64_t M, int64_t N, int64_t K,
+                    float s_scalar, const float *s_row, const float *s_col, const float *bias,
+                    int epi_order, void *stream);
+
+/* ---- whole module forward: W8A8BFP32OFP32Linear / ...QKVLinear / ...LinearWithQuantScale .forward
+ * (linear.py:83-106, :158-208, :278-302) = asq_quantize_act + asq_linear_w8a8 on `stream`.
+ * out has x's dtype.  workspace: asq_linear_w8a8_workspace_bytes(M,K) bytes, 256-B aligned. */
+size_t asq_linear_w8a8_workspace_bytes(int64_t M, int64_t K);
+int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t *w, void *out,
+                            int64_t M, int64_t N, int64_t K,
+                            int act_mode, float quant_scale,
+                            float s_scalar, const float *s_col, const float *bias,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- introspection for tests / bench: which GEMM kernel the dispatcher picks for a shape.
+ * Returns a static string ("t256", "generic", ...). */
+const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASQ_HIP_H */

@@ -360,3 +360,27 @@ def fold_norm_weight(norm_weight, dt, input_scale: float):
     (python-float divisor: stays in weight's dtype)."""
     w = np.asarray(norm_weight, np.float32)
     return round_to(w / np.float32(input_scale), dt)
+
+
+# --------------------------------------------------------------------------
+# optional fast exact backends for the CPU-baseline leg of bench.py
+# --------------------------------------------------------------------------
+def igemm_torch(xq: np.ndarray, wq: np.ndarray) -> np.ndarray:
+    """torch._int_mm (oneDNN int8 -> int32, exact) -- the "torch int8 matmul" the reference's
+    CPU path would use; falls back to an int32 matmul for shapes _int_mm rejects."""
+    import torch
+    a = torch.from_numpy(np.ascontiguousarray(xq, dtype=np.int8))
+    b = torch.from_numpy(np.ascontiguousarray(wq, dtype=np.int8))
+    try:
+        return torch._int_mm(a, b.t()).numpy()
+    except RuntimeError:
+        return (a.to(torch.int32) @ b.to(torch.int32).t()).numpy()
+
+
+_BACKENDS = {"numpy": igemm_numpy, "c": igemm_c, "torch": igemm_torch}
+
+
+def set_igemm_backend(name: str):
+    """Select the exact-integer GEMM used by the module forwards (all are bit-identical)."""
+    global igemm
+    igemm = _BACKENDS[name]

@@ -1,0 +1,129 @@
+"""CPU: the C-ABI library loads, exports every symbol include/asq_hip.h declares, argument
+validation works without a GPU, and the host-side module mirror keeps the reference's
+checkpoint contract.  No compute is launched."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "asq_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(asq_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from autosmoothquant_amd import _lib
+    h = _lib.lib()
+    names = _declared_symbols()
+    assert len(names) >= 9
+    for n in names:
+        assert hasattr(h, n), f"libasq_hip.so lacks {n}"
+        assert n in _lib.SIGNATURES, f"_lib.SIGNATURES lacks {n}"
+    assert sorted(_lib.SIGNATURES) == names
+    assert h.asq_version() == 100
+
+
+def test_argument_errors_without_gpu():
+    from autosmoothquant_amd import _lib
+    h = _lib.lib()
+    assert h.asq_gemm_i8_i32(None, None, None, -1, 4, 4, None) == -2          # ASQ_ERR_DIM
+    assert b"bad dims" in h.asq_last_error()
+    assert h.asq_gemm_i8_i32(None, None, None, 4, 4, 4, None) == -1           # ASQ_ERR_NULL
+    assert h.asq_quantize_act(None, 7, 0, 1.0, None, None, 1, 1, None) == -3  # ASQ_ERR_DTYPE
+    assert h.asq_linear_w8a8_forward(None, 1, None, None, 4, 4, 4, 0, 1.0, 1.0, None, None, None, 0, None) == -5
+    assert h.asq_gemm_i8_i32(None, None, None, 0, 4, 4, None) == 0            # empty problem is a no-op
+    assert h.asq_linear_w8a8_workspace_bytes(3, 5) == 256 + 256
+    assert h.asq_gemm_kernel_name(4096, 4096, 4096) == b"t256"
+    assert h.asq_gemm_kernel_name(4, 4096, 4095) == b"generic"
+
+
+def test_ops_refuse_cpu_tensors_loudly():
+    from autosmoothquant_amd import ops
+    from autosmoothquant_amd._CUDA import I8CUGEMM
+    x = torch.zeros(4, 16, dtype=torch.int8)
+    w = torch.zeros(8, 16, dtype=torch.int8)
+    out = torch.zeros(4, 8, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        I8CUGEMM().linear_a8_w8_o32_(x, w, out)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.quantize_act(torch.zeros(2, 8), "per-token")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from autosmoothquant_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
+        _lib.lib()
+
+
+def test_module_checkpoint_contract():
+    from autosmoothquant_amd.layers.nn.linear import (Int8GEMM, W8A8BFP32OFP32Linear, W8A8BFP32OFP32LinearWithQuantScale,
+                                                      W8A8BFP32OFP32QKVLinear)
+    assert Int8GEMM() is Int8GEMM()
+    m = W8A8BFP32OFP32Linear(64, 48, True, "per-token")
+    sd = m.state_dict()
+    assert sorted(sd) == ["bias", "dequant_scale", "weight"]
+    assert sd["weight"].dtype == torch.int8 and tuple(sd["weight"].shape) == (48, 64)
+    assert sd["bias"].dtype == torch.float32 and sd["dequant_scale"].dtype == torch.float32 and sd["dequant_scale"].dim() == 0
+    assert sorted(W8A8BFP32OFP32Linear(64, 48).state_dict()) == ["dequant_scale", "weight"]
+    q = W8A8BFP32OFP32QKVLinear([24, 12, 12], 64, 48, False, "per-tensor")
+    assert sorted(q.state_dict()) == ["k_dequant_scale", "q_dequant_scale", "v_dequant_scale", "weight"]
+    s = W8A8BFP32OFP32LinearWithQuantScale(64, 48, True, "per-tensor")
+    assert sorted(s.state_dict()) == ["bias", "dequant_scale", "quant_scale", "weight"]
+    assert sorted(W8A8BFP32OFP32LinearWithQuantScale(64, 48, False, "per-token").state_dict()) == ["dequant_scale", "weight"]
+    with pytest.raises(AssertionError):
+        W8A8BFP32OFP32Linear(4, 4, False, "per-channel")
+    # .half() keeps fp32 bias and host-side fp32 scalar scales; state dict round-trips
+    s.half()
+    assert s.bias.dtype == torch.float32 and s.dequant_scale.dtype == torch.float32 and s.quant_scale.device.type == "cpu"
+    s2 = W8A8BFP32OFP32LinearWithQuantScale(64, 48, True, "per-tensor")
+    s.dequant_scale.fill_(0.25)
+    s2.load_state_dict(s.state_dict())
+    assert float(s2.dequant_scale) == 0.25
+
+
+def test_from_float_matches_golden():
+    """Weight-side conversion (reference linear.py:108-129, 210-245, 304-329) against G3."""
+    import numpy as np
+    import goldenio
+    from autosmoothquant_amd.layers.nn.linear import (W8A8BFP32OFP32Linear, W8A8BFP32OFP32LinearWithQuantScale,
+                                                      W8A8BFP32OFP32QKVLinear)
+    from autosmoothquant_amd.layers.functional import quantization as Q
+    TDT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+    z, index = goldenio.load_g3()
+    for name, wdt, kind, aq, iscale, qkv in index:
+        lin = torch.nn.Linear(64, 48, bias=True)
+        lin.weight.data = torch.from_numpy(z[f"W_{wdt}"].copy()).to(TDT[wdt])
+        lin.bias.data = torch.from_numpy(z[f"b_{wdt}"].copy()).to(TDT[wdt])
+        qkv_size = [int(v) for v in qkv.split(",")]
+        if kind == "linear":
+            m = W8A8BFP32OFP32Linear.from_float(lin, float(iscale), act_quant=aq)
+        elif kind == "quantscale":
+            m = W8A8BFP32OFP32LinearWithQuantScale.from_float(lin, float(iscale), act_quant=aq)
+        else:
+            m = W8A8BFP32OFP32QKVLinear.from_float(lin, float(iscale), qkv_size, act_quant=aq)
+        assert np.array_equal(m.weight.numpy(), z[name + "_wq"]), name
+        assert np.array_equal(m.bias.detach().numpy(), z[name + "_bias"]) and m.bias.dtype == torch.float32
+        if kind == "qkv":
+            got = np.array([float(m.q_dequant_scale), float(m.k_dequant_scale), float(m.v_dequant_scale)], np.float32)
+            assert np.array_equal(got, z[name + "_qkv_scales"]), name
+        else:
+            assert np.float32(float(m.dequant_scale)) == z[name + "_dequant_scale"], name
+            if kind == "quantscale" and aq == "per-tensor":
+                assert np.float32(float(m.quant_scale)) == z[name + "_quant_scale"]
+        assert np.array_equal(lin.weight.data.float().numpy(), z[name + "_src_after"]), name + " side effect"
+    for wdt in ("f32", "f16", "bf16"):
+        wq, sc = Q.quantize_weight_per_channel_absmax(torch.from_numpy(z[f"W_{wdt}"].copy()).to(TDT[wdt]))
+        assert np.array_equal(wq.numpy(), z[f"pc_{wdt}_wq"]) and np.array_equal(sc.float().numpy().reshape(-1), z[f"pc_{wdt}_scales"])
+        q, s = Q.dynamic_quantize_activation_per_token_absmax(torch.from_numpy(z[f"dyn_tok_{wdt}_x"].copy()).to(TDT[wdt]))
+        assert np.array_equal(q.numpy(), z[f"dyn_tok_{wdt}_q"]) and np.array_equal(s.float().numpy().reshape(-1), z[f"dyn_tok_{wdt}_s"])
+        r = Q.dequantize_activation_w_per_channel_a_per_token(torch.from_numpy(z[f"dq_{wdt}_acc"].copy()),
+                                                              torch.from_numpy(z[f"dq_{wdt}_ws"].copy()),
+                                                              torch.from_numpy(z[f"dq_{wdt}_atok"].copy()).to(TDT[wdt]).view(-1, 1))
+        assert np.array_equal(r.float().numpy(), z[f"dq_{wdt}_tok_out"])

@@ -1,0 +1,299 @@
+"""GPU (-m gpu): the HIP path, called through the C-ABI, against
+  (1) the golden vectors captured from the reference's Python hot path (G1, G2, G4),
+  (2) the oracle on seeded inputs at sizes it finishes in seconds (every GEMM kernel the
+      dispatcher can pick, ragged M/N, unaligned operands, all epilogues),
+  (3) size-independent properties at BASELINE.json's full sizes (row/column checksums
+      computed in exact integers, sampled entries, M-sharding invariance).
+Tolerances: int8 activations, int32 accumulators AND the dequantised outputs are compared
+BIT-EXACTLY (the epilogue mirrors the reference's op order); the north-star contract is the
+looser rtol 1e-3."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import detrng
+import goldenio
+from oracle import w8a8 as O
+
+pytestmark = pytest.mark.gpu
+
+TDT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from autosmoothquant_amd import _lib
+    _lib.lib()  # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def t_in(a, dt, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(TDT[dt]).to(dev)
+
+
+def t_out(t):
+    return t.detach().float().cpu().numpy()
+
+
+def build_module(c, dev):
+    from autosmoothquant_amd.layers.nn.linear import (W8A8BFP32OFP32Linear, W8A8BFP32OFP32LinearWithQuantScale,
+                                                      W8A8BFP32OFP32QKVLinear)
+    N, K = c["wq"].shape
+    if c["kind"] == "linear":
+        m = W8A8BFP32OFP32Linear(K, N, c["use_bias"], c["act_quant"])
+        m.dequant_scale = torch.tensor(c["dequant_scale"], dtype=torch.float32)
+    elif c["kind"] == "quantscale":
+        m = W8A8BFP32OFP32LinearWithQuantScale(K, N, c["use_bias"], c["act_quant"])
+        m.dequant_scale = torch.tensor(c["dequant_scale"], dtype=torch.float32)
+        if c["act_quant"] == "per-tensor":
+            m.quant_scale = torch.tensor(c["quant_scale"], dtype=torch.float32)
+    else:
+        m = W8A8BFP32OFP32QKVLinear(c["qkv_size"], K, N, c["use_bias"], c["act_quant"])
+        m.q_dequant_scale, m.k_dequant_scale, m.v_dequant_scale = (torch.tensor(float(v), dtype=torch.float32)
+                                                                   for v in c["qkv_scales"])
+    m.weight = torch.from_numpy(c["wq"].copy())
+    if c["use_bias"]:
+        m.bias = torch.from_numpy(np.asarray(c["bias"], np.float32).copy())
+    return m.to(dev)
+
+
+def act_mode(c):
+    if c["act_quant"] == "per-token":
+        return "per-token", 1.0
+    if c["kind"] == "quantscale":
+        return "per-tensor-div", c["quant_scale"]
+    return "per-tensor-round", 1.0
+
+
+G1 = goldenio.load_g1()
+G2 = goldenio.load_g2()
+G4 = goldenio.load_g4()
+
+
+@pytest.mark.parametrize("c", G1 + G2, ids=lambda c: f"{c['id']}-{c['kind']}-{c['act_quant']}-{c['dt']}")
+def test_golden_module_forward(c, dev):
+    """Module forward == the reference's output, bit for bit; intermediates too."""
+    from autosmoothquant_amd import ops
+    m = build_module(c, dev)
+    x = t_in(c["x"], c["dt"], dev)
+    y = m(x)
+    assert y.dtype == TDT[c["dt"]] and tuple(y.shape) == tuple(c["out"].shape)
+    assert np.array_equal(t_out(y), c["out"], equal_nan=True)
+    # the two halves separately: prologue (int8 activations) and native boundary (int32 accumulators)
+    mode, qs = act_mode(c)
+    xq, s_row = ops.quantize_act(x.reshape(-1, x.shape[-1]), mode, qs)
+    assert np.array_equal(xq.cpu().numpy(), c["xq"])
+    acc = torch.empty(c["acc"].shape, dtype=torch.int32, device=dev)
+    m.i8cugemm.linear_a8_w8_o32_(xq, m.weight, acc)
+    assert np.array_equal(acc.cpu().numpy(), c["acc"])
+
+
+def test_golden_bigk_accumulator(dev):
+    from autosmoothquant_amd import ops
+    g = goldenio.load_g2_bigk()
+    xq, _ = ops.quantize_act(t_in(g["x"], "f32", dev), "per-tensor-round")
+    w = torch.from_numpy(g["wq"]).to(dev)
+    acc = torch.empty(g["acc"].shape, dtype=torch.int32, device=dev)
+    ops.gemm_i8_i32(xq, w, acc)
+    assert np.array_equal(acc.cpu().numpy(), g["acc"])
+    y = ops.linear_w8a8(xq, w, torch.float32, float(g["dequant_scale"]))
+    assert np.array_equal(t_out(y), g["out"])
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("c", G4, ids=lambda c: c["id"])
+def test_golden_config_shapes(c, dev):
+    """LLaMA-2-7B / OPT-13B / Mixtral layer shapes: SHA-256 of xq, acc and out equal the reference's."""
+    from autosmoothquant_amd import ops
+    x, wq, bias = goldenio.g4_inputs(c)
+    cc = dict(c, wq=wq, bias=bias)
+    m = build_module(cc, dev)
+    xt = t_in(x, c["dt"], dev)
+    y = m(xt)
+    mode, qs = act_mode(c)
+    xq, _ = ops.quantize_act(xt, mode, qs)
+    acc = torch.empty((c["M"], c["N"]), dtype=torch.int32, device=dev)
+    ops.gemm_i8_i32(xq, m.weight, acc)
+    assert _sha(xq.cpu().numpy()) == c["sha_xq"]
+    assert _sha(acc.cpu().numpy()) == c["sha_acc"]
+    assert _sha(t_out(y).astype(np.float32)) == c["sha_out"]
+
+
+# ---- oracle comparisons on seeded inputs -------------------------------------------------
+GEMM_SHAPES = [
+    # (M, N, K)  -- chosen to hit: generic (odd K / small), t256 (K%128==0, M,N>=128) with ragged edges
+    (1, 1, 1), (3, 5, 7), (17, 33, 95), (64, 64, 64), (65, 130, 200), (33, 48, 320),
+    (128, 128, 128), (256, 256, 256), (300, 520, 384), (129, 257, 1024), (512, 768, 1024),
+    (1000, 300, 512), (255, 4096, 256), (2048, 128, 2048),
+]
+
+
+@pytest.mark.parametrize("shape", GEMM_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_gemm_i8_i32_vs_oracle(shape, dev):
+    from autosmoothquant_amd import ops
+    M, N, K = shape
+    x = detrng.int8_uniform(101, M * 7 + K, (M, K))
+    w = detrng.int8_uniform(102, N * 5 + K, (N, K))
+    out = torch.full((M, N), -7, dtype=torch.int32, device=dev)
+    ops.gemm_i8_i32(torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), out)
+    assert np.array_equal(out.cpu().numpy(), O.igemm(x, w))
+
+
+def test_gemm_transpose_detecting(dev):
+    """x = one-hot rows selects rows of W: an m<->n swap or wrong fragment map cannot pass."""
+    from autosmoothquant_amd import ops
+    M, N, K = 256, 384, 256
+    w = detrng.int8_uniform(103, 0, (N, K))
+    x = np.zeros((M, K), np.int8)
+    x[np.arange(M), (np.arange(M) * 37) % K] = 1
+    out = torch.empty((M, N), dtype=torch.int32, device=dev)
+    ops.gemm_i8_i32(torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), out)
+    assert np.array_equal(out.cpu().numpy(), w[:, (np.arange(M) * 37) % K].T.astype(np.int32))
+
+
+def test_gemm_unaligned_operands_take_generic_path(dev):
+    from autosmoothquant_amd import ops
+    M, N, K = 130, 140, 256
+    xb = torch.from_numpy(detrng.int8_uniform(104, 0, (M * K + 1,))).to(dev)
+    wb = torch.from_numpy(detrng.int8_uniform(104, 1, (N * K + 3,))).to(dev)
+    x, w = xb[1:].view(M, K), wb[3:].view(N, K)
+    out = torch.empty((M, N), dtype=torch.int32, device=dev)
+    ops.gemm_i8_i32(x, w, out)
+    assert np.array_equal(out.cpu().numpy(), O.igemm(x.cpu().numpy(), w.cpu().numpy()))
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape", [(5, 64), (33, 320), (7, 4096), (3, 11008), (2, 20480), (4, 24584), (9, 77)])
+def test_quantize_act_vs_oracle(dt, shape, dev):
+    from autosmoothquant_amd import ops
+    M, K = shape
+    x = O.round_to(detrng.act_like(105, M + K, (M, K), scale=30.0), dt)
+    x[M // 2, K // 3] = 1e4 if dt != "f16" else 6e4
+    xt = t_in(x, dt, dev)
+    xq, s = ops.quantize_act(xt, "per-token")
+    rq, rs = O.act_quant_per_token(x, dt)
+    assert np.array_equal(s.cpu().numpy(), rs) and np.array_equal(xq.cpu().numpy(), rq)
+    xq, _ = ops.quantize_act(xt, "per-tensor-round")
+    assert np.array_equal(xq.cpu().numpy(), O.act_quant_round(x, dt))
+    xq, _ = ops.quantize_act(xt, "per-tensor-div", 0.7312)
+    assert np.array_equal(xq.cpu().numpy(), O.act_quant_div(x, dt, np.float32(0.7312)))
+
+
+@pytest.mark.parametrize("out_dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("order", ["scale_first", "acc_first"])
+@pytest.mark.parametrize("shape", [(67, 50, 96), (256, 384, 256), (130, 258, 128)])
+def test_fused_epilogue_vs_oracle(out_dt, order, shape, dev):
+    """All epilogue operand combinations incl. per-channel s_col (north star: 'per-channel dequant')."""
+    from autosmoothquant_amd import ops
+    M, N, K = shape
+    xq = detrng.int8_uniform(106, M, (M, K))
+    w = detrng.int8_uniform(107, N, (N, K))
+    s_row = (np.abs(detrng.normal(108, 0, (M,))) * 0.01 + 1e-3).astype(np.float32)
+    s_col = (np.abs(detrng.normal(108, 1, (N,))) * 0.01 + 1e-3).astype(np.float32)
+    bias = detrng.normal(108, 2, (N,)).astype(np.float32)
+    acc = O.igemm(xq, w)
+    d = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    for use_row in (False, True):
+        for use_col in (False, True):
+            for use_bias in (False, True):
+                got = ops.linear_w8a8(d(xq), d(w), TDT[out_dt], 0.00123, d(s_row) if use_row else None,
+                                      d(s_col) if use_col else None, d(bias) if use_bias else None, order)
+                ref = O.dequant_epilogue(acc, s_col if use_col else np.float32(0.00123), s_row if use_row else None,
+                                         bias if use_bias else None, out_dt, order)
+                assert np.array_equal(t_out(got), ref), (use_row, use_col, use_bias)
+
+
+def test_int8_out_gemms(dev):
+    """I8CUGEMM.linear_a8_w8_o8 / _o8_ / _b8_o8_ (no reference call sites; semantics restated:
+    sat_i8(rne(alpha*acc + beta*c)))."""
+    from autosmoothquant_amd._CUDA import I8CUGEMM
+    g = I8CUGEMM()
+    for (M, N, K) in [(37, 52, 96), (256, 256, 256)]:
+        x = detrng.int8_uniform(109, M, (M, K))
+        w = detrng.int8_uniform(110, N, (N, K))
+        b = detrng.int8_uniform(111, N, (N,))
+        acc = O.igemm(x, w).astype(np.float32)
+        alpha, beta = np.float32(0.0009), np.float32(0.75)
+        xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+        out = torch.zeros((M, N), dtype=torch.int8, device=dev)
+        g.linear_a8_w8_o8(xd, wd, out, float(alpha))
+        ref = np.clip(np.rint(alpha * acc), -128, 127).astype(np.int8)
+        assert np.array_equal(out.cpu().numpy(), ref)
+        c0 = detrng.int8_uniform(112, M, (M, N))
+        out = torch.from_numpy(c0.copy()).to(dev)
+        g.linear_a8_w8_o8_(xd, wd, out, float(alpha), float(beta))
+        ref = np.clip(np.rint((alpha * acc).astype(np.float32) + (beta * c0.astype(np.float32)).astype(np.float32)), -128, 127).astype(np.int8)
+        assert np.array_equal(out.cpu().numpy(), ref)
+        out = g.linear_a8_w8_b8_o8_(xd, wd, torch.from_numpy(b).to(dev), float(alpha), float(beta))
+        ref = np.clip(np.rint((alpha * acc).astype(np.float32) + (beta * b.astype(np.float32)[None, :]).astype(np.float32)), -128, 127).astype(np.int8)
+        assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_empty_and_degenerate_inputs(dev):
+    from autosmoothquant_amd.layers.nn.linear import W8A8BFP32OFP32Linear
+    m = W8A8BFP32OFP32Linear(64, 32, True, "per-token")
+    m.weight = torch.from_numpy(detrng.int8_uniform(113, 0, (32, 64)))
+    m = m.to(dev)
+    y = m(torch.zeros(0, 64, dtype=torch.float16, device=dev))
+    assert tuple(y.shape) == (0, 32) and y.dtype == torch.float16
+    y = m(torch.zeros(2, 0, 64, dtype=torch.float16, device=dev))
+    assert tuple(y.shape) == (2, 0, 32)
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 63, dtype=torch.float16, device=dev))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 64, dtype=torch.float16))  # CPU tensor: no fallback
+    # non-contiguous but reshape-able input
+    xb = torch.randn(4, 128, device=dev).half()
+    y1 = m(xb[:, ::2])
+    y2 = m(xb[:, ::2].contiguous())
+    assert torch.equal(y1, y2)
+
+
+# ---- full-size properties (BASELINE.json sizes; the oracle would take minutes) -----------
+@pytest.mark.parametrize("shape", [(4096, 4096, 4096), (2048, 11008, 4096), (2048, 4096, 11008), (256, 5120, 20480)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_full_size_checksums(shape, dev):
+    """sum_n acc[m,n] == x[m,:] . (sum_n w[n,:]) and sum_m acc[m,n] == (sum_m x[m,:]) . w[n,:] in exact
+    integers, plus 4096 sampled entries, plus M-sharding invariance (rows are independent)."""
+    from autosmoothquant_amd import ops
+    M, N, K = shape
+    x = detrng.int8_uniform(120, M, (M, K))
+    w = detrng.int8_uniform(121, N, (N, K))
+    xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    out = torch.empty((M, N), dtype=torch.int32, device=dev)
+    ops.gemm_i8_i32(xd, wd, out)
+    acc = out.cpu().numpy().astype(np.int64)
+    assert np.array_equal(acc.sum(axis=1), x.astype(np.int64) @ w.astype(np.int64).sum(axis=0))
+    assert np.array_equal(acc.sum(axis=0), w.astype(np.int64) @ x.astype(np.int64).sum(axis=0))
+    idx = (detrng.u64(122, M, 4096) % np.uint64(M * N)).astype(np.int64)
+    mi, ni = idx // N, idx % N
+    ref = np.einsum("ik,ik->i", x[mi].astype(np.int64), w[ni].astype(np.int64))
+    assert np.array_equal(acc[mi, ni], ref)
+    # replica-parallel invariance: computing a row shard alone gives the same rows bit-for-bit
+    lo, hi = M // 3, M // 3 + M // 4
+    part = torch.empty((hi - lo, N), dtype=torch.int32, device=dev)
+    ops.gemm_i8_i32(xd[lo:hi], wd, part)
+    assert torch.equal(part, out[lo:hi])
+
+
+def test_full_size_fused_forward_matches_unfused(dev):
+    """4096^3 per-tensor W8A8 forward (north-star shape): fused epilogue == epilogue recomputed
+    from the exact accumulators with the oracle's arithmetic."""
+    from autosmoothquant_amd import ops
+    M = N = K = 4096
+    x = O.round_to(detrng.act_like(130, 0, (M, K), scale=40.0), "f16")
+    w = detrng.int8_uniform(131, 0, (N, K))
+    xd, wd = t_in(x, "f16", dev), torch.from_numpy(w).to(dev)
+    y = ops.linear_w8a8_forward(xd, wd, "per-tensor-round", 1.0, 1.0 / 8192)
+    xq, _ = ops.quantize_act(xd, "per-tensor-round")
+    assert np.array_equal(xq.cpu().numpy(), O.act_quant_round(x, "f16"))
+    acc = torch.empty((M, N), dtype=torch.int32, device=dev)
+    ops.gemm_i8_i32(xq, wd, acc)
+    ref = O.dequant_epilogue(acc.cpu().numpy(), np.float32(1.0 / 8192), None, None, "f16")
+    assert np.array_equal(t_out(y), ref)
