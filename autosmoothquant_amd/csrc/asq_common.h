@@ -59,7 +59,15 @@ __device__ __forceinline__ float f16_bits_to_f32(uint16_t b)
     return __half2float(__ushort_as_half(b));
 }
 
-__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) { return __half_as_ushort(__float2half_rn(f)); }
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f)
+{
+    // Opaque barrier: without it LLVM folds `fptrunc(fmul a, b)` into v_fma_mixlo_f16 a, b, 0,
+    // which rounds the EXACT product once to fp16 (and turns -0 into +0) -- not the
+    // "round to fp32, then to fp16" the reference's separate ATen ops perform.  Caught by the
+    // bit-exact parity tests (-144951 * 0.0040789647 = -591.25000126 -> -591.5 instead of -591.0).
+    asm volatile("" : "+v"(f));
+    return __half_as_ushort(__float2half_rn(f));
+}
 
 template <int DT> struct ElemT;
 template <> struct ElemT<ASQ_F32> {

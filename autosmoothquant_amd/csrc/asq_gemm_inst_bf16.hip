@@ -1,0 +1,5 @@
+// fp-epilogue instantiations of the INT8 GEMM kernels for out dtype BF16 (own TU: parallel build)
+#include "asq_gemm_kernels.h"
+namespace asq {
+template <> int launch_dequant<ASQ_BF16>(const DequantArgs &a, hipStream_t s) { return launch_dequant_impl<ASQ_BF16>(a, s); }
+}  // namespace asq

@@ -1,0 +1,5 @@
+// fp-epilogue instantiations of the INT8 GEMM kernels for out dtype F16 (own TU: parallel build)
+#include "asq_gemm_kernels.h"
+namespace asq {
+template <> int launch_dequant<ASQ_F16>(const DequantArgs &a, hipStream_t s) { return launch_dequant_impl<ASQ_F16>(a, s); }
+}  // namespace asq

@@ -1,0 +1,5 @@
+// fp-epilogue instantiations of the INT8 GEMM kernels for out dtype F32 (own TU: parallel build)
+#include "asq_gemm_kernels.h"
+namespace asq {
+template <> int launch_dequant<ASQ_F32>(const DequantArgs &a, hipStream_t s) { return launch_dequant_impl<ASQ_F32>(a, s); }
+}  // namespace asq

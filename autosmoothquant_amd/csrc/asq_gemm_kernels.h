@@ -1,0 +1,345 @@
+// INT8 x INT8 -> INT32 GEMM on CDNA4 matrix cores with fused epilogues: kernels + launcher.
+//
+//   acc[m,n] = sum_k x[m,k] * w[n,k]          (both operands K-contiguous, "TN")
+//
+// replaces cublasLtMatmul behind I8CUGEMM::linear_a8_w8_o32_ (reference
+// csrc/int8gemm/cublasINT8MMWrapper.cc:224-354) and, through the epilogue functors, the
+// eager dequant/bias code of layers/nn/linear.py:104,197-206,300 and the int8-out flavours
+// (cublasINT8MMWrapper.cc:360-672).
+//
+// MFMA mapping (v_mfma_i32_32x32x32_i8, 64-lane wave):
+//   the W tile is the matrix-core "A" operand (rows = output channel n), the X tile is "B"
+//   (cols = token m).  Lane l therefore owns token m = l&31 and, per accumulator register
+//   group g = reg>>2, FOUR CONSECUTIVE output channels n = 8g + 4(l>>5) + (reg&3): the
+//   epilogue stores 16 B (i32/f32) or 8 B (f16/bf16) per lane per group without any
+//   cross-lane shuffle.  Both operands read the same 16 k-bytes per lane
+//   (k = 32*ks + 16*(l>>5) ...), so the dot product is independent of the hardware's
+//   internal k ordering.
+//
+// Epilogue protocol (one wave, NTN x NTM accumulator tiles of 32(n) x 32(m)):
+//   1. every per-token / per-channel operand the lane will need (<= 4 row scales, <= 8 float4
+//      of column scales, <= 8 float4 of bias) is loaded UP FRONT into registers,
+//   2. then all tiles are converted and stored with no memory wait in between
+//      (on gfx9 stores count in vmcnt: a load-wait inside the store loop would serialise the
+//      stores on their write acknowledgements -- measured 2.7x on the whole epilogue).
+#pragma once
+#include "asq_common.h"
+#include <string.h>
+#include <type_traits>
+
+namespace asq {
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// ---------------------------------------------------------------------------------
+// epilogue functors
+// ---------------------------------------------------------------------------------
+struct EpiI32 {
+    static constexpr bool kHasRow = false, kHasCol = false, kHasBias = false;
+    int32_t *out;
+    int64_t N;
+    bool vec_ok;
+    __device__ __forceinline__ float row(int64_t) const { return 1.0f; }
+    __device__ __forceinline__ void cols(int64_t, int64_t, v4f &, v4f &) const {}
+    __device__ __forceinline__ void store4(int64_t m, int64_t n, const v4i &a, float, const v4f &, const v4f &, int64_t Ncols) const
+    {
+        int32_t *p = out + m * N + n;
+        if (vec_ok && n + 3 < Ncols) {
+            *(v4i *)p = a;
+        } else {
+            if (n < Ncols) p[0] = a[0];
+            if (n + 1 < Ncols) p[1] = a[1];
+            if (n + 2 < Ncols) p[2] = a[2];
+            if (n + 3 < Ncols) p[3] = a[3];
+        }
+    }
+};
+
+// out = dequant(acc) (+bias) -> DT.  HAS_* are compile-time so the hot instantiations carry no
+// dead loads or branches; `order` is a wave-uniform runtime select.
+template <int DT, bool HAS_ROW, bool HAS_COL, bool HAS_BIAS> struct EpiDequant {
+    static constexpr bool kHasRow = HAS_ROW, kHasCol = HAS_COL, kHasBias = HAS_BIAS;
+    void *out;
+    int64_t N;
+    float s_scalar;
+    const float *s_row;  // [M]   (HAS_ROW)
+    const float *s_col;  // [N]   (HAS_COL)
+    const float *bias;   // [N]   (HAS_BIAS)
+    int order;
+    bool vec_ok;
+
+    __device__ __forceinline__ float row(int64_t m) const { return HAS_ROW ? s_row[m] : 1.0f; }
+
+    __device__ __forceinline__ void cols(int64_t n, int64_t Ncols, v4f &sc, v4f &b) const
+    {
+        sc = (v4f){s_scalar, s_scalar, s_scalar, s_scalar};
+        b = (v4f){0.f, 0.f, 0.f, 0.f};
+        if (vec_ok && n + 3 < Ncols) {
+            if constexpr (HAS_COL) sc = *(const v4f *)(s_col + n);
+            if constexpr (HAS_BIAS) b = *(const v4f *)(bias + n);
+        } else {
+            if constexpr (HAS_COL) {
+                if (n < Ncols) sc[0] = s_col[n];
+                if (n + 1 < Ncols) sc[1] = s_col[n + 1];
+                if (n + 2 < Ncols) sc[2] = s_col[n + 2];
+                if (n + 3 < Ncols) sc[3] = s_col[n + 3];
+            }
+            if constexpr (HAS_BIAS) {
+                if (n < Ncols) b[0] = bias[n];
+                if (n + 1 < Ncols) b[1] = bias[n + 1];
+                if (n + 2 < Ncols) b[2] = bias[n + 2];
+                if (n + 3 < Ncols) b[3] = bias[n + 3];
+            }
+        }
+    }
+
+    __device__ __forceinline__ float one(int acc, float sc, float sr, float b) const
+    {
+        const float a = (float)acc;  // v_cvt_f32_i32: round-to-nearest-even, as ATen
+        float v;
+        if (order == ASQ_EPI_SCALE_FIRST) {
+            const float ds = HAS_ROW ? __fmul_rn(sc, sr) : sc;
+            v = __fmul_rn(ds, a);
+        } else {
+            v = __fmul_rn(a, sc);
+            if constexpr (HAS_ROW) v = __fmul_rn(v, sr);
+        }
+        if constexpr (HAS_BIAS) v = __fadd_rn(v, b);
+        return v;
+    }
+
+    __device__ __forceinline__ void store4(int64_t m, int64_t n, const v4i &a, float sr, const v4f &sc, const v4f &b, int64_t Ncols) const
+    {
+        using E = ElemT<DT>;
+        const float v0 = one(a[0], sc[0], sr, b[0]), v1 = one(a[1], sc[1], sr, b[1]);
+        const float v2 = one(a[2], sc[2], sr, b[2]), v3 = one(a[3], sc[3], sr, b[3]);
+        typename E::type *p = (typename E::type *)out + m * N + n;
+        if (vec_ok && n + 3 < Ncols) {
+            if constexpr (DT == ASQ_F32) {
+                *(v4f *)p = (v4f){v0, v1, v2, v3};
+            } else {
+                const uint32_t lo = (uint32_t)E::store(v0) | ((uint32_t)E::store(v1) << 16);
+                const uint32_t hi = (uint32_t)E::store(v2) | ((uint32_t)E::store(v3) << 16);
+                *(uint2 *)p = make_uint2(lo, hi);
+            }
+        } else {
+            if (n < Ncols) p[0] = E::store(v0);
+            if (n + 1 < Ncols) p[1] = E::store(v1);
+            if (n + 2 < Ncols) p[2] = E::store(v2);
+            if (n + 3 < Ncols) p[3] = E::store(v3);
+        }
+    }
+};
+
+struct EpiI8 {  // out = sat_i8(rne(alpha*acc + beta*c)), c = previous out
+    static constexpr bool kHasRow = false, kHasCol = false, kHasBias = false;
+    int8_t *out;
+    int64_t N;
+    float alpha, beta;
+    bool vec_ok;
+    __device__ __forceinline__ float row(int64_t) const { return 1.0f; }
+    __device__ __forceinline__ void cols(int64_t, int64_t, v4f &, v4f &) const {}
+    __device__ __forceinline__ int one(int acc, int c) const
+    {
+        float v = __fmul_rn(alpha, (float)acc);
+        if (beta != 0.0f) v = __fadd_rn(v, __fmul_rn(beta, (float)c));
+        return quant_i8(v);
+    }
+    __device__ __forceinline__ void store4(int64_t m, int64_t n, const v4i &a, float, const v4f &, const v4f &, int64_t Ncols) const
+    {
+        int8_t *p = out + m * N + n;
+        if (vec_ok && n + 3 < Ncols) {
+            const uint32_t c = (beta != 0.0f) ? *(const uint32_t *)p : 0u;
+            uint32_t r = 0;
+            r |= (uint32_t)(one(a[0], (int)(int8_t)(c)) & 0xFF);
+            r |= (uint32_t)(one(a[1], (int)(int8_t)(c >> 8)) & 0xFF) << 8;
+            r |= (uint32_t)(one(a[2], (int)(int8_t)(c >> 16)) & 0xFF) << 16;
+            r |= (uint32_t)(one(a[3], (int)(int8_t)(c >> 24)) & 0xFF) << 24;
+            *(uint32_t *)p = r;
+        } else {
+            if (n < Ncols) p[0] = (int8_t)one(a[0], (beta != 0.0f) ? (int)p[0] : 0);
+            if (n + 1 < Ncols) p[1] = (int8_t)one(a[1], (beta != 0.0f) ? (int)p[1] : 0);
+            if (n + 2 < Ncols) p[2] = (int8_t)one(a[2], (beta != 0.0f) ? (int)p[2] : 0);
+            if (n + 3 < Ncols) p[3] = (int8_t)one(a[3], (beta != 0.0f) ? (int)p[3] : 0);
+        }
+    }
+};
+
+// Wave-level epilogue over NTN x NTM accumulator tiles; tile (in, im) covers
+// n in [nw0 + 32*in, +32), m in [mw0 + mstep(im), +32).  `get(in, im)` returns the v16i.
+template <int NTN, int NTM, class Epi, class Get, class MOff>
+__device__ __forceinline__ void epilogue_wave(const Epi &epi, Get get, MOff moff, int64_t mw0, int64_t nw0, int lane, int64_t M, int64_t N)
+{
+    float sr[NTM];
+    int64_t mrow[NTM];
+#pragma unroll
+    for (int im = 0; im < NTM; ++im) {
+        mrow[im] = mw0 + moff(im) + (lane & 31);
+        sr[im] = 1.0f;
+        if constexpr (Epi::kHasRow) {
+            if (mrow[im] < M) sr[im] = epi.row(mrow[im]);
+        }
+    }
+    v4f sc[NTN][4], bb[NTN][4];
+#pragma unroll
+    for (int in = 0; in < NTN; ++in)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t n = nw0 + in * 32 + 8 * g + 4 * (lane >> 5);
+            sc[in][g] = (v4f){0.f, 0.f, 0.f, 0.f};
+            bb[in][g] = (v4f){0.f, 0.f, 0.f, 0.f};
+            if (n < N) epi.cols(n, N, sc[in][g], bb[in][g]);
+        }
+#pragma unroll
+    for (int im = 0; im < NTM; ++im) {
+        if (mrow[im] >= M) continue;
+#pragma unroll
+        for (int in = 0; in < NTN; ++in) {
+            const v16i a = get(in, im);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t n = nw0 + in * 32 + 8 * g + 4 * (lane >> 5);
+                if (n < N) epi.store4(mrow[im], n, (v4i){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g], N);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// "generic": any M, N, K, any alignment.  64x64x64 tile, 4 waves (2x2), single LDS buffer.
+// Correctness net for odd shapes (K % 128 != 0, unaligned rows); not a tuned kernel.
+// ---------------------------------------------------------------------------------
+constexpr int GEN_T = 64, GEN_LD = 80;  // 64 k-bytes + 16 pad per row
+
+__device__ __forceinline__ v4i load16_guarded(const int8_t *base, int64_t ld, int64_t row, int64_t nrows, int64_t k, int64_t K, bool fast)
+{
+    v4i v = {0, 0, 0, 0};
+    if (row >= nrows || k >= K) return v;
+    const int8_t *p = base + row * ld + k;
+    if (fast && k + 16 <= K) return *(const v4i *)p;
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 16; ++i)
+        if (k + i < K) w[i >> 2] |= (uint32_t)(uint8_t)p[i] << (8 * (i & 3));
+    return (v4i){(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+}
+
+template <class Epi>
+__global__ void __launch_bounds__(256) gemm_i8_generic(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N,
+                                                       int64_t K, bool fast, Epi epi)
+{
+    __shared__ __attribute__((aligned(16))) char lds[2 * GEN_T * GEN_LD];
+    char *xs = lds, *ws = lds + GEN_T * GEN_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.y * GEN_T, n0 = (int64_t)blockIdx.x * GEN_T;
+    const int lrow = tid >> 2, lchunk = tid & 3;
+    v16i acc = {0};
+    for (int64_t k0 = 0; k0 < K; k0 += GEN_T) {
+        v4i vx = load16_guarded(x, K, m0 + lrow, M, k0 + lchunk * 16, K, fast);
+        v4i vw = load16_guarded(w, K, n0 + lrow, N, k0 + lchunk * 16, K, fast);
+        __syncthreads();
+        *(v4i *)(xs + lrow * GEN_LD + lchunk * 16) = vx;
+        *(v4i *)(ws + lrow * GEN_LD + lchunk * 16) = vw;
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v4i a = *(const v4i *)(ws + (wn * 32 + (lane & 31)) * GEN_LD + ks * 32 + (lane >> 5) * 16);
+            v4i b = *(const v4i *)(xs + (wm * 32 + (lane & 31)) * GEN_LD + ks * 32 + (lane >> 5) * 16);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
+        }
+    }
+    epilogue_wave<1, 1>(
+        epi, [&](int, int) -> const v16i & { return acc; }, [](int) { return 0; }, m0 + wm * 32, n0 + wn * 32, lane, M, N);
+}
+
+// bijective XCD-aware remap: consecutive logical ids land on the same XCD (its private L2
+// then serves the operand panels shared by neighbouring tiles)
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+}  // namespace asq
+
+#include "asq_gemm_p8.h"
+
+namespace asq {
+
+// ---------------------------------------------------------------------------------
+// dispatch + launch
+// ---------------------------------------------------------------------------------
+enum GemmKernel { KERN_GENERIC = 0, KERN_P8 = 2 };
+
+int forced_kernel();  // env ASQ_GEMM_KERNEL=generic|p8 (development / A-B aid), asq_gemm.hip
+
+static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, int64_t N, int64_t K)
+{
+    const bool aligned = ((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0;
+    const bool tiled_ok = aligned && K % 128 == 0 && K >= 128 && K <= (1 << 24);
+    const int f = forced_kernel();
+    if (f == KERN_GENERIC) return KERN_GENERIC;
+    if (tiled_ok && f == KERN_P8) return KERN_P8;
+    if (tiled_ok && M >= 128 && N >= 128) return KERN_P8;
+    return KERN_GENERIC;
+}
+
+template <class Epi> int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, Epi epi, hipStream_t s, const char *what)
+{
+    if (M == 0 || N == 0) return ASQ_OK;
+    const GemmKernel kern = pick_kernel(x, w, M, N, K);
+    if (kern == KERN_P8) {
+        const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
+        ASQ_REQUIRE(tm * tn < (1ll << 31), ASQ_ERR_DIM, "%s: too many tiles", what);
+        auto kfn = gemm_i8_p8<Epi>;
+        hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES);
+        if (e != hipSuccess) {
+            asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+            return (int)e;
+        }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, epi);
+    } else {
+        const bool fast = (K % 16 == 0) && (((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0);
+        dim3 grid((unsigned)((N + GEN_T - 1) / GEN_T), (unsigned)((M + GEN_T - 1) / GEN_T));
+        ASQ_REQUIRE(grid.y < 65536, ASQ_ERR_DIM, "%s: M too large for the generic kernel (K %% 128 != 0 or unaligned operands)", what);
+        hipLaunchKernelGGL((gemm_i8_generic<Epi>), grid, dim3(256), 0, s, x, w, M, N, K, fast, epi);
+    }
+    return asq_after_launch(s, what);
+}
+
+// per-dtype instantiation units (asq_gemm_inst_*.hip)
+struct DequantArgs {
+    const int8_t *xq, *w;
+    void *out;
+    int64_t M, N, K;
+    float s_scalar;
+    const float *s_row, *s_col, *bias;
+    int order;
+    bool vec_ok;
+};
+template <int DT> int launch_dequant(const DequantArgs &a, hipStream_t s);
+
+template <int DT, bool R, bool C, bool B> static inline int launch_dequant_one(const DequantArgs &a, hipStream_t s)
+{
+    return launch_gemm(a.xq, a.w, a.M, a.N, a.K, EpiDequant<DT, R, C, B>{a.out, a.N, a.s_scalar, a.s_row, a.s_col, a.bias, a.order, a.vec_ok}, s,
+                       "asq_linear_w8a8");
+}
+
+template <int DT> static inline int launch_dequant_impl(const DequantArgs &a, hipStream_t s)
+{
+    const int key = (a.s_row ? 4 : 0) | (a.s_col ? 2 : 0) | (a.bias ? 1 : 0);
+    switch (key) {
+    case 0: return launch_dequant_one<DT, false, false, false>(a, s);
+    case 1: return launch_dequant_one<DT, false, false, true>(a, s);
+    case 2: return launch_dequant_one<DT, false, true, false>(a, s);
+    case 3: return launch_dequant_one<DT, false, true, true>(a, s);
+    case 4: return launch_dequant_one<DT, true, false, false>(a, s);
+    case 5: return launch_dequant_one<DT, true, false, true>(a, s);
+    case 6: return launch_dequant_one<DT, true, true, false>(a, s);
+    default: return launch_dequant_one<DT, true, true, true>(a, s);
+    }
+}
+
+}  // namespace asq

@@ -1,0 +1,327 @@
+// "p8": 256(m) x 256(n) x 128(k) INT8 MFMA GEMM with a phase-staggered, deep-prefetch
+// schedule.  Included by asq_gemm.hip (needs its epilogue functors and helpers).
+//
+// Work split: 8 waves = 2 (m) x 4 (n); wave (wm, wn) owns out[wm*128 .. +128][wn*64 .. +64]
+// = 2x2 "quadrants" of 64(m) x 32(n), each 2 MFMA tiles of 32x32 (v_mfma_i32_32x32x32_i8,
+// W = matrix-core A operand, X = B operand; see asq_gemm.hip header).
+//
+// One K-tile (128 k-bytes) is FOUR phases, one quadrant each (8 MFMAs = 256 MFMA cycles):
+//     P1 (m-half 0, n-half 0)   reads X-even (8 x ds_read_b128) + W-even (4)
+//     P2 (m-half 0, n-half 1)   reads W-odd (4)
+//     P3 (m-half 1, n-half 1)   reads X-odd (8)
+//     P4 (m-half 1, n-half 0)   reads nothing (W-even fragments stay in VGPRs)
+// Each phase is   { issue 2 LDS-DMAs ; ds_reads ; counted vmcnt ; s_barrier ;
+//                   lgkmcnt(0) ; 8 MFMAs ; s_barrier }.
+// The wm=1 waves run ONE BARRIER behind the wm=0 waves, so on every SIMD (one wave of each
+// group) one wave is in its MFMA segment while the other issues loads: the matrix pipe
+// never waits for LDS or the barrier.
+//
+// The load segment contains NO VALU instruction (measured: a VALU op issued beside the
+// partner wave's prio-1 MFMA stream costs 100-300 cycles): DMA addresses are
+// SGPR base (+k, advanced with SALU) + a loop-invariant 32-bit VGPR offset, the LDS
+// destination goes through M0, and every ds_read address is a loop-invariant VGPR plus an
+// immediate (the K loop is unrolled by 2 so the LDS stage is a compile-time constant).
+//
+// LDS = ring of 8 "units" of 16 KiB (2 K-tiles x {X-even, W-even, W-odd, X-odd}); a unit is
+// the 128 operand rows all 8 waves need for one phase:
+//     X-even: tile rows [0,64) u [128,192)      X-odd: [64,128) u [192,256)
+//     W-even: rows 64*wn + [0,32)               W-odd: rows 64*wn + [32,64)
+// Units are filled by global_load_lds (16 B/lane, lane-linear 1 KiB per wave-instruction,
+// 2 per wave per unit) in consumption order, FOUR phases ahead of their first read:
+// phase g issues unit g+4.  Waits are counted, never 0 in the loop: after a phase's issue,
+// `s_waitcnt vmcnt(4)` retires exactly the units the NEXT phase reads (2 units = 4 DMAs may
+// stay in flight); the barrier after it makes every wave's share visible (RAW), and a unit's
+// slot is re-filled >= 2 phases after its last ds_read (WAR).
+// Unit image: [128 rows][8 x 16-B chunks], chunk ^= (row>>1)&7 -> conflict-free ds_read_b128
+// (SQ_LDS_BANK_CONFLICT = 0 measured); the swizzle is applied to the DMA's per-lane global
+// source address.
+//
+// Past the last K-tile the prefetcher re-reads the last tile (clamped k) into dead slots,
+// keeping every vmcnt count uniform; all DMAs are drained before the epilogue.
+#pragma once
+#include <type_traits>
+
+namespace asq {
+
+constexpr int P8_UNIT = 128 * 128;        // 16 KiB
+constexpr int P8_STAGE = 4 * P8_UNIT;     // one K-tile: 64 KiB
+constexpr int P8_LDS_BYTES = 2 * P8_STAGE;
+
+#define P8_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define P8_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// ---- probe support (tools/ubench/p8_probe.hip): ablation + per-phase s_memtime stamps -------
+//   ABL 1 = no LDS-DMA, 2 = no fragment ds_reads, 4 = no MFMA, 8 = no barriers,
+//       32 = timing stamps of block 0 waves 0/4, 64 = no s_setprio.   Production uses ABL = 0.
+static __device__ unsigned long long p8_dbg[2][4][8];
+static __device__ unsigned long long p8_blk[4096][6];  // ABL & 128: per-block {start, prologue done, loop done, end, xcc_id, tile id}
+#define P8_BLK(i) do { if constexpr (ABL & 128) { if (wave == 0 && lane == 0 && blockIdx.x < 4096) p8_blk[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define P8_BAR() do { if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier(); } while (0)
+#define P8_PRIO(v) do { if constexpr (!(ABL & 64)) __builtin_amdgcn_s_setprio(v); } while (0)
+#define P8_STAMP(i) do { if constexpr (ABL & 32) st[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define P8_ACCUM(ph) do { if constexpr (ABL & 32) { _Pragma("unroll") for (int q_ = 0; q_ < 7; ++q_) tacc[ph][q_] += st[q_ + 1] - st[q_]; } } while (0)
+
+template <int ABL> __device__ __forceinline__ v16i p8_mfma(const v4i &a, const v4i &b, const v16i &c)
+{
+    if constexpr (ABL & 4) {
+        asm volatile("" ::"v"(a), "v"(b));  // keep the fragment loads alive
+        return c;
+    } else {
+        return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+    }
+}
+typedef const __attribute__((address_space(3))) v4i *p8_lds_v4i;
+template <int ABL> __device__ __forceinline__ v4i p8_ldfrag(unsigned lds_addr, int lane)
+{
+    if constexpr (ABL & 2) return (v4i){lane, 1, 2, 3};
+    else return *(p8_lds_v4i)(uintptr_t)lds_addr;
+}
+
+// LDS-DMA, 16 B per lane: global address = SGPR-pair base + 32-bit VGPR offset (no VALU address
+// math), LDS destination = M0 (wave-uniform) + lane*16.  hipcc does not count asm memory
+// operations: every consumer is ordered by this kernel's own counted s_waitcnt vmcnt + barrier.
+__device__ __forceinline__ void p8_dma16(const int8_t *sbase, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+template <class Epi, int ABL = 0>
+__global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N,
+                                                     int64_t K, int tiles_m, int tiles_n, Epi epi)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    P8_BLK(0);
+    constexpr int GM = 4;
+    const int nwg = tiles_m * tiles_n;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int per_group = GM * tiles_n;
+    const int group = id / per_group, in_group = id - group * per_group;
+    const int first_m = group * GM;
+    const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int tile_m = first_m + in_group % gm, tile_n = in_group / gm;
+    const int64_t m0 = (int64_t)tile_m * 256, n0 = (int64_t)tile_n * 256;
+
+    // ---- DMA sources: uniform tile base (SGPR pair, + k advanced per K-tile) + 32-bit lane offset.
+    // This wave fills row-groups 2*wave, 2*wave+1 (8 rows each) of every unit.
+    const int8_t *const xbase = x + m0 * K;  // wave-uniform
+    const int8_t *const wbase = w + n0 * K;
+    const int64_t mrem = M - m0 - 1, nrem = N - n0 - 1;  // last valid local row
+    unsigned voff[4][2];  // [kind][i]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ru = (wave * 2 + i) * 8 + (lane >> 3);          // row within the unit, 0..127
+        const unsigned cb = (unsigned)(((lane & 7) ^ ((ru >> 1) & 7)) * 16);  // swizzled source chunk
+        int64_t rxe = (ru >> 6) * 128 + (ru & 63), rxo = rxe + 64;  // local tile rows
+        int64_t rwe = (ru >> 5) * 64 + (ru & 31), rwo = rwe + 32;
+        rxe = rxe < mrem ? rxe : mrem;
+        rxo = rxo < mrem ? rxo : mrem;
+        rwe = rwe < nrem ? rwe : nrem;
+        rwo = rwo < nrem ? rwo : nrem;
+        voff[0][i] = (unsigned)(rxe * K) + cb;
+        voff[1][i] = (unsigned)(rwe * K) + cb;
+        voff[2][i] = (unsigned)(rwo * K) + cb;
+        voff[3][i] = (unsigned)(rxo * K) + cb;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
+    const unsigned dma_dst = lds0 + wave * 2048;  // + stage*P8_STAGE + kind*P8_UNIT + i*1024
+
+    // ---- fragment read addresses: one VGPR per (stage, operand, k-substep); the rest is an immediate
+    const int frow = lane & 31, sw = (frow >> 1) & 7, hi = lane >> 5;
+    unsigned xb[2][4], wbp[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const unsigned off = lds0 + frow * 128 + ((((ks * 2 + hi) ^ sw)) << 4) + s * P8_STAGE;
+            xb[s][ks] = off + wm * 64 * 128;   // X units: this wave's 64 rows
+            wbp[s][ks] = off + wn * 32 * 128;  // W units: this wave's 32 rows
+            // opaque to the optimiser: keep these 16 addresses in VGPRs instead of re-deriving them
+            // with VALU adds inside the load segments
+            asm volatile("" : "+v"(xb[s][ks]), "+v"(wbp[s][ks]));
+        }
+
+    v16i acc[2][2][2];  // [m-half][n-half][j]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[a][b][c] = (v16i){0};
+
+    const int nt = (int)(K / 128);
+    const int klast = (nt - 1) * 128;
+
+    auto issue = [&](int kind, int stage, int k0) {
+        if constexpr (ABL & 1) return;
+        const int8_t *b = ((kind == 0 || kind == 3) ? xbase : wbase) + k0;  // SALU
+#pragma unroll
+        for (int i = 0; i < 2; ++i) p8_dma16(b, voff[kind][i], dma_dst + stage * P8_STAGE + kind * P8_UNIT + i * 1024);
+    };
+
+    // ---- prologue: K-tile 0 entirely (units 0..3), wait for the two units P1 reads
+#pragma unroll
+    for (int kind = 0; kind < 4; ++kind) issue(kind, 0, 0);
+    P8_WAIT_VM(4);
+    P8_BAR();
+    if (wm == 1) P8_BAR();  // stagger: the wm=1 group runs one barrier behind
+    P8_BLK(1);
+
+    v4i xf[2][4], wa[4], wb[4];
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tacc[4][7] = {};
+    (void)st;
+    (void)tacc;
+
+    // one K-tile at LDS stage S (compile-time), prefetching K-tile (t+1) into stage S^1
+    auto ktile = [&](auto stage_tag, int t) {
+        constexpr int S = decltype(stage_tag)::value, NS = S ^ 1;
+        int kn = (t + 1) * 128;  // SALU: s_min_i32
+        kn = kn < klast ? kn : klast;
+
+        // ---------------- P1: (m-half 0, n-half 0)
+        P8_STAMP(0);
+        issue(0, NS, kn);
+        P8_STAMP(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wa[ks] = p8_ldfrag<ABL>(wbp[S][ks] + 1 * P8_UNIT, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) xf[j][ks] = p8_ldfrag<ABL>(xb[S][ks] + 0 * P8_UNIT + j * 4096, lane);
+        P8_STAMP(2);
+        P8_WAIT_VM(4);
+        P8_STAMP(3);
+        P8_BAR();
+        P8_STAMP(4);
+        P8_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        P8_STAMP(5);
+        P8_PRIO(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[0][0][j] = p8_mfma<ABL>(wa[ks], xf[j][ks], acc[0][0][j]);
+        P8_PRIO(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_STAMP(6);
+        P8_BAR();
+        P8_STAMP(7);
+        P8_ACCUM(0);
+
+        // ---------------- P2: (m-half 0, n-half 1)
+        P8_STAMP(0);
+        issue(1, NS, kn);
+        P8_STAMP(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wb[ks] = p8_ldfrag<ABL>(wbp[S][ks] + 2 * P8_UNIT, lane);
+        P8_STAMP(2);
+        P8_WAIT_VM(4);
+        P8_STAMP(3);
+        P8_BAR();
+        P8_STAMP(4);
+        P8_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        P8_STAMP(5);
+        P8_PRIO(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[0][1][j] = p8_mfma<ABL>(wb[ks], xf[j][ks], acc[0][1][j]);
+        P8_PRIO(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_STAMP(6);
+        P8_BAR();
+        P8_STAMP(7);
+        P8_ACCUM(1);
+
+        // ---------------- P3: (m-half 1, n-half 1)
+        P8_STAMP(0);
+        issue(2, NS, kn);
+        P8_STAMP(1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) xf[j][ks] = p8_ldfrag<ABL>(xb[S][ks] + 3 * P8_UNIT + j * 4096, lane);
+        P8_STAMP(2);
+        P8_STAMP(3);
+        P8_BAR();
+        P8_STAMP(4);
+        P8_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        P8_STAMP(5);
+        P8_PRIO(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[1][1][j] = p8_mfma<ABL>(wb[ks], xf[j][ks], acc[1][1][j]);
+        P8_PRIO(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_STAMP(6);
+        P8_BAR();
+        P8_STAMP(7);
+        P8_ACCUM(2);
+
+        // ---------------- P4: (m-half 1, n-half 0) -- W-even fragments are still in wa[]
+        P8_STAMP(0);
+        issue(3, NS, kn);
+        P8_STAMP(1);
+        P8_STAMP(2);
+        P8_WAIT_VM(4);
+        P8_STAMP(3);
+        P8_BAR();
+        P8_STAMP(4);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_STAMP(5);
+        P8_PRIO(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[1][0][j] = p8_mfma<ABL>(wa[ks], xf[j][ks], acc[1][0][j]);
+        P8_PRIO(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_STAMP(6);
+        P8_BAR();
+        P8_STAMP(7);
+        P8_ACCUM(3);
+    };
+
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {
+        ktile(std::integral_constant<int, 0>{}, t);
+        ktile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (t < nt) ktile(std::integral_constant<int, 0>{}, t);
+
+    if constexpr (ABL & 32) {
+        if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 7; ++b) p8_dbg[wave >> 2][a][b] = tacc[a][b];
+    }
+    P8_BLK(2);
+    P8_WAIT_VM(0);          // drain the dead prefetches before LDS is released
+    if (wm == 0) P8_BAR();  // balance the stagger barrier
+
+    // accumulator tile (in = n-half, im = 2*m-half + j) -> rows m0 + wm*128 + 32*im, cols n0 + wn*64 + 32*in
+    epilogue_wave<2, 4>(
+        epi, [&](int in, int im) -> const v16i & { return acc[im >> 1][in][im & 1]; }, [](int im) { return im * 32; }, m0 + wm * 128, n0 + wn * 64, lane,
+        M, N);
+    if constexpr (ABL & 128) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        P8_BLK(3);
+        if (wave == 0 && lane == 0 && blockIdx.x < 4096) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            p8_blk[blockIdx.x][4] = xcc;
+            p8_blk[blockIdx.x][5] = (unsigned)(tile_m * 65536 + tile_n);
+        }
+    }
+}
+
+}  // namespace asq

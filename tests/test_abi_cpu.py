@@ -38,7 +38,7 @@ def test_argument_errors_without_gpu():
     assert h.asq_linear_w8a8_forward(None, 1, None, None, 4, 4, 4, 0, 1.0, 1.0, None, None, None, 0, None) == -5
     assert h.asq_gemm_i8_i32(None, None, None, 0, 4, 4, None) == 0            # empty problem is a no-op
     assert h.asq_linear_w8a8_workspace_bytes(3, 5) == 256 + 256
-    assert h.asq_gemm_kernel_name(4096, 4096, 4096) == b"t256"
+    assert h.asq_gemm_kernel_name(4096, 4096, 4096) == b"p8"
     assert h.asq_gemm_kernel_name(4, 4096, 4095) == b"generic"
 
 
