@@ -13,6 +13,7 @@ int forced_kernel()
         if (e) {
             if (!strcmp(e, "generic")) v = KERN_GENERIC;
             else if (!strcmp(e, "p8")) v = KERN_P8;
+            else if (!strcmp(e, "skinny")) v = KERN_SKINNY;
         }
     }
     return v;
@@ -36,6 +37,7 @@ extern "C" const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K)
 {
     switch (pick_kernel(nullptr, nullptr, M, N, K)) {
     case KERN_P8: return "p8";
+    case KERN_SKINNY: return "skinny";
     default: return "generic";
     }
 }

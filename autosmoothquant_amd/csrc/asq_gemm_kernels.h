@@ -265,13 +265,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 }  // namespace asq
 
 #include "asq_gemm_p8.h"
+#include "asq_gemm_skinny.h"
 
 namespace asq {
 
 // ---------------------------------------------------------------------------------
 // dispatch + launch
 // ---------------------------------------------------------------------------------
-enum GemmKernel { KERN_GENERIC = 0, KERN_P8 = 2 };
+enum GemmKernel { KERN_GENERIC = 0, KERN_SKINNY = 1, KERN_P8 = 2 };
 
 int forced_kernel();  // env ASQ_GEMM_KERNEL=generic|p8 (development / A-B aid), asq_gemm.hip
 
@@ -282,7 +283,8 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
     const int f = forced_kernel();
     if (f == KERN_GENERIC) return KERN_GENERIC;
     if (tiled_ok && f == KERN_P8) return KERN_P8;
-    if (tiled_ok && M >= 128 && N >= 128) return KERN_P8;
+    if (tiled_ok && M <= 64 && (f == KERN_SKINNY || f < 0)) return KERN_SKINNY;
+    if (tiled_ok && M > 64 && f < 0) return KERN_P8;
     return KERN_GENERIC;
 }
 
@@ -300,6 +302,22 @@ template <class Epi> int launch_gemm(const int8_t *x, const int8_t *w, int64_t M
             return (int)e;
         }
         hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, epi);
+    } else if (kern == KERN_SKINNY) {
+        const int mt = (int)((M + 15) / 16);
+        const int64_t blocks = (N + 15) / 16;
+        // enough waves to cover 256 CUs x 16 wave slots; few blocks -> more waves per block
+        const int wpb = blocks * 4 >= 4096 ? 4 : (blocks * 8 >= 4096 ? 8 : 16);
+        dim3 grid((unsigned)blocks), block((unsigned)(wpb * 64));
+#define ASQ_SK(MT_, W_) hipLaunchKernelGGL((gemm_i8_skinny<Epi, MT_, W_>), grid, block, 0, s, x, w, M, N, K, epi)
+#define ASQ_SKW(MT_) do { if (wpb == 4) ASQ_SK(MT_, 4); else if (wpb == 8) ASQ_SK(MT_, 8); else ASQ_SK(MT_, 16); } while (0)
+        switch (mt) {
+        case 1: ASQ_SKW(1); break;
+        case 2: ASQ_SKW(2); break;
+        case 3: ASQ_SKW(3); break;
+        default: ASQ_SKW(4); break;
+        }
+#undef ASQ_SKW
+#undef ASQ_SK
     } else {
         const bool fast = (K % 16 == 0) && (((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0);
         dim3 grid((unsigned)((N + GEN_T - 1) / GEN_T), (unsigned)((M + GEN_T - 1) / GEN_T));
