@@ -6,7 +6,7 @@
 // cast, div, round, clamp, cast as separate ATen launches).
 #include "asq_common.h"
 
-namespace {
+namespace asq {
 
 // ---- per-element quantisation cores (bit-exact restatements; see oracle/w8a8.py) -------
 template <int DT> struct QRound {  // x.round().clamp().to(int8)
@@ -223,7 +223,8 @@ template <int DT> int quantize_dt(const void *x, int mode, float quant_scale, in
     }
 }
 
-}  // namespace
+}  // namespace asq
+using namespace asq;
 
 extern "C" int asq_quantize_act(const void *x, int x_dtype, int mode, float quant_scale, int8_t *xq, float *s_row,
                                 int64_t M, int64_t K, void *stream)

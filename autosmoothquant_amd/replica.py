@@ -64,7 +64,7 @@ def buffers_fingerprint(root):
             t = m._buffers.get(n)
             if t is None:
                 continue
-            b = t.detach().contiguous().view(torch.uint8).to(torch.int64)
+            b = t.detach().contiguous().reshape(-1).view(torch.uint8).to(torch.int64)
             idx = torch.arange(1, b.numel() + 1, device=b.device, dtype=torch.int64)
             acc = (acc * 1000003 + int((b * (idx % 8191 + 1)).sum().item())) % (1 << 61)
     return acc

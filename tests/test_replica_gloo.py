@@ -1,0 +1,115 @@
+"""CPU, world_size 2, gloo: the replica-parallel path (autosmoothquant_amd/replica.py) --
+row sharding, the one-time broadcast of the quantised buffers, the post-broadcast fingerprint,
+and 'every replica's rows == the single-process rows bit for bit' (the oracle stands in for the
+HIP compute, which needs a GPU; the sharding/collective logic under test is device-agnostic)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import detrng
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_model(seed):
+    from autosmoothquant_amd.layers.nn.linear import (W8A8BFP32OFP32Linear, W8A8BFP32OFP32LinearWithQuantScale,
+                                                      W8A8BFP32OFP32QKVLinear)
+    g = torch.Generator().manual_seed(seed)
+    mods = torch.nn.ModuleDict()
+    a = W8A8BFP32OFP32Linear(64, 48, True, "per-tensor")
+    b = W8A8BFP32OFP32LinearWithQuantScale(48, 64, False, "per-tensor")
+    c = W8A8BFP32OFP32QKVLinear([32, 16, 16], 64, 64, True, "per-token")
+    for m in (a, b, c):
+        m.weight = torch.randint(-128, 128, m.weight.shape, generator=g, dtype=torch.int8)
+        if m.use_bias:
+            m.bias = torch.randn(m.out_features, generator=g)
+    a.dequant_scale = torch.tensor(0.001 * (seed + 1))
+    b.dequant_scale = torch.tensor(0.002 * (seed + 1))
+    b.quant_scale = torch.tensor(0.5 + seed)
+    c.q_dequant_scale, c.k_dequant_scale, c.v_dequant_scale = (torch.tensor(0.003 * (seed + 1) * (i + 1)) for i in range(3))
+    mods["a"], mods["b"], mods["c"] = a, b, c
+    return mods
+
+
+def _oracle_forward(mods, x):
+    """x [M,64] f32 -> y [M,48] through module a, with the oracle as the compute"""
+    from oracle import w8a8 as O
+    a = mods["a"]
+    return O.linear_forward(x, "f32", a.weight.numpy(), float(a.dequant_scale), a.bias.numpy(), a.act_quant)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from autosmoothquant_amd import replica
+        mods = _make_model(seed=0 if rank == 0 else 7)  # non-source ranks start from different buffers
+        fp_before = replica.buffers_fingerprint(mods)
+        differs_before = not replica.all_ranks_equal(fp_before)
+        nbytes = replica.broadcast_quantized(mods, src=0)
+        fp = replica.buffers_fingerprint(mods)
+        same_after = replica.all_ranks_equal(fp)
+        # scalar scales stay host-side fp32 after the broadcast
+        host_ok = all(m._buffers[n].device.type == "cpu" and m._buffers[n].dtype == torch.float32
+                      for m in mods.values() for n in m._host_scalars)
+        # each rank computes its shard of a global batch; rank 0 gathers and compares with the 1-process result
+        M = 37
+        xg = detrng.act_like(5, 0, (M, 64), scale=40.0)
+        lo, hi = replica.shard_rows(M, world, rank)
+        y_local = torch.from_numpy(_oracle_forward(mods, xg[lo:hi]))
+        parts = [None] * world
+        dist.all_gather_object(parts, (lo, hi, y_local.numpy()))
+        q.put((rank, differs_before, same_after, host_ok, nbytes, fp, parts if rank == 0 else None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_rows_partition():
+    from autosmoothquant_amd import replica
+    for M in (0, 1, 7, 256, 1000):
+        for G in (1, 2, 3, 8):
+            spans = [replica.shard_rows(M, G, r) for r in range(G)]
+            assert spans[0][0] == 0 and spans[-1][1] == M
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(G - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    with pytest.raises(ValueError):
+        replica.shard_rows(4, 2, 2)
+
+
+@pytest.mark.timeout(300)
+def test_broadcast_and_row_sharding_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    fps = set()
+    for rank, differs_before, same_after, host_ok, nbytes, fp, parts in res:
+        assert differs_before, "test is vacuous if ranks start identical"
+        assert same_after and host_ok
+        assert nbytes == (48 * 64 + 64 * 48 + 64 * 64) + 4 * (48 + 64) + 4 * 6  # int8 weights + fp32 biases + 6 scalars
+        fps.add(fp)
+    assert len(fps) == 1
+    # replica rows == single-process rows, bit for bit
+    ref_mods = _make_model(seed=0)
+    xg = detrng.act_like(5, 0, (37, 64), scale=40.0)
+    ref = _oracle_forward(ref_mods, xg)
+    got = np.concatenate([p[2] for p in sorted(res[0][6], key=lambda t: t[0])], axis=0)
+    assert np.array_equal(got, ref)
