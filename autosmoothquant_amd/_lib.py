@@ -19,11 +19,12 @@ _vp, _i64, _f32, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ct
 SIGNATURES = {
     "asq_version": (_int, []),
     "asq_last_error": (ctypes.c_char_p, []),
-    "asq_gemm_i8_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
-    "asq_gemm_i8_i8": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _f32, _vp]),
+    "asq_gemm_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "asq_gemm_i8_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz, _vp]),
+    "asq_gemm_i8_i8": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _f32, _vp, _sz, _vp]),
     "asq_quantize_act": (_int, [_vp, _int, _int, _f32, _vp, _vp, _i64, _i64, _vp]),
-    "asq_linear_w8a8": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _int, _vp]),
-    "asq_linear_w8a8_workspace_bytes": (_sz, [_i64, _i64]),
+    "asq_linear_w8a8": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _int, _vp, _sz, _vp]),
+    "asq_linear_w8a8_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "asq_linear_w8a8_forward": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _int, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "asq_gemm_kernel_name": (ctypes.c_char_p, [_i64, _i64, _i64]),
 }

@@ -27,11 +27,11 @@ extern "C" const char *asq_last_error(void) { return g_err; }
 
 static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// workspace layout: [ xq int8 M*K | pad to 256 | s_row f32 M ]
-extern "C" size_t asq_linear_w8a8_workspace_bytes(int64_t M, int64_t K)
+// workspace layout: [ xq int8 M*K | pad to 256 | s_row f32 M | pad to 256 | GEMM split-K slabs ]
+extern "C" size_t asq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K)
 {
-    if (M < 0 || K < 0) return 0;
-    return round_up((size_t)M * (size_t)K, 256) + round_up((size_t)M * 4, 256);
+    if (M < 0 || K < 0 || N < 0) return 0;
+    return round_up((size_t)M * (size_t)K, 256) + round_up((size_t)M * 4, 256) + asq_gemm_workspace_bytes(M, N, K);
 }
 
 extern "C" int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t *w, void *out, int64_t M, int64_t N, int64_t K,
@@ -40,7 +40,7 @@ extern "C" int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t 
 {
     ASQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, ASQ_ERR_DIM, "asq_linear_w8a8_forward: bad dims");
     if (M == 0 || N == 0) return ASQ_OK;
-    const size_t need = asq_linear_w8a8_workspace_bytes(M, K);
+    const size_t need = round_up((size_t)M * (size_t)K, 256) + round_up((size_t)M * 4, 256);  // the GEMM part is optional
     ASQ_REQUIRE(workspace != nullptr && workspace_bytes >= need, ASQ_ERR_WORKSPACE,
                 "asq_linear_w8a8_forward: workspace %zu B < required %zu B", workspace_bytes, need);
     ASQ_REQUIRE(((uintptr_t)workspace & 255) == 0, ASQ_ERR_ALIGN, "asq_linear_w8a8_forward: workspace must be 256-B aligned");
@@ -48,6 +48,7 @@ extern "C" int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t 
     float *s_row = (float *)((char *)workspace + round_up((size_t)M * (size_t)K, 256));
     int rc = asq_quantize_act(x, x_dtype, act_mode, quant_scale, xq, s_row, M, K, stream);
     if (rc) return rc;
+    char *gws = (char *)workspace + need;
     return asq_linear_w8a8(xq, w, out, x_dtype, M, N, K, s_scalar, act_mode == ASQ_ACT_PER_TOKEN ? s_row : nullptr, s_col, bias,
-                           ASQ_EPI_SCALE_FIRST, stream);
+                           ASQ_EPI_SCALE_FIRST, workspace_bytes > need ? gws : nullptr, workspace_bytes > need ? workspace_bytes - need : 0, stream);
 }

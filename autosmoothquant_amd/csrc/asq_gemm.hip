@@ -42,26 +42,36 @@ extern "C" const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K)
     }
 }
 
-extern "C" int asq_gemm_i8_i32(const int8_t *x, const int8_t *w, int32_t *out, int64_t M, int64_t N, int64_t K, void *stream)
+extern "C" size_t asq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K)
+{
+    if (M <= 0 || N <= 0 || K <= 0 || pick_kernel(nullptr, nullptr, M, N, K) != KERN_P8) return 0;
+    const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    const int s = pick_ksplit(tiles, K, M, N, (size_t)-1);
+    return s > 1 ? (size_t)s * (size_t)M * (size_t)N * 4 : 0;
+}
+
+extern "C" int asq_gemm_i8_i32(const int8_t *x, const int8_t *w, int32_t *out, int64_t M, int64_t N, int64_t K, void *workspace,
+                               size_t workspace_bytes, void *stream)
 {
     int rc = check_gemm_args("asq_gemm_i8_i32", x, w, out, M, N, K);
     if (rc) return rc;
     ASQ_REQUIRE(((uintptr_t)out & 3) == 0, ASQ_ERR_ALIGN, "asq_gemm_i8_i32: out misaligned");
     EpiI32 epi{out, N, (N % 4 == 0) && (((uintptr_t)out & 15) == 0)};
-    return launch_gemm(x, w, M, N, K, epi, (hipStream_t)stream, "asq_gemm_i8_i32");
+    return launch_gemm(x, w, M, N, K, epi, (hipStream_t)stream, "asq_gemm_i8_i32", workspace, workspace_bytes);
 }
 
 extern "C" int asq_gemm_i8_i8(const int8_t *x, const int8_t *w, int8_t *out, int64_t M, int64_t N, int64_t K, float alpha, float beta,
-                              void *stream)
+                              void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = check_gemm_args("asq_gemm_i8_i8", x, w, out, M, N, K);
     if (rc) return rc;
     EpiI8 epi{out, N, alpha, beta, (N % 4 == 0) && (((uintptr_t)out & 3) == 0)};
-    return launch_gemm(x, w, M, N, K, epi, (hipStream_t)stream, "asq_gemm_i8_i8");
+    return launch_gemm(x, w, M, N, K, epi, (hipStream_t)stream, "asq_gemm_i8_i8", workspace, workspace_bytes);
 }
 
 extern "C" int asq_linear_w8a8(const int8_t *xq, const int8_t *w, void *out, int out_dtype, int64_t M, int64_t N, int64_t K,
-                               float s_scalar, const float *s_row, const float *s_col, const float *bias, int epi_order, void *stream)
+                               float s_scalar, const float *s_row, const float *s_col, const float *bias, int epi_order, void *workspace,
+                               size_t workspace_bytes, void *stream)
 {
     int rc = check_gemm_args("asq_linear_w8a8", xq, w, out, M, N, K);
     if (rc) return rc;
@@ -71,7 +81,7 @@ extern "C" int asq_linear_w8a8(const int8_t *xq, const int8_t *w, void *out, int
     ASQ_REQUIRE((((uintptr_t)s_row | (uintptr_t)s_col | (uintptr_t)bias) & 3) == 0, ASQ_ERR_ALIGN, "asq_linear_w8a8: scale/bias misaligned");
     const size_t vbytes = out_dtype == ASQ_F32 ? 16 : 8;
     const bool vec_ok = (N % 4 == 0) && (((uintptr_t)out & (vbytes - 1)) == 0) && ((((uintptr_t)s_col | (uintptr_t)bias) & 15) == 0);
-    DequantArgs a{xq, w, out, M, N, K, s_scalar, s_row, s_col, bias, epi_order, vec_ok};
+    DequantArgs a{xq, w, out, M, N, K, s_scalar, s_row, s_col, bias, epi_order, vec_ok, workspace, workspace_bytes};
     hipStream_t s = (hipStream_t)stream;
     switch (out_dtype) {
     case ASQ_F32: return launch_dequant<ASQ_F32>(a, s);

@@ -40,6 +40,7 @@ struct EpiI32 {
     int32_t *out;
     int64_t N;
     bool vec_ok;
+    __device__ __forceinline__ EpiI32 with_slab(int s, int64_t M, int64_t Ncols) const { return EpiI32{out + (int64_t)s * M * Ncols, N, vec_ok}; }
     __device__ __forceinline__ float row(int64_t) const { return 1.0f; }
     __device__ __forceinline__ void cols(int64_t, int64_t, v4f &, v4f &) const {}
     __device__ __forceinline__ void store4(int64_t m, int64_t n, const v4i &a, float, const v4f &, const v4f &, int64_t Ncols) const
@@ -69,6 +70,7 @@ template <int DT, bool HAS_ROW, bool HAS_COL, bool HAS_BIAS> struct EpiDequant {
     int order;
     bool vec_ok;
 
+    __device__ __forceinline__ const EpiDequant &with_slab(int, int64_t, int64_t) const { return *this; }
     __device__ __forceinline__ float row(int64_t m) const { return HAS_ROW ? s_row[m] : 1.0f; }
 
     __device__ __forceinline__ void cols(int64_t n, int64_t Ncols, v4f &sc, v4f &b) const
@@ -138,6 +140,7 @@ struct EpiI8 {  // out = sat_i8(rne(alpha*acc + beta*c)), c = previous out
     int64_t N;
     float alpha, beta;
     bool vec_ok;
+    __device__ __forceinline__ const EpiI8 &with_slab(int, int64_t, int64_t) const { return *this; }
     __device__ __forceinline__ float row(int64_t) const { return 1.0f; }
     __device__ __forceinline__ void cols(int64_t, int64_t, v4f &, v4f &) const {}
     __device__ __forceinline__ int one(int acc, int c) const
@@ -270,6 +273,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 namespace asq {
 
 // ---------------------------------------------------------------------------------
+// split-K tail: sum S int32 slabs [S][M][N] (exact, order-free) and run the fused epilogue.
+// One thread per 4 consecutive channels of one token; N % 4 == 0 (enforced by the launcher).
+// ---------------------------------------------------------------------------------
+template <class Epi>
+__global__ void __launch_bounds__(256) splitk_reduce(const int32_t *__restrict__ slabs, int S, int64_t M, int64_t N, Epi epi)
+{
+    const int64_t nq = N / 4, total = M * nq;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / nq, n = (i - m * nq) * 4;
+        const int32_t *p = slabs + m * N + n;
+        v4i a = *(const v4i *)p;
+        for (int s = 1; s < S; ++s) a += *(const v4i *)(p + (int64_t)s * M * N);
+        const float sr = Epi::kHasRow ? epi.row(m) : 1.0f;
+        v4f sc = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
+        epi.cols(n, N, sc, bb);
+        epi.store4(m, n, a, sr, sc, bb, N);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // dispatch + launch
 // ---------------------------------------------------------------------------------
 enum GemmKernel { KERN_GENERIC = 0, KERN_SKINNY = 1, KERN_P8 = 2 };
@@ -288,20 +311,64 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
     return KERN_GENERIC;
 }
 
-template <class Epi> int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, Epi epi, hipStream_t s, const char *what)
+// number of K splits for the tiled kernel: fill the 256 CUs when the M x N tile grid cannot
+static inline int pick_ksplit(int64_t tiles, int64_t K, int64_t M, int64_t N, size_t ws_bytes)
+{
+    if (N % 4 != 0) return 1;
+    const int64_t nt = K / 128;
+    {   // env ASQ_KSPLIT=n forces a split count (development / tuning aid)
+        static int forced = -2;
+        if (forced == -2) {
+            const char *e = getenv("ASQ_KSPLIT");
+            forced = e ? atoi(e) : -1;
+        }
+        if (forced > 0) {
+            int64_t f = forced > nt ? nt : forced;
+            while (f > 1 && (size_t)f * (size_t)M * (size_t)N * 4 > ws_bytes) --f;
+            return (int)f;
+        }
+    }
+    // measured on MI355X (ASQ_KSPLIT sweep, 128..2048 rows x LLaMA/OPT widths): the slab write +
+    // reduce pass costs ~2 x S x M x N x 4 B of traffic, so the optimum is ~130-200 blocks, not 256
+    if (tiles >= 118) return 1;
+    int64_t s = (176 + tiles / 2) / tiles;
+    if (s > nt / 4) s = nt / 4;              // >= 4 K-tiles (512 k) per split: keep the pipeline efficient
+    while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ws_bytes) --s;
+    return s < 1 ? 1 : (int)s;
+}
+
+template <class Epi>
+int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, Epi epi, hipStream_t s, const char *what, void *ws = nullptr,
+                size_t ws_bytes = 0)
 {
     if (M == 0 || N == 0) return ASQ_OK;
     const GemmKernel kern = pick_kernel(x, w, M, N, K);
     if (kern == KERN_P8) {
         const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
-        ASQ_REQUIRE(tm * tn < (1ll << 31), ASQ_ERR_DIM, "%s: too many tiles", what);
+        ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
+        const int ksplit = (ws != nullptr && (((uintptr_t)ws) & 15) == 0) ? pick_ksplit(tm * tn, K, M, N, ws_bytes) : 1;
+        if (ksplit > 1) {
+            // pass 1: int32 partial slabs; pass 2: reduce + the caller's epilogue
+            EpiI32 slab{(int32_t *)ws, N, true};
+            auto kfn = gemm_i8_p8<EpiI32>;
+            hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES);
+            if (e != hipSuccess) {
+                asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+                return (int)e;
+            }
+            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn * ksplit)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, ksplit, slab);
+            int64_t blocks = (M * (N / 4) + 255) / 256;
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL((splitk_reduce<Epi>), dim3((unsigned)blocks), dim3(256), 0, s, (const int32_t *)ws, ksplit, M, N, epi);
+            return asq_after_launch(s, what);
+        }
         auto kfn = gemm_i8_p8<Epi>;
         hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES);
         if (e != hipSuccess) {
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
             return (int)e;
         }
-        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, epi);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, epi);
     } else if (kern == KERN_SKINNY) {
         const int mt = (int)((M + 15) / 16);
         const int64_t blocks = (N + 15) / 16;
@@ -336,13 +403,15 @@ struct DequantArgs {
     const float *s_row, *s_col, *bias;
     int order;
     bool vec_ok;
+    void *ws;
+    size_t ws_bytes;
 };
 template <int DT> int launch_dequant(const DequantArgs &a, hipStream_t s);
 
 template <int DT, bool R, bool C, bool B> static inline int launch_dequant_one(const DequantArgs &a, hipStream_t s)
 {
     return launch_gemm(a.xq, a.w, a.M, a.N, a.K, EpiDequant<DT, R, C, B>{a.out, a.N, a.s_scalar, a.s_row, a.s_col, a.bias, a.order, a.vec_ok}, s,
-                       "asq_linear_w8a8");
+                       "asq_linear_w8a8", a.ws, a.ws_bytes);
 }
 
 template <int DT> static inline int launch_dequant_impl(const DequantArgs &a, hipStream_t s)

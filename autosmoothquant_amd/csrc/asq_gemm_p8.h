@@ -91,7 +91,7 @@ __device__ __forceinline__ void p8_dma16(const int8_t *sbase, unsigned voff, uns
 
 template <class Epi, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N,
-                                                     int64_t K, int tiles_m, int tiles_n, Epi epi)
+                                                     int64_t K, int tiles_m, int tiles_n, int ksplit, Epi epi_in)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -99,9 +99,14 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
     const int wm = wave >> 2, wn = wave & 3;
 
     P8_BLK(0);
+    // split-K (ksplit > 1, int32 slabs only): logical id = split * ntiles + tile, so the blocks an XCD
+    // receives share one K range and neighbouring tiles (operand panels stay L2-local)
     constexpr int GM = 4;
     const int nwg = tiles_m * tiles_n;
-    const int id = xcd_remap(blockIdx.x, nwg);
+    const int lid = xcd_remap(blockIdx.x, nwg * ksplit);
+    const int split = lid / nwg;
+    const int id = lid - split * nwg;
+    const Epi epi = epi_in.with_slab(split, M, N);
     const int per_group = GM * tiles_n;
     const int group = id / per_group, in_group = id - group * per_group;
     const int first_m = group * GM;
@@ -111,8 +116,10 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
 
     // ---- DMA sources: uniform tile base (SGPR pair, + k advanced per K-tile) + 32-bit lane offset.
     // This wave fills row-groups 2*wave, 2*wave+1 (8 rows each) of every unit.
-    const int8_t *const xbase = x + m0 * K;  // wave-uniform
-    const int8_t *const wbase = w + n0 * K;
+    const int nt_all = (int)(K / 128);
+    const int kt0 = (int)((int64_t)nt_all * split / ksplit), kt1 = (int)((int64_t)nt_all * (split + 1) / ksplit);
+    const int8_t *const xbase = x + m0 * K + (int64_t)kt0 * 128;  // wave-uniform
+    const int8_t *const wbase = w + n0 * K + (int64_t)kt0 * 128;
     const int64_t mrem = M - m0 - 1, nrem = N - n0 - 1;  // last valid local row
     unsigned voff[4][2];  // [kind][i]
 #pragma unroll
@@ -156,7 +163,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[a][b][c] = (v16i){0};
 
-    const int nt = (int)(K / 128);
+    const int nt = kt1 - kt0;  // K-tiles of this block (>= 1)
     const int klast = (nt - 1) * 128;
 
     auto issue = [&](int kind, int stage, int k0) {

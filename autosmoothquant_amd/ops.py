@@ -28,6 +28,13 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _gemm_ws(M, N, K, dev):
+    """split-K scratch for shapes whose tile grid cannot fill the chip (None when not needed);
+    comes from torch's stream-ordered caching allocator, so concurrent streams never share it"""
+    n = L.lib().asq_gemm_workspace_bytes(M, N, K)
+    return (torch.empty((n,), dtype=torch.uint8, device=dev), n) if n else (None, 0)
+
+
 def _same_device(*ts):
     d = None
     for t in ts:
@@ -49,8 +56,9 @@ def gemm_i8_i32(x, w, out):
         raise ValueError(f"shape mismatch: input {tuple(x.shape)}, weight {tuple(w.shape)}, out {tuple(out.shape)}")
     dev = _same_device(x, w, out)
     with torch.cuda.device(dev):
-        L.check(L.lib().asq_gemm_i8_i32(x.data_ptr(), w.data_ptr(), out.data_ptr(), x.shape[0], w.shape[0], x.shape[1], _stream(x)),
-                "asq_gemm_i8_i32")
+        ws, n = _gemm_ws(x.shape[0], w.shape[0], x.shape[1], dev)
+        L.check(L.lib().asq_gemm_i8_i32(x.data_ptr(), w.data_ptr(), out.data_ptr(), x.shape[0], w.shape[0], x.shape[1], _ptr(ws), n,
+                                        _stream(x)), "asq_gemm_i8_i32")
     return out
 
 
@@ -63,8 +71,9 @@ def gemm_i8_i8(x, w, out, alpha, beta=0.0):
         raise ValueError(f"shape mismatch: input {tuple(x.shape)}, weight {tuple(w.shape)}, out {tuple(out.shape)}")
     dev = _same_device(x, w, out)
     with torch.cuda.device(dev):
+        ws, n = _gemm_ws(x.shape[0], w.shape[0], x.shape[1], dev)
         L.check(L.lib().asq_gemm_i8_i8(x.data_ptr(), w.data_ptr(), out.data_ptr(), x.shape[0], w.shape[0], x.shape[1],
-                                       float(alpha), float(beta), _stream(x)), "asq_gemm_i8_i8")
+                                       float(alpha), float(beta), _ptr(ws), n, _stream(x)), "asq_gemm_i8_i8")
     return out
 
 
@@ -103,9 +112,10 @@ def linear_w8a8(xq, w, out_dtype, s_scalar=1.0, s_row=None, s_col=None, bias=Non
             raise ValueError("out has wrong dtype/shape")
     dev = _same_device(xq, w, out, s_row, s_col, bias)
     with torch.cuda.device(dev):
+        ws, n = _gemm_ws(M, N, K, dev)
         L.check(L.lib().asq_linear_w8a8(xq.data_ptr(), w.data_ptr(), out.data_ptr(), _DT[out_dtype], M, N, K, float(s_scalar),
                                         _ptr(s_row), _ptr(s_col), _ptr(bias),
-                                        L.ASQ_EPI_SCALE_FIRST if order == "scale_first" else L.ASQ_EPI_ACC_FIRST, _stream(xq)),
+                                        L.ASQ_EPI_SCALE_FIRST if order == "scale_first" else L.ASQ_EPI_ACC_FIRST, _ptr(ws), n, _stream(xq)),
                 "asq_linear_w8a8")
     return out
 
@@ -130,7 +140,7 @@ def linear_w8a8_forward(x2d, w, act_mode, quant_scale, s_scalar, s_col=None, bia
     if M == 0 or N == 0:
         return out
     lib = L.lib()
-    nbytes = lib.asq_linear_w8a8_workspace_bytes(M, K)
+    nbytes = lib.asq_linear_w8a8_workspace_bytes(M, N, K)
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)  # caching allocator: 512-B aligned, stream-ordered
     with torch.cuda.device(dev):
         L.check(lib.asq_linear_w8a8_forward(x2d.data_ptr(), _DT[x2d.dtype], w.data_ptr(), out.data_ptr(), M, N, K,

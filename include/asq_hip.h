@@ -64,7 +64,16 @@ const char *asq_last_error(void);
  * Also serves I8CUGEMM::linear_a8_w8_o32 (bindings.cpp:52-67): that flavour differs only in
  * cuBLASLt's COL32 operand layouts, which have no gfx950 counterpart. */
 int asq_gemm_i8_i32(const int8_t *x, const int8_t *w, int32_t *out,
-                    int64_t M, int64_t N, int64_t K, void *stream);
+                    int64_t M, int64_t N, int64_t K,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* Optional scratch for the GEMM entry points.  When the M x N tile grid cannot fill the 256 CUs
+ * (e.g. OPT-13B fc2 at 256 rows: 20 tiles) the dispatcher splits K across CUs, writes exact int32
+ * partial slabs into `workspace` and reduces them in a second launch that applies the epilogue.
+ * asq_gemm_workspace_bytes() returns the size that enables this for a shape (0 = never needed).
+ * workspace may be NULL / smaller (then fewer or no K splits are used); it must be 16-B aligned and
+ * not shared by concurrently running calls. */
+size_t asq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
 /* ---- K3/K4/K5: I8CUGEMM::linear_a8_w8_o8 / linear_a8_w8_o8_ / linear_a8_w8_b8_o8_
  * (bindings.cpp:86-142 -> cublasINT8MMWrapper.cc:360-672)
@@ -72,7 +81,8 @@ int asq_gemm_i8_i32(const int8_t *x, const int8_t *w, int32_t *out,
  * c = the previous contents of `out` when beta != 0 (cuBLASLt C==D in-place), ignored when beta == 0.
  * For linear_a8_w8_b8_o8_ the caller pre-fills out with the broadcast int8 bias (bindings.cpp:132). */
 int asq_gemm_i8_i8(const int8_t *x, const int8_t *w, int8_t *out,
-                   int64_t M, int64_t N, int64_t K, float alpha, float beta, void *stream);
+                   int64_t M, int64_t N, int64_t K, float alpha, float beta,
+                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- GEMM prologue: the activation quantisers of layers/nn/linear.py
  * x is [M,K] of x_dtype.  xq is int8 [M,K].
@@ -93,12 +103,13 @@ int asq_quantize_act(const void *x, int x_dtype, int mode, float quant_scale,
 int asq_linear_w8a8(const int8_t *xq, const int8_t *w, void *out, int out_dtype,
                     int64_t M, int64_t N, int64_t K,
                     float s_scalar, const float *s_row, const float *s_col, const float *bias,
-                    int epi_order, void *stream);
+                    int epi_order, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- whole module forward: W8A8BFP32OFP32Linear / ...QKVLinear / ...LinearWithQuantScale .forward
  * (linear.py:83-106, :158-208, :278-302) = asq_quantize_act + asq_linear_w8a8 on `stream`.
- * out has x's dtype.  workspace: asq_linear_w8a8_workspace_bytes(M,K) bytes, 256-B aligned. */
-size_t asq_linear_w8a8_workspace_bytes(int64_t M, int64_t K);
+ * out has x's dtype.  workspace: asq_linear_w8a8_workspace_bytes(M,N,K) bytes (int8 activations + row scales +
+ * the GEMM scratch above), 256-B aligned. */
+size_t asq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t *w, void *out,
                             int64_t M, int64_t N, int64_t K,
                             int act_mode, float quant_scale,

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     from autosmoothquant_amd import _lib
     h = _lib.lib()
     names = _declared_symbols()
-    assert len(names) >= 9
+    assert len(names) >= 10
     for n in names:
         assert hasattr(h, n), f"libasq_hip.so lacks {n}"
         assert n in _lib.SIGNATURES, f"_lib.SIGNATURES lacks {n}"
@@ -31,13 +31,16 @@ def test_library_exports_every_declared_symbol():
 def test_argument_errors_without_gpu():
     from autosmoothquant_amd import _lib
     h = _lib.lib()
-    assert h.asq_gemm_i8_i32(None, None, None, -1, 4, 4, None) == -2          # ASQ_ERR_DIM
+    assert h.asq_gemm_i8_i32(None, None, None, -1, 4, 4, None, 0, None) == -2          # ASQ_ERR_DIM
     assert b"bad dims" in h.asq_last_error()
-    assert h.asq_gemm_i8_i32(None, None, None, 4, 4, 4, None) == -1           # ASQ_ERR_NULL
+    assert h.asq_gemm_i8_i32(None, None, None, 4, 4, 4, None, 0, None) == -1           # ASQ_ERR_NULL
     assert h.asq_quantize_act(None, 7, 0, 1.0, None, None, 1, 1, None) == -3  # ASQ_ERR_DTYPE
     assert h.asq_linear_w8a8_forward(None, 1, None, None, 4, 4, 4, 0, 1.0, 1.0, None, None, None, 0, None) == -5
-    assert h.asq_gemm_i8_i32(None, None, None, 0, 4, 4, None) == 0            # empty problem is a no-op
-    assert h.asq_linear_w8a8_workspace_bytes(3, 5) == 256 + 256
+    assert h.asq_gemm_i8_i32(None, None, None, 0, 4, 4, None, 0, None) == 0            # empty problem is a no-op
+    assert h.asq_linear_w8a8_workspace_bytes(3, 7, 5) == 256 + 256
+    assert h.asq_gemm_workspace_bytes(4096, 4096, 4096) == 0            # 256 tiles fill the chip: no split-K
+    assert h.asq_gemm_workspace_bytes(256, 5120, 20480) == 9 * 256 * 5120 * 4   # OPT-13B fc2: 20 tiles -> 9 K splits
+    assert h.asq_gemm_workspace_bytes(32, 4096, 4096) == 0              # skinny path
     assert h.asq_gemm_kernel_name(4096, 4096, 4096) == b"p8"
     assert h.asq_gemm_kernel_name(4, 4096, 4095) == b"generic"
 

@@ -25,13 +25,13 @@ int main(int argc, char** argv)
         const int batch = 24;
         int nb = (int)((300e6 / (double)(sh.N * sh.K)) + 1); if (nb > NB) nb = NB;   // rotate through > 256 MiB when the shape allows
         // weights for shape sh live at the start of each buffer (contiguous [N,K])
-        for (int i = 0; i < 5; ++i) asq_linear_w8a8(x, w[i % NB], out, ASQ_F16, sh.M, sh.N, sh.K, 1e-4f, nullptr, nullptr, nullptr, 0, nullptr);
+        for (int i = 0; i < 5; ++i) asq_linear_w8a8(x, w[i % NB], out, ASQ_F16, sh.M, sh.N, sh.K, 1e-4f, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
         CK(hipDeviceSynchronize());
         float best = 1e9, sum = 0; const int it = 8;
         for (int r = 0; r < it; ++r) {
             CK(hipEventRecord(a));
             for (int i = 0; i < batch; ++i) {
-                int rc = asq_linear_w8a8(x, w[i % NB], out, ASQ_F16, sh.M, sh.N, sh.K, 1e-4f, nullptr, nullptr, nullptr, 0, nullptr);
+                int rc = asq_linear_w8a8(x, w[i % NB], out, ASQ_F16, sh.M, sh.N, sh.K, 1e-4f, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
                 if (rc) { printf("rc=%d %s\n", rc, asq_last_error()); return 1; }
             }
             CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
