@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libasq_hip.so")
 ASQ_F32, ASQ_F16, ASQ_BF16 = 0, 1, 2
 ASQ_ACT_ROUND, ASQ_ACT_DIV, ASQ_ACT_PER_TOKEN = 0, 1, 2
 ASQ_EPI_SCALE_FIRST, ASQ_EPI_ACC_FIRST = 0, 1
+ASQ_FP8_PER_TOKEN, ASQ_FP8_PER_TENSOR, ASQ_FP8_STATIC = 0, 1, 2
 
 _lock = threading.Lock()
 _lib = None
@@ -27,6 +28,9 @@ SIGNATURES = {
     "asq_linear_w8a8_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "asq_linear_w8a8_forward": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _int, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "asq_gemm_kernel_name": (ctypes.c_char_p, [_i64, _i64, _i64]),
+    "asq_quantize_act_fp8": (_int, [_vp, _int, _int, _f32, _vp, _vp, _i64, _i64, _vp]),
+    "asq_linear_fp8": (_int, [_vp, _vp, _int, _vp, _int, _i64, _i64, _i64, _vp, _int, _f32, _f32, _vp, _vp]),
+    "asq_cast_e5m2": (_int, [_vp, _int, _vp, _i64, _vp]),
 }
 
 

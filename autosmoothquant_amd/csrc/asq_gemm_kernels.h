@@ -33,9 +33,50 @@ typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
 // ---------------------------------------------------------------------------------
+// matrix-core policies: one "MMA step" consumes 16 k-bytes per lane of each operand (a v4i)
+// ---------------------------------------------------------------------------------
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef long v2l __attribute__((ext_vector_type(2)));
+
+struct MmaI8 {  // int8 x int8 -> int32, exact: one v_mfma_i32_32x32x32_i8
+    using acc_t = v16i;
+    using acc4_t = v4i;
+    static constexpr bool kIsInt = true;
+    static __device__ __forceinline__ acc_t mma(const v4i &a, const v4i &b, const acc_t &c)
+    {
+        return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+    }
+};
+
+struct MmaFp8 {  // OCP e4m3fn x e4m3fn -> fp32: two v_mfma_f32_32x32x16_fp8_fp8 on the low / high 8 k-bytes
+    using acc_t = v16f;
+    using acc4_t = v4f;
+    static constexpr bool kIsInt = false;
+    static __device__ __forceinline__ acc_t mma(const v4i &a, const v4i &b, const acc_t &c)
+    {
+        const v2l al = __builtin_bit_cast(v2l, a), bl = __builtin_bit_cast(v2l, b);
+        acc_t r = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(al[0], bl[0], c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(al[1], bl[1], r, 0, 0, 0);
+    }
+};
+
+struct MmaBf8 {  // OCP e5m2 x e5m2 -> fp32
+    using acc_t = v16f;
+    using acc4_t = v4f;
+    static constexpr bool kIsInt = false;
+    static __device__ __forceinline__ acc_t mma(const v4i &a, const v4i &b, const acc_t &c)
+    {
+        const v2l al = __builtin_bit_cast(v2l, a), bl = __builtin_bit_cast(v2l, b);
+        acc_t r = __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(al[0], bl[0], c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(al[1], bl[1], r, 0, 0, 0);
+    }
+};
+
+// ---------------------------------------------------------------------------------
 // epilogue functors
 // ---------------------------------------------------------------------------------
 struct EpiI32 {
+    using Mma = MmaI8;
     static constexpr bool kHasRow = false, kHasCol = false, kHasBias = false;
     int32_t *out;
     int64_t N;
@@ -60,6 +101,7 @@ struct EpiI32 {
 // out = dequant(acc) (+bias) -> DT.  HAS_* are compile-time so the hot instantiations carry no
 // dead loads or branches; `order` is a wave-uniform runtime select.
 template <int DT, bool HAS_ROW, bool HAS_COL, bool HAS_BIAS> struct EpiDequant {
+    using Mma = MmaI8;
     static constexpr bool kHasRow = HAS_ROW, kHasCol = HAS_COL, kHasBias = HAS_BIAS;
     void *out;
     int64_t N;
@@ -135,6 +177,7 @@ template <int DT, bool HAS_ROW, bool HAS_COL, bool HAS_BIAS> struct EpiDequant {
 };
 
 struct EpiI8 {  // out = sat_i8(rne(alpha*acc + beta*c)), c = previous out
+    using Mma = MmaI8;
     static constexpr bool kHasRow = false, kHasCol = false, kHasBias = false;
     int8_t *out;
     int64_t N;
@@ -169,6 +212,64 @@ struct EpiI8 {  // out = sat_i8(rne(alpha*acc + beta*c)), c = previous out
     }
 };
 
+// fp8 linear (reference easy_fp8_gemm, linear.py:336-369): out = acc_f32 * (a_scale * w_scale) (+ bias).
+// a_scale: device pointer (per-token [M], or per-tensor [1] produced on the device by the dynamic
+// quantiser) or, when null, the host scalar.  Tolerance-checked (the reference dequantises both
+// operands and calls F.linear; its summation order is unspecified).
+template <int DT, bool HAS_BIAS, class MMA_ = MmaFp8> struct EpiFp8 {
+    using Mma = MMA_;
+    static constexpr bool kHasRow = true, kHasCol = false, kHasBias = HAS_BIAS;
+    void *out;
+    int64_t N;
+    const float *a_scale_dev;
+    bool a_per_token;
+    float a_scale_host, w_scale;
+    const float *bias;
+    bool vec_ok;
+    __device__ __forceinline__ const EpiFp8 &with_slab(int, int64_t, int64_t) const { return *this; }
+    __device__ __forceinline__ float row(int64_t m) const { return a_scale_dev ? (a_per_token ? a_scale_dev[m] : a_scale_dev[0]) : a_scale_host; }
+    __device__ __forceinline__ void cols(int64_t n, int64_t Ncols, v4f &sc, v4f &b) const
+    {
+        sc = (v4f){w_scale, w_scale, w_scale, w_scale};
+        b = (v4f){0.f, 0.f, 0.f, 0.f};
+        if constexpr (HAS_BIAS) {
+            if (vec_ok && n + 3 < Ncols) {
+                b = *(const v4f *)(bias + n);
+            } else {
+                if (n < Ncols) b[0] = bias[n];
+                if (n + 1 < Ncols) b[1] = bias[n + 1];
+                if (n + 2 < Ncols) b[2] = bias[n + 2];
+                if (n + 3 < Ncols) b[3] = bias[n + 3];
+            }
+        }
+    }
+    __device__ __forceinline__ void store4(int64_t m, int64_t n, const v4f &a, float sr, const v4f &sc, const v4f &b, int64_t Ncols) const
+    {
+        using E = ElemT<DT>;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = __fmul_rn(a[i], __fmul_rn(sr, sc[i]));
+            if constexpr (HAS_BIAS) v[i] = __fadd_rn(v[i], b[i]);
+        }
+        typename E::type *p = (typename E::type *)out + m * N + n;
+        if (vec_ok && n + 3 < Ncols) {
+            if constexpr (DT == ASQ_F32) {
+                *(v4f *)p = (v4f){v[0], v[1], v[2], v[3]};
+            } else {
+                const uint32_t lo = (uint32_t)E::store(v[0]) | ((uint32_t)E::store(v[1]) << 16);
+                const uint32_t hi = (uint32_t)E::store(v[2]) | ((uint32_t)E::store(v[3]) << 16);
+                *(uint2 *)p = make_uint2(lo, hi);
+            }
+        } else {
+            if (n < Ncols) p[0] = E::store(v[0]);
+            if (n + 1 < Ncols) p[1] = E::store(v[1]);
+            if (n + 2 < Ncols) p[2] = E::store(v[2]);
+            if (n + 3 < Ncols) p[3] = E::store(v[3]);
+        }
+    }
+};
+
 // Wave-level epilogue over NTN x NTM accumulator tiles; tile (in, im) covers
 // n in [nw0 + 32*in, +32), m in [mw0 + mstep(im), +32).  `get(in, im)` returns the v16i.
 template <int NTN, int NTM, class Epi, class Get, class MOff>
@@ -199,11 +300,12 @@ __device__ __forceinline__ void epilogue_wave(const Epi &epi, Get get, MOff moff
         if (mrow[im] >= M) continue;
 #pragma unroll
         for (int in = 0; in < NTN; ++in) {
-            const v16i a = get(in, im);
+            const typename Epi::Mma::acc_t a = get(in, im);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int64_t n = nw0 + in * 32 + 8 * g + 4 * (lane >> 5);
-                if (n < N) epi.store4(mrow[im], n, (v4i){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g], N);
+                if (n < N)
+                    epi.store4(mrow[im], n, (typename Epi::Mma::acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g], N);
             }
         }
     }
@@ -237,7 +339,8 @@ __global__ void __launch_bounds__(256) gemm_i8_generic(const int8_t *__restrict_
     const int wm = wave >> 1, wn = wave & 1;
     const int64_t m0 = (int64_t)blockIdx.y * GEN_T, n0 = (int64_t)blockIdx.x * GEN_T;
     const int lrow = tid >> 2, lchunk = tid & 3;
-    v16i acc = {0};
+    using MMA = typename Epi::Mma;
+    typename MMA::acc_t acc = {0};
     for (int64_t k0 = 0; k0 < K; k0 += GEN_T) {
         v4i vx = load16_guarded(x, K, m0 + lrow, M, k0 + lchunk * 16, K, fast);
         v4i vw = load16_guarded(w, K, n0 + lrow, N, k0 + lchunk * 16, K, fast);
@@ -249,11 +352,11 @@ __global__ void __launch_bounds__(256) gemm_i8_generic(const int8_t *__restrict_
         for (int ks = 0; ks < 2; ++ks) {
             v4i a = *(const v4i *)(ws + (wn * 32 + (lane & 31)) * GEN_LD + ks * 32 + (lane >> 5) * 16);
             v4i b = *(const v4i *)(xs + (wm * 32 + (lane & 31)) * GEN_LD + ks * 32 + (lane >> 5) * 16);
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
+            acc = MMA::mma(a, b, acc);
         }
     }
     epilogue_wave<1, 1>(
-        epi, [&](int, int) -> const v16i & { return acc; }, [](int) { return 0; }, m0 + wm * 32, n0 + wn * 32, lane, M, N);
+        epi, [&](int, int) -> const typename MMA::acc_t & { return acc; }, [](int) { return 0; }, m0 + wm * 32, n0 + wn * 32, lane, M, N);
 }
 
 // bijective XCD-aware remap: consecutive logical ids land on the same XCD (its private L2
@@ -337,17 +440,38 @@ static inline int pick_ksplit(int64_t tiles, int64_t K, int64_t M, int64_t N, si
     return s < 1 ? 1 : (int)s;
 }
 
+template <class Epi> void launch_skinny(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, const Epi &epi, hipStream_t s)
+{
+    const int mt = (int)((M + 15) / 16);
+    const int64_t blocks = (N + 15) / 16;
+    // enough waves to cover 256 CUs x 16 wave slots; few blocks -> more waves per block
+    const int wpb = blocks * 4 >= 4096 ? 4 : (blocks * 8 >= 4096 ? 8 : 16);
+    dim3 grid((unsigned)blocks), block((unsigned)(wpb * 64));
+#define ASQ_SK(MT_, W_) hipLaunchKernelGGL((gemm_i8_skinny<Epi, MT_, W_>), grid, block, 0, s, x, w, M, N, K, epi)
+#define ASQ_SKW(MT_) do { if (wpb == 4) ASQ_SK(MT_, 4); else if (wpb == 8) ASQ_SK(MT_, 8); else ASQ_SK(MT_, 16); } while (0)
+    switch (mt) {
+    case 1: ASQ_SKW(1); break;
+    case 2: ASQ_SKW(2); break;
+    case 3: ASQ_SKW(3); break;
+    default: ASQ_SKW(4); break;
+    }
+#undef ASQ_SKW
+#undef ASQ_SK
+}
+
 template <class Epi>
 int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, Epi epi, hipStream_t s, const char *what, void *ws = nullptr,
                 size_t ws_bytes = 0)
 {
     if (M == 0 || N == 0) return ASQ_OK;
-    const GemmKernel kern = pick_kernel(x, w, M, N, K);
+    constexpr bool kInt = Epi::Mma::kIsInt;
+    GemmKernel kern = pick_kernel(x, w, M, N, K);
+    if (!kInt && kern == KERN_SKINNY) kern = KERN_P8;  // fp8: no weight-streaming variant yet
     if (kern == KERN_P8) {
         const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
         ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
-        const int ksplit = (ws != nullptr && (((uintptr_t)ws) & 15) == 0) ? pick_ksplit(tm * tn, K, M, N, ws_bytes) : 1;
-        if (ksplit > 1) {
+        const int ksplit = (kInt && ws != nullptr && (((uintptr_t)ws) & 15) == 0) ? pick_ksplit(tm * tn, K, M, N, ws_bytes) : 1;
+        if constexpr (kInt) if (ksplit > 1) {
             // pass 1: int32 partial slabs; pass 2: reduce + the caller's epilogue
             EpiI32 slab{(int32_t *)ws, N, true};
             auto kfn = gemm_i8_p8<EpiI32>;
@@ -370,21 +494,7 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
         }
         hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, epi);
     } else if (kern == KERN_SKINNY) {
-        const int mt = (int)((M + 15) / 16);
-        const int64_t blocks = (N + 15) / 16;
-        // enough waves to cover 256 CUs x 16 wave slots; few blocks -> more waves per block
-        const int wpb = blocks * 4 >= 4096 ? 4 : (blocks * 8 >= 4096 ? 8 : 16);
-        dim3 grid((unsigned)blocks), block((unsigned)(wpb * 64));
-#define ASQ_SK(MT_, W_) hipLaunchKernelGGL((gemm_i8_skinny<Epi, MT_, W_>), grid, block, 0, s, x, w, M, N, K, epi)
-#define ASQ_SKW(MT_) do { if (wpb == 4) ASQ_SK(MT_, 4); else if (wpb == 8) ASQ_SK(MT_, 8); else ASQ_SK(MT_, 16); } while (0)
-        switch (mt) {
-        case 1: ASQ_SKW(1); break;
-        case 2: ASQ_SKW(2); break;
-        case 3: ASQ_SKW(3); break;
-        default: ASQ_SKW(4); break;
-        }
-#undef ASQ_SKW
-#undef ASQ_SK
+        if constexpr (kInt) launch_skinny(x, w, M, N, K, epi, s);
     } else {
         const bool fast = (K % 16 == 0) && (((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0);
         dim3 grid((unsigned)((N + GEN_T - 1) / GEN_T), (unsigned)((M + GEN_T - 1) / GEN_T));

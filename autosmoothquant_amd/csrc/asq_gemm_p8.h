@@ -61,13 +61,13 @@ static __device__ unsigned long long p8_blk[4096][6];  // ABL & 128: per-block {
 #define P8_STAMP(i) do { if constexpr (ABL & 32) st[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define P8_ACCUM(ph) do { if constexpr (ABL & 32) { _Pragma("unroll") for (int q_ = 0; q_ < 7; ++q_) tacc[ph][q_] += st[q_ + 1] - st[q_]; } } while (0)
 
-template <int ABL> __device__ __forceinline__ v16i p8_mfma(const v4i &a, const v4i &b, const v16i &c)
+template <int ABL, class MMA> __device__ __forceinline__ typename MMA::acc_t p8_mfma(const v4i &a, const v4i &b, const typename MMA::acc_t &c)
 {
     if constexpr (ABL & 4) {
         asm volatile("" ::"v"(a), "v"(b));  // keep the fragment loads alive
         return c;
     } else {
-        return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
+        return MMA::mma(a, b, c);
     }
 }
 typedef const __attribute__((address_space(3))) v4i *p8_lds_v4i;
@@ -155,13 +155,15 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
             asm volatile("" : "+v"(xb[s][ks]), "+v"(wbp[s][ks]));
         }
 
-    v16i acc[2][2][2];  // [m-half][n-half][j]
+    using MMA = typename Epi::Mma;
+    using acc_t = typename MMA::acc_t;
+    acc_t acc[2][2][2];  // [m-half][n-half][j]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) acc[a][b][c] = (v16i){0};
+            for (int c = 0; c < 2; ++c) acc[a][b][c] = (acc_t){0};
 
     const int nt = kt1 - kt0;  // K-tiles of this block (>= 1)
     const int klast = (nt - 1) * 128;
@@ -214,7 +216,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[0][0][j] = p8_mfma<ABL>(wa[ks], xf[j][ks], acc[0][0][j]);
+            for (int j = 0; j < 2; ++j) acc[0][0][j] = p8_mfma<ABL, MMA>(wa[ks], xf[j][ks], acc[0][0][j]);
         P8_PRIO(0);
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(6);
@@ -240,7 +242,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[0][1][j] = p8_mfma<ABL>(wb[ks], xf[j][ks], acc[0][1][j]);
+            for (int j = 0; j < 2; ++j) acc[0][1][j] = p8_mfma<ABL, MMA>(wb[ks], xf[j][ks], acc[0][1][j]);
         P8_PRIO(0);
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(6);
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[1][1][j] = p8_mfma<ABL>(wb[ks], xf[j][ks], acc[1][1][j]);
+            for (int j = 0; j < 2; ++j) acc[1][1][j] = p8_mfma<ABL, MMA>(wb[ks], xf[j][ks], acc[1][1][j]);
         P8_PRIO(0);
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(6);
@@ -290,7 +292,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[1][0][j] = p8_mfma<ABL>(wa[ks], xf[j][ks], acc[1][0][j]);
+            for (int j = 0; j < 2; ++j) acc[1][0][j] = p8_mfma<ABL, MMA>(wa[ks], xf[j][ks], acc[1][0][j]);
         P8_PRIO(0);
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(6);
@@ -317,7 +319,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
 
     // accumulator tile (in = n-half, im = 2*m-half + j) -> rows m0 + wm*128 + 32*im, cols n0 + wn*64 + 32*in
     epilogue_wave<2, 4>(
-        epi, [&](int in, int im) -> const v16i & { return acc[im >> 1][in][im & 1]; }, [](int im) { return im * 32; }, m0 + wm * 128, n0 + wn * 64, lane,
+        epi, [&](int in, int im) -> const acc_t & { return acc[im >> 1][in][im & 1]; }, [](int im) { return im * 32; }, m0 + wm * 128, n0 + wn * 64, lane,
         M, N);
     if constexpr (ABL & 128) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -92,3 +92,64 @@ def dequantize_activation_w_per_channel_a_per_token(q_act, w_scales, a_scales):
 def dequantize_activation_w_per_channel_a_per_tensor(q_act, w_scales, a_scales):
     out = q_act.to(torch.float32) * w_scales.reshape(1, -1) * a_scales
     return out.to(a_scales.dtype)
+
+
+##### FP8 (OCP e4m3fn) -- reference quantization.py:126-211 ########################################
+import re as _re
+
+
+def new_dtype_byte_size(dtype):
+    """Byte size of a dtype parsed from its name (float8_e4m3fn -> 1): the reference installs this over
+    transformers.modeling_utils.dtype_byte_size so fp8 checkpoints can be sharded (quantization.py:126-136)."""
+    if dtype == torch.bool:
+        return 1 / 8
+    m = _re.search(r"[^\d](\d+)_?", str(dtype))
+    if m is None:
+        raise ValueError(f"`dtype` is not a valid dtype: {dtype}.")
+    return int(m.groups()[0]) // 8
+
+
+try:  # same monkey-patch as the reference, when the installed transformers still has the hook
+    import transformers.modeling_utils as _tmu
+    if hasattr(_tmu, "dtype_byte_size"):
+        _tmu.dtype_byte_size = new_dtype_byte_size
+except Exception:  # transformers absent or incompatible: nothing to patch
+    pass
+
+_E4M3 = torch.finfo(torch.float8_e4m3fn)
+
+
+def per_tensor_quantize_fp8(tensor):
+    """(float8_e4m3fn tensor, scale) with scale = absmax / 448 as a 0-dim tensor of the input dtype.
+    Empty tensors (empty MoE experts) use the fixed range [-16, 16].  On a HIP tensor the per-forward
+    version of this is ops.quantize_act_fp8(x, "per-tensor")."""
+    if tensor.numel() == 0:
+        lo, hi = torch.tensor(-16.0, dtype=tensor.dtype), torch.tensor(16.0, dtype=tensor.dtype)
+    else:
+        lo, hi = tensor.aminmax()
+    scale = torch.maximum(lo.abs(), hi.abs()) / _E4M3.max
+    q = (tensor / scale).clamp(min=_E4M3.min, max=_E4M3.max).to(torch.float8_e4m3fn)
+    return q, scale
+
+
+def per_token_quantize_fp8(tensor):
+    assert tensor.numel() > 0
+    scale = tensor.abs().max(dim=-1, keepdim=True)[0].div(_E4M3.max).to(torch.float32)
+    q = (tensor / scale).clamp(min=_E4M3.min, max=_E4M3.max).to(torch.float8_e4m3fn)
+    return q, scale
+
+
+def static_per_tensor_quantize_fp8(tensor, inv_scale):
+    return (tensor / inv_scale).clamp(min=_E4M3.min, max=_E4M3.max).to(torch.float8_e4m3fn)
+
+
+def fake_per_tensor_quantize_fp8(tensor):
+    assert tensor.numel() > 0
+    scale = tensor.abs().max().div(_E4M3.max).to(torch.float32)
+    return (tensor / scale).clamp(min=_E4M3.min, max=_E4M3.max).mul(scale)
+
+
+def fake_per_token_quantize_fp8(tensor):
+    assert tensor.numel() > 0
+    scale = tensor.abs().max(dim=-1, keepdim=True)[0].div(_E4M3.max).to(torch.float32)
+    return (tensor / scale).clamp(min=_E4M3.min, max=_E4M3.max).mul(scale)

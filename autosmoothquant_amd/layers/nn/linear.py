@@ -223,3 +223,185 @@ class W8A8BFP32OFP32LinearWithQuantScale(_W8A8Base):
         if has_bias:
             q.bias = module.bias.to(torch.float32).to(save_device)
         return q
+
+
+##### FP8 linears (reference linear.py:332-644) ###################################################
+# The reference hard-codes native_fp8_support = False and runs F.linear on dequantised operands
+# (easy_fp8_gemm, :336-369).  Here the product runs on the e4m3 / e5m2 matrix cores with fp32
+# accumulation and the two scales are applied once in the epilogue: agreement is to fp32 rounding
+# (tests: rtol 1e-3), and every activation dtype works (the reference's path only accepts fp32
+# activations once a bias or per-token scales are involved: F.linear rejects Float x Half).
+from ..functional.quantization import per_tensor_quantize_fp8  # noqa: E402
+
+
+def easy_fp8_gemm(A, A_scale, B, B_scale, bias, out_dtype):
+    """out = (A . B^T) * A_scale * B_scale (+ bias) in out_dtype; empty A (empty MoE expert) gives an
+    empty output (reference :336-340)."""
+    if A.numel() == 0:
+        return torch.empty(size=(0, B.shape[0]), dtype=out_dtype, device=A.device)
+    lead = A.shape[:-1]
+    out = ops.linear_fp8(A.reshape(-1, A.shape[-1]), A_scale, B, float(B_scale), bias, out_dtype)
+    return out.view(*lead, B.shape[0])
+
+
+class _FP8Base(torch.nn.Module):
+    _host_scalars = ("weight_scale",)
+    _weight_dtype = torch.float8_e4m3fn
+
+    def __init__(self, in_features, out_features, use_bias=False):
+        super().__init__()
+        self.in_features, self.out_features, self.use_bias = in_features, out_features, use_bias
+        self.register_buffer("weight", torch.empty(out_features, in_features, dtype=self._weight_dtype, requires_grad=False))
+        if use_bias:
+            self.register_buffer("bias", torch.zeros(out_features, dtype=torch.float32, requires_grad=False))
+        for name in self._host_scalars:
+            self.register_buffer(name, torch.tensor(1.0, dtype=torch.float32, requires_grad=False))
+
+    def _apply(self, fn, *args, **kwargs):
+        bias = self._buffers.get("bias")
+        super()._apply(fn, *args, **kwargs)
+        if bias is not None and self._buffers["bias"].dtype != torch.float32:
+            self._buffers["bias"] = bias.to(self._buffers["bias"].device)
+        for name in self._host_scalars:  # scalar scales live on the host (reference :406-410, :543-549)
+            if self._buffers.get(name) is not None:
+                self._buffers[name] = self._buffers[name].detach().to("cpu", torch.float32)
+        return self
+
+    def _bias_dev(self, device):
+        if not self.use_bias or self._buffers.get("bias") is None:
+            return None
+        if self.bias.device != device or self.bias.dtype != torch.float32:
+            self.bias = self.bias.detach().to(device=device, dtype=torch.float32)
+        return self.bias
+
+    def _x2d(self, x):
+        x2 = x.reshape(-1, x.shape[-1])
+        return x2 if x2.is_contiguous() else x2.contiguous()
+
+
+class FP8LinearDynamic(_FP8Base):
+    """Dynamic activation scaling, per-tensor weight scale (reference :373-452)."""
+
+    def __init__(self, in_features, out_features, act_quant, use_bias=False):
+        super().__init__(in_features, out_features, use_bias)
+        self.act_quant = act_quant
+
+    @torch.no_grad()
+    def forward(self, x):
+        lead = x.shape[:-1]
+        x2 = self._x2d(x)
+        if x2.numel() == 0:
+            return torch.empty(*lead, self.out_features, dtype=x.dtype, device=x.device)
+        q, s = ops.quantize_act_fp8(x2, "per-token" if self.act_quant == "per-token" else "per-tensor")
+        out = ops.linear_fp8(q, s, self.weight, float(self.weight_scale), self._bias_dev(x.device), x.dtype)
+        return out.view(*lead, self.out_features)
+
+    @staticmethod
+    def from_float(module: torch.nn.Linear, input_scale=1.0, save_device=torch.device("cpu"), act_quant="per-token"):
+        """reference :429-452.  Kept bug-for-bug: the reference passes `use_bias` positionally into the
+        `act_quant` slot (:444-446), so the converted module has act_quant = True/False (=> the
+        per-tensor branch) and use_bias = False (the bias is dropped)."""
+        assert act_quant == "per-token"
+        qw, wscale = per_tensor_quantize_fp8(module.weight)
+        use_bias = module.bias is not None
+        m = FP8LinearDynamic(module.in_features, module.out_features, use_bias)
+        m.weight = qw
+        m.weight_scale = input_scale * wscale
+        if use_bias:
+            import copy
+            m.bias = copy.deepcopy(module.bias)  # registered (a Parameter) but unused: use_bias is False
+        return m
+
+
+class FP8StaticLinearQuantizer(torch.nn.Module):
+    """Calibration-time wrapper that records the running max of the dynamic per-tensor input (and
+    optionally output) scale (reference :455-500)."""
+
+    def __init__(self, in_features, out_features, weight, weight_scale, bias, quantize_output=False):
+        super().__init__()
+        self.weight = torch.nn.Parameter(weight, requires_grad=False)
+        self.weight_scale = torch.nn.Parameter(weight_scale, requires_grad=False)
+        self.bias = bias
+        self.input_scale = None
+        self.output_scale = None
+        self.quantize_output = quantize_output
+        self.in_features, self.out_features = in_features, out_features
+
+    @staticmethod
+    def _track(cur, new):
+        if cur is None or bool(new > cur):
+            return torch.nn.Parameter(new.detach().clone(), requires_grad=False)
+        return cur
+
+    @torch.no_grad()
+    def forward(self, x):
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        q, s = ops.quantize_act_fp8(x2, "per-tensor")
+        self.input_scale = self._track(self.input_scale, s)
+        bias = None if self.bias is None else self.bias.detach().to(device=x.device, dtype=torch.float32)
+        # as the reference: the GEMM uses the RUNNING input scale, not this batch's
+        out = ops.linear_fp8(q, self.input_scale.detach().to(x.device), self.weight, float(self.weight_scale), bias, x.dtype)
+        if self.quantize_output:
+            qo, so = ops.quantize_act_fp8(out, "per-tensor")
+            self.output_scale = self._track(self.output_scale, so)
+            out = qo.to(out.dtype) * so
+        return out.view(*lead, self.out_features)
+
+
+class FP8LinearStatic(_FP8Base):
+    """Static (calibrated) input / output scales (reference :503-580)."""
+    _host_scalars = ("weight_scale", "input_scale", "output_scale")
+
+    @torch.no_grad()
+    def forward(self, x):
+        lead = x.shape[:-1]
+        x2 = self._x2d(x)
+        if x2.numel() == 0:
+            return torch.empty(*lead, self.out_features, dtype=x.dtype, device=x.device)
+        in_scale = float(self.input_scale)
+        q, _ = ops.quantize_act_fp8(x2, "static", in_scale)
+        out = ops.linear_fp8(q, in_scale, self.weight, float(self.weight_scale), self._bias_dev(x.device), x.dtype)
+        out_scale = float(self.output_scale)
+        if out_scale:  # `if self.output_scale:` in the reference (:562): re-quantise the output when non-zero
+            qo, _ = ops.quantize_act_fp8(out, "static", out_scale)
+            out = qo.to(out.dtype) * out_scale
+        return out.view(*lead, self.out_features)
+
+    @staticmethod
+    def from_float(quantizer):
+        use_bias = quantizer.bias is not None
+        m = FP8LinearStatic(quantizer.in_features, quantizer.out_features, use_bias)
+        m.weight = quantizer.weight.detach()
+        if use_bias:
+            m.bias = quantizer.bias.detach().to(torch.float32)
+        m.weight_scale = quantizer.weight_scale.detach().to("cpu", torch.float32)
+        m.input_scale = quantizer.input_scale.detach().to("cpu", torch.float32)
+        m.output_scale = (quantizer.output_scale.detach() if quantizer.output_scale is not None else torch.tensor(0.0)).to("cpu", torch.float32)
+        return m
+
+
+class FP8E5M2Linear(_FP8Base):
+    """Unscaled e5m2 weights and activations (reference :583-644).  The reference's forward calls
+    torch._scaled_mm(qinput, self.weight, scale_a=None, ...), which current PyTorch rejects (and which
+    lacks the weight transpose); restated from its intent: y = e5m2(x) . e5m2(W)^T + bias."""
+    _host_scalars = ()
+    _weight_dtype = torch.float8_e5m2
+
+    @torch.no_grad()
+    def forward(self, x):
+        lead = x.shape[:-1]
+        x2 = self._x2d(x)
+        if x2.numel() == 0:
+            return torch.empty(*lead, self.out_features, dtype=x.dtype, device=x.device)
+        out = ops.linear_fp8(ops.cast_e5m2(x2), 1.0, self.weight, 1.0, self._bias_dev(x.device), x.dtype)
+        return out.view(*lead, self.out_features)
+
+    @staticmethod
+    def from_float(module: torch.nn.Linear):
+        use_bias = module.bias is not None
+        m = FP8E5M2Linear(module.in_features, module.out_features, use_bias=use_bias)
+        m.weight = module.weight.detach().to(torch.float8_e5m2)
+        if use_bias:
+            m.bias = module.bias.detach().clone().to(torch.float32)
+        return m

@@ -149,5 +149,82 @@ def linear_w8a8_forward(x2d, w, act_mode, quant_scale, s_scalar, s_col=None, bia
     return out
 
 
+_FP8 = {"per-token": L.ASQ_FP8_PER_TOKEN, "per-tensor": L.ASQ_FP8_PER_TENSOR, "static": L.ASQ_FP8_STATIC}
+
+
+def quantize_act_fp8(x, mode, static_scale=1.0):
+    """x [M,K] f32/f16/bf16 -> (xq float8_e4m3fn [M,K], scale).  mode "per-token": scale f32 [M,1] on the
+    device; "per-tensor" (dynamic): scale f32 0-dim ON THE DEVICE (no host sync, like the reference's
+    0-dim scale tensor); "static": scale is the given host value (returned as a python float).
+    Reference: layers/functional/quantization.py:144-211."""
+    _dev(x, "x")
+    if x.dtype not in _DT or x.dim() != 2:
+        raise ValueError("x must be a 2-D float32/float16/bfloat16 tensor")
+    M, K = x.shape
+    xq = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    if mode == "per-token":
+        sc = torch.empty((M,), dtype=torch.float32, device=x.device)
+    elif mode == "per-tensor":
+        sc = torch.empty((2,), dtype=torch.float32, device=x.device)
+    else:
+        sc = None
+    with torch.cuda.device(x.device):
+        L.check(L.lib().asq_quantize_act_fp8(x.data_ptr(), _DT[x.dtype], _FP8[mode], float(static_scale), xq.data_ptr(), _ptr(sc), M, K,
+                                             _stream(x)), "asq_quantize_act_fp8")
+    xq = xq.view(torch.float8_e4m3fn)
+    if mode == "per-token":
+        return xq, sc.view(M, 1)
+    if mode == "per-tensor":
+        return xq, sc[0]
+    return xq, float(static_scale)
+
+
+def cast_e5m2(x):
+    """x [M,K] f32/f16/bf16 -> float8_e5m2 [M,K], plain round-to-nearest-even cast (FP8E5M2Linear, linear.py:612)."""
+    _dev(x, "x")
+    if x.dtype not in _DT or x.dim() != 2:
+        raise ValueError("x must be a 2-D float32/float16/bfloat16 tensor")
+    M, K = x.shape
+    xq = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().asq_cast_e5m2(x.data_ptr(), _DT[x.dtype], xq.data_ptr(), M * K, _stream(x)), "asq_cast_e5m2")
+    return xq.view(torch.float8_e5m2)
+
+
+def linear_fp8(xq, a_scale, w, w_scale, bias, out_dtype):
+    """easy_fp8_gemm on the fp8 matrix cores (reference linear.py:336-369): out = (xq . w^T) * a_scale * w_scale (+ bias).
+    a_scale: device f32 tensor ([M,1] per-token or 0-dim per-tensor) or a python float."""
+    _dev(xq, "xq"), _dev(w, "weight")
+    f8 = (torch.float8_e4m3fn, torch.float8_e5m2)
+    if xq.dtype not in f8 or w.dtype != xq.dtype or xq.dim() != 2 or w.dim() != 2 or xq.shape[1] != w.shape[1]:
+        raise ValueError("xq [M,K] and weight [N,K] must both be float8_e4m3fn (or both float8_e5m2) with equal K")
+    fmt = 0 if xq.dtype == torch.float8_e4m3fn else 1
+    M, K = xq.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=out_dtype, device=xq.device)
+    if M == 0 or N == 0:
+        return out
+    a_dev, per_token, a_host = None, 0, 1.0
+    if isinstance(a_scale, torch.Tensor):
+        if a_scale.is_cuda:
+            a_dev = a_scale.to(torch.float32).contiguous()
+            per_token = 1 if (a_scale.dim() >= 1 and a_scale.numel() == M) else 0
+            if not per_token and a_dev.numel() != 1:
+                raise ValueError("a_scale must have 1 or M elements")
+        else:
+            a_host = float(a_scale)
+    else:
+        a_host = float(a_scale)
+    if bias is not None:
+        _dev(bias, "bias")
+        if bias.dtype != torch.float32 or bias.numel() != N:
+            raise ValueError(f"bias must be float32 with {N} elements")
+    dev = _same_device(xq, w, a_dev, bias)
+    with torch.cuda.device(dev):
+        L.check(L.lib().asq_linear_fp8(xq.data_ptr(), w.data_ptr(), fmt, out.data_ptr(), _DT[out_dtype], M, N, K, _ptr(a_dev), per_token,
+                                       a_host, float(w_scale), _ptr(bias), _stream(xq)), "asq_linear_fp8")
+    return out
+
+
 def gemm_kernel_name(M, N, K):
     return L.lib().asq_gemm_kernel_name(M, N, K).decode()

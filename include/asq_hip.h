@@ -116,6 +116,39 @@ int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t *w, void *o
                             float s_scalar, const float *s_col, const float *bias,
                             void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- FP8 (OCP e4m3fn) linear path: layers/functional/quantization.py:144-211 (quantisers),
+ * layers/nn/linear.py:336-369 easy_fp8_gemm, :373-452 FP8LinearDynamic, :503-580 FP8LinearStatic.
+ * fp8 tensors are raw bytes (torch.float8_e4m3fn storage).
+ *
+ * asq_quantize_act_fp8: x [M,K] -> xq e4m3fn [M,K] = cast(clamp(x / scale, +-448)), round-to-nearest-even.
+ *   ASQ_FP8_PER_TOKEN : scale[m] = (rowabsmax / 448 in x_dtype) as f32, division in fp32; scale_out f32[M]
+ *   ASQ_FP8_PER_TENSOR: scale = absmax / 448 in x_dtype, quotient rounded to x_dtype (dynamic per-tensor);
+ *                       scale_out f32[2]: [0] receives the scale, [1] is scratch.  The scale stays on the
+ *                       device (no host sync), exactly like the reference's 0-dim scale tensor.
+ *   ASQ_FP8_STATIC    : scale = static_scale (calibrated input_scale / output_scale); scale_out may be NULL. */
+#define ASQ_FP8_PER_TOKEN 0
+#define ASQ_FP8_PER_TENSOR 1
+#define ASQ_FP8_STATIC 2
+int asq_quantize_act_fp8(const void *x, int x_dtype, int mode, float static_scale,
+                         uint8_t *xq, float *scale_out, int64_t M, int64_t K, void *stream);
+
+/* out[M,N] (out_dtype) = (xq . w^T as fp32, fp8 matrix cores) * (a_scale * w_scale) (+ bias[n])
+ * a_scale: a_scale_dev (device f32; [M] if a_per_token else [1]) or, when NULL, a_scale_host.
+ * The reference dequantises both operands and calls F.linear (native_fp8_support = False,
+ * linear.py:342,364-368): results agree to fp32 rounding, not bit-for-bit. */
+#define ASQ_FP8_E4M3 0
+#define ASQ_FP8_E5M2 1
+int asq_linear_fp8(const uint8_t *xq, const uint8_t *w, int fp8_format, void *out, int out_dtype,
+                   int64_t M, int64_t N, int64_t K,
+                   const float *a_scale_dev, int a_per_token, float a_scale_host, float w_scale,
+                   const float *bias, void *stream);
+
+/* FP8E5M2Linear (linear.py:583-644): plain unscaled cast x -> e5m2 (round-to-nearest-even, IEEE-like
+ * overflow to inf); the product then runs through asq_linear_fp8(..., ASQ_FP8_E5M2, ...) with unit scales.
+ * (The reference's forward calls torch._scaled_mm with scale_a=None, which current PyTorch rejects;
+ * restated from its intent: y = e5m2(x) . e5m2(W)^T + bias.) */
+int asq_cast_e5m2(const void *x, int x_dtype, uint8_t *xq, int64_t n, void *stream);
+
 /* ---- introspection for tests / bench: which GEMM kernel the dispatcher picks for a shape.
  * Returns a static string ("t256", "generic", ...). */
 const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K);

@@ -360,6 +360,98 @@ def gen_g3():
     print(f"G3: {len(index)} conversions")
 
 
+def gen_g5():
+    """G5: fp8 (e4m3fn) path -- quantiser outputs as raw bytes + scales (bit-exact), FP8LinearDynamic /
+    FP8LinearStatic outputs (fp32 activations; plus the one fp16 combination the reference accepts:
+    per-tensor, no bias), the from_float act_quant quirk, and the empty-tensor guard."""
+    from oracle import fp8 as F8
+    store, index = {}, []
+    K, N, M = 96, 40, 9
+    Wf = make_w(51, 0, N, K)
+    b = (detrng.normal(52, 0, (N,)) * np.float32(0.5)).astype(np.float32)
+    store["W"], store["b"] = Wf, b
+    u8 = lambda t: t.view(torch.uint8).numpy().copy()
+    for dt in ("f32", "f16", "bf16"):
+        x = make_x(53, {"f32": 0, "f16": 1, "bf16": 2}[dt], (M, K), dt, scale=3.0)
+        x[2] = 0.0
+        x[4, 7] = 1000.0 if dt != "f16" else 900.0
+        x = t2n(torch.from_numpy(x).to(TDT[dt]))
+        store[f"x_{dt}"] = x
+        q, s_ = RQ.per_tensor_quantize_fp8(n2t(x, dt))
+        store[f"pt_{dt}_q"], store[f"pt_{dt}_s"] = u8(q), np.float32(s_.float().item())
+        assert s_.dtype == TDT[dt]
+        oq, os_ = F8.per_tensor_quantize_fp8(x, dt)
+        same(oq, store[f"pt_{dt}_q"], f"fp8 per-tensor q {dt}")
+        same(np.float32(os_), store[f"pt_{dt}_s"], f"fp8 per-tensor s {dt}")
+        q, s_ = RQ.per_token_quantize_fp8(n2t(x, dt))
+        assert s_.dtype == torch.float32
+        store[f"tok_{dt}_q"], store[f"tok_{dt}_s"] = u8(q), s_.numpy().reshape(-1).copy()
+        oq, os_ = F8.per_token_quantize_fp8(x, dt)
+        # zero rows: scale 0 -> 0/0 = NaN -> e4m3fn NaN (0x7f / 0xff): compare as decoded values
+        same(F8.e4m3fn_to_f32(oq), F8.e4m3fn_to_f32(store[f"tok_{dt}_q"]), f"fp8 per-token q {dt}")
+        same(os_.reshape(-1), store[f"tok_{dt}_s"], f"fp8 per-token s {dt}")
+        q = RQ.static_per_tensor_quantize_fp8(n2t(x, dt), torch.tensor(0.0371, dtype=torch.float32))
+        store[f"st_{dt}_q"] = u8(q)
+        same(F8.static_per_tensor_quantize_fp8(x, dt, np.float32(0.0371)), store[f"st_{dt}_q"], f"fp8 static q {dt}")
+    # weight quantisation (per-tensor) used by the modules
+    wq_t, ws_t = RQ.per_tensor_quantize_fp8(torch.from_numpy(Wf.copy()))
+    store["wq"], store["ws"] = u8(wq_t), np.float32(ws_t.item())
+    owq, ows = F8.per_tensor_quantize_fp8(Wf, "f32")
+    same(owq, store["wq"], "fp8 weight q")
+    same(np.float32(ows), store["ws"], "fp8 weight scale")
+    x32 = store["x_f32"]
+
+    def dyn(aq, use_bias, x, dt):
+        m = RL.FP8LinearDynamic(K, N, aq, use_bias=use_bias)
+        m.weight, m.weight_scale = wq_t.clone(), ws_t.clone()
+        if use_bias:
+            m.bias = torch.from_numpy(b.copy())
+        return t2n(m(n2t(x, dt)))
+
+    for aq in ("per-token", "per-tensor"):
+        for use_bias in (False, True):
+            name = f"dyn_f32_{aq}_{int(use_bias)}"
+            xin = x32.copy()
+            if aq == "per-token":
+                xin[2] = 0.5   # a zero row makes the reference's per-token fp8 output NaN; keep this case finite
+            store[name + "_x"] = xin
+            store[name] = dyn(aq, use_bias, xin, "f32")
+            o = F8.fp8_linear_dynamic_forward(xin, "f32", store["wq"], store["ws"], b if use_bias else None, aq)
+            err = np.abs(o - store[name]).max() / np.abs(store[name]).max()
+            assert err < 1e-5, (name, err)
+            index.append(f"{name}|f32|{aq}|{int(use_bias)}")
+    store["dyn_f16_per-tensor_0"] = dyn("per-tensor", False, store["x_f16"], "f16")
+    o = F8.fp8_linear_dynamic_forward(store["x_f16"], "f16", store["wq"], store["ws"], None, "per-tensor")
+    err = np.abs(o - store["dyn_f16_per-tensor_0"]).max() / np.abs(store["dyn_f16_per-tensor_0"]).max()
+    assert err < 4e-3, err
+    for osc in (0.0, 0.05):
+        st = RL.FP8LinearStatic(K, N, True)
+        st.weight, st.weight_scale, st.bias = wq_t.clone(), ws_t.clone(), torch.from_numpy(b.copy())
+        st.input_scale, st.output_scale = torch.tensor(0.0371), torch.tensor(osc)
+        name = f"static_f32_{osc}"
+        store[name] = t2n(st(torch.from_numpy(x32.copy())))
+        o = F8.fp8_linear_static_forward(x32, "f32", store["wq"], store["ws"], np.float32(0.0371), np.float32(osc), b)
+        # the requantised output may flip one fp8 code where the fp32 sums differ in the last ulp
+        nbad = int((o != store[name]).sum())
+        assert nbad <= (2 if osc else 10**9) and np.abs(o - store[name]).max() <= (0.05 * 64 if osc else 1e-4), (name, nbad)
+    # from_float quirk (linear.py:444-446): use_bias lands in the act_quant slot
+    lin = torch.nn.Linear(K, N, bias=True)
+    lin.weight.data = torch.from_numpy(Wf.copy())
+    m2 = RL.FP8LinearDynamic.from_float(lin, 1.0)
+    store["ff_act_quant_is_true"] = np.array(m2.act_quant is True)
+    store["ff_use_bias"] = np.array(bool(m2.use_bias))
+    store["ff_wq"], store["ff_ws"] = u8(m2.weight), np.float32(m2.weight_scale.item())
+    same(store["ff_wq"], store["wq"], "from_float fp8 weight")
+    # empty-tensor guards (linear.py:337-339, quantization.py:153-158)
+    q, s_ = RQ.per_tensor_quantize_fp8(torch.empty(0, K))
+    store["empty_scale"] = np.float32(s_.item())
+    same(np.float32(F8.per_tensor_quantize_fp8(np.zeros((0, K), np.float32), "f32")[1]), store["empty_scale"], "empty scale")
+    assert tuple(RL.easy_fp8_gemm(q, s_, wq_t, ws_t, None, torch.float32).shape) == (0, N)
+    store["index"] = np.array(index)
+    np.savez_compressed(os.path.join(HERE, "g5_fp8.npz"), **store)
+    print("G5: fp8 vectors written")
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -432,13 +524,15 @@ def _fast_mm(self, x, w, out):
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g4"]
     if "g1" in which:
         gen_g1()
     if "g2" in which:
         gen_g2()
     if "g3" in which:
         gen_g3()
+    if "g5" in which:
+        gen_g5()
     if "g4" in which:
         # cross-check the fast stub against the plain int32 matmul once, then use it
         a = torch.from_numpy(detrng.int8_uniform(1, 1, (32, 512)))

@@ -1,0 +1,142 @@
+"""GPU (-m gpu): the FP8 (e4m3fn / e5m2) linear path through the C-ABI.
+Quantiser outputs are compared BIT-EXACTLY with the oracle (pinned to the reference by G5);
+linear outputs within rtol 1e-3 / atol 1e-3*max|out| (the reference dequantises and calls
+F.linear; summation order unspecified -> tolerance, as SURVEY 8c states)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import detrng
+import goldenio
+from oracle import fp8 as F8
+from oracle import w8a8 as O
+
+pytestmark = pytest.mark.gpu
+TDT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from autosmoothquant_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def t_in(a, dt, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(TDT[dt]).to(dev)
+
+
+def u8(t):
+    return t.view(torch.uint8).cpu().numpy()
+
+
+def close(got, ref, rtol=1e-3):
+    return np.abs(got - ref).max() <= rtol * np.abs(ref).max() + 1e-30
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape", [(9, 96), (5, 64), (33, 4096), (3, 77), (2, 11008)])
+def test_fp8_quantisers_bit_exact(dt, shape, dev):
+    from autosmoothquant_amd import ops
+    M, K = shape
+    x = O.round_to(detrng.act_like(201, M + K, (M, K), scale=3.0), dt)
+    x[M // 2, K // 3] = 900.0
+    if M > 2:
+        x[1] = 0.0   # zero row: per-token scale 0 -> 0/0 -> NaN codes, as the reference
+    xt = t_in(x, dt, dev)
+    q, s = ops.quantize_act_fp8(xt, "per-token")
+    rq, rs = F8.per_token_quantize_fp8(x, dt)
+    assert np.array_equal(s.cpu().numpy().reshape(-1), rs.reshape(-1))
+    assert np.array_equal(F8.e4m3fn_to_f32(u8(q)), F8.e4m3fn_to_f32(rq), equal_nan=True)
+    q, s = ops.quantize_act_fp8(xt, "per-tensor")
+    rq, rs = F8.per_tensor_quantize_fp8(x, dt)
+    assert np.float32(s.item()) == np.float32(rs) and np.array_equal(u8(q), rq)
+    q, _ = ops.quantize_act_fp8(xt, "static", 0.0371)
+    assert np.array_equal(u8(q), F8.static_per_tensor_quantize_fp8(x, dt, np.float32(0.0371)))
+    e = ops.cast_e5m2(xt)
+    assert np.array_equal(F8.e5m2_to_f32(u8(e)), torch.from_numpy(x).to(TDT[dt]).to(torch.float8_e5m2).float().numpy(), equal_nan=True)
+
+
+def test_fp8_codec_exhaustive_f16(dev):
+    """every finite fp16 value through the device encoders == torch's casts"""
+    from autosmoothquant_amd import ops
+    h = torch.arange(65536, dtype=torch.int32).to(torch.uint16).view(torch.float16)
+    h = h[torch.isfinite(h)].reshape(1, -1)
+    pad = (-h.numel()) % 8
+    h = torch.cat([h, torch.zeros(1, pad, dtype=torch.float16)], dim=1).contiguous()
+    e = ops.cast_e5m2(h.to(dev))
+    assert torch.equal(e.cpu().view(torch.uint8), h.to(torch.float8_e5m2).view(torch.uint8))
+    q, _ = ops.quantize_act_fp8(h.clamp(-448, 448).to(dev), "static", 1.0)
+    assert torch.equal(q.cpu().view(torch.uint8), h.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape", [(9, 40, 96), (130, 264, 384), (33, 100, 200), (256, 512, 1024)])
+def test_fp8_linear_vs_oracle(dt, shape, dev):
+    from autosmoothquant_amd import ops
+    M, N, K = shape
+    x = O.round_to(detrng.act_like(202, M, (M, K), scale=3.0), dt)
+    W = (detrng.normal(203, N, (N, K)) * np.float32(0.02)).astype(np.float32)
+    b = (detrng.normal(204, N, (N,)) * np.float32(0.5)).astype(np.float32)
+    wq, ws = F8.per_tensor_quantize_fp8(W, "f32")
+    wt = torch.from_numpy(wq).to(dev).view(torch.float8_e4m3fn)
+    bt = torch.from_numpy(b).to(dev)
+    xt = t_in(x, dt, dev)
+    for mode in ("per-token", "per-tensor"):
+        q, s = ops.quantize_act_fp8(xt, mode)
+        for bias in (None, bt):
+            got = ops.linear_fp8(q, s, wt, float(ws), bias, TDT[dt]).float().cpu().numpy()
+            aq, a_s = (F8.per_token_quantize_fp8 if mode == "per-token" else F8.per_tensor_quantize_fp8)(x, dt)
+            ref = F8.easy_fp8_gemm(aq, a_s, wq, ws, None if bias is None else b, "f32")
+            # 1e-3 contract on fp32; for 16-bit outputs a last-place flip of the output rounding is
+            # up to 2^-10 (f16) / 2^-7 (bf16) of the value, so allow one output ulp on top
+            tol = {"f32": 1e-3, "f16": 2e-3, "bf16": 1e-2}[dt]
+            assert close(got, O.round_to(ref, dt), tol), (mode, bias is not None)
+
+
+def test_fp8_modules_vs_golden(dev):
+    """FP8LinearDynamic / FP8LinearStatic against the reference's own outputs (G5, fp32 activations)."""
+    from autosmoothquant_amd.layers.nn.linear import FP8LinearDynamic, FP8LinearStatic, FP8E5M2Linear, easy_fp8_gemm
+    z = np.load(os.path.join(goldenio.GOLDEN, "g5_fp8.npz"))
+    wq = torch.from_numpy(z["wq"]).view(torch.float8_e4m3fn)
+    K, N = z["W"].shape[1], z["W"].shape[0]
+    for line in z["index"]:
+        name, dt, aq, ub = str(line).split("|")
+        m = FP8LinearDynamic(K, N, aq, use_bias=bool(int(ub)))
+        m.weight, m.weight_scale = wq.clone(), torch.tensor(float(z["ws"]))
+        if int(ub):
+            m.bias = torch.from_numpy(z["b"].copy())
+        m = m.to(dev)
+        y = m(t_in(z[name + "_x"], dt, dev).view(3, 3, K))
+        assert tuple(y.shape) == (3, 3, N) and y.dtype == TDT[dt]
+        assert close(y.float().cpu().numpy().reshape(9, N), z[name]), name
+    for osc in (0.0, 0.05):
+        st = FP8LinearStatic(K, N, True)
+        st.weight, st.weight_scale, st.bias = wq.clone(), torch.tensor(float(z["ws"])), torch.from_numpy(z["b"].copy())
+        st.input_scale, st.output_scale = torch.tensor(0.0371), torch.tensor(osc)
+        st = st.to(dev)
+        y = st(t_in(z["x_f32"], "f32", dev)).cpu().numpy()
+        ref = z[f"static_f32_{osc}"]
+        if osc:
+            assert (y != ref).sum() <= 3 and np.abs(y - ref).max() <= 0.05 * 64   # a last-ulp sum difference may flip one fp8 code
+        else:
+            assert close(y, ref)
+    # from_float keeps the reference's act_quant/use_bias quirk; empty inputs give empty outputs
+    lin = torch.nn.Linear(K, N, bias=True)
+    lin.weight.data = torch.from_numpy(z["W"].copy())
+    m2 = FP8LinearDynamic.from_float(lin, 1.0)
+    assert m2.act_quant is True and m2.use_bias is False
+    assert np.array_equal(m2.weight.view(torch.uint8).numpy(), z["ff_wq"]) and np.float32(m2.weight_scale.item()) == z["ff_ws"]
+    m2 = m2.to(dev)
+    assert tuple(m2(torch.zeros(0, K, device=dev)).shape) == (0, N)
+    assert tuple(easy_fp8_gemm(torch.zeros(0, K, device=dev).to(torch.float8_e4m3fn), 1.0, wq.to(dev), 1.0, None, torch.float32).shape) == (0, N)
+    # e5m2: y = e5m2(x) . e5m2(W)^T + bias
+    e = FP8E5M2Linear.from_float(lin).to(dev)
+    x = z["x_f32"]
+    y = e(t_in(x, "f32", dev)).cpu().numpy()
+    xe = torch.from_numpy(x).to(torch.float8_e5m2).float().numpy().astype(np.float64)
+    we = lin.weight.data.to(torch.float8_e5m2).float().numpy().astype(np.float64)
+    assert close(y, (xe @ we.T + lin.bias.data.numpy().astype(np.float64)).astype(np.float32))

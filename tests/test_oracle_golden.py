@@ -114,3 +114,43 @@ def test_c_igemm_matches_numpy_igemm():
         ref = x.astype(np.int64) @ w.astype(np.int64).T
         assert np.array_equal(O.igemm_numpy(x, w), ref)
         assert np.array_equal(O.igemm_c(x, w), ref)
+
+
+def test_g5_fp8_quantisers_and_linears():
+    """fp8 (e4m3fn) path: quantiser bytes + scales bit-exact vs the reference; linears within fp32 rounding."""
+    import os
+    from oracle import fp8 as F8
+    z = np.load(os.path.join(goldenio.GOLDEN, "g5_fp8.npz"))
+    for dt in ("f32", "f16", "bf16"):
+        x = z[f"x_{dt}"]
+        q, s = F8.per_tensor_quantize_fp8(x, dt)
+        assert np.array_equal(q, z[f"pt_{dt}_q"]) and np.float32(s) == z[f"pt_{dt}_s"]
+        q, s = F8.per_token_quantize_fp8(x, dt)
+        assert np.array_equal(F8.e4m3fn_to_f32(q), F8.e4m3fn_to_f32(z[f"tok_{dt}_q"]), equal_nan=True)
+        assert np.array_equal(s.reshape(-1), z[f"tok_{dt}_s"])
+        assert np.array_equal(F8.static_per_tensor_quantize_fp8(x, dt, np.float32(0.0371)), z[f"st_{dt}_q"])
+    wq, ws = F8.per_tensor_quantize_fp8(z["W"], "f32")
+    assert np.array_equal(wq, z["wq"]) and np.float32(ws) == z["ws"]
+    assert np.array_equal(z["ff_wq"], z["wq"]) and bool(z["ff_act_quant_is_true"]) and not bool(z["ff_use_bias"])
+    for line in z["index"]:
+        name, dt, aq, ub = str(line).split("|")
+        o = F8.fp8_linear_dynamic_forward(z[name + "_x"], dt, z["wq"], z["ws"], z["b"] if int(ub) else None, aq)
+        assert np.abs(o - z[name]).max() <= 1e-5 * np.abs(z[name]).max()
+    o = F8.fp8_linear_dynamic_forward(z["x_f16"], "f16", z["wq"], z["ws"], None, "per-tensor")
+    assert np.abs(o - z["dyn_f16_per-tensor_0"]).max() <= 4e-3 * np.abs(z["dyn_f16_per-tensor_0"]).max()
+    o = F8.fp8_linear_static_forward(z["x_f32"], "f32", z["wq"], z["ws"], np.float32(0.0371), np.float32(0.0), z["b"])
+    assert np.abs(o - z["static_f32_0.0"]).max() <= 1e-4
+    assert np.float32(F8.per_tensor_quantize_fp8(np.zeros((0, 8), np.float32), "f32")[1]) == z["empty_scale"]
+
+
+def test_fp8_codecs_match_torch_casts():
+    import torch
+    from oracle import fp8 as F8
+    h = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    rng = np.random.default_rng(1)
+    r = np.concatenate([h, (rng.standard_normal(100000) * np.exp(rng.uniform(-12, 8, 100000))).astype(np.float32),
+                        np.array([448, 464, 465, 480, -448, 2 ** -9, 2 ** -10, 1.5 * 2 ** -10, 57344, 61440, 65536, 0.0, -0.0], np.float32)])
+    t = torch.from_numpy(r)
+    for enc, dec, tdt in ((F8.f32_to_e4m3fn, F8.e4m3fn_to_f32, torch.float8_e4m3fn), (F8.f32_to_e5m2, F8.e5m2_to_f32, torch.float8_e5m2)):
+        ref = t.to(tdt).float().numpy()
+        assert np.array_equal(dec(enc(r)), ref, equal_nan=True)
