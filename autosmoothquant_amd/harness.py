@@ -1,0 +1,136 @@
+"""LLaMA-architecture decoder-layer harness around the W8A8 linears (measurement plumbing).
+
+The reference does not own this arithmetic: it borrows ``forward`` from HF ``transformers==4.42.3``
+(reference models/llama.py:111,218,289) and only decides (1) which quantised linear class and
+``act_quant`` each projection uses (:99-106, :206-211) and (2) when ``1/input_scale`` is folded
+into the preceding RMSNorm weight (:27-37, :326-339).  Those two things are reproduced here;
+RMSNorm, RoPE, causal attention and SiLU are stock PyTorch-ROCm ops.
+Nothing in here is on the product's hot path except the seven linears.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .layers.nn.linear import W8A8BFP32OFP32Linear, W8A8BFP32OFP32LinearWithQuantScale
+
+
+class RMSNorm(torch.nn.Module):
+    def __init__(self, hidden, eps=1e-5):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.ones(hidden))
+        self.eps = eps
+
+    def forward(self, x):
+        v = x.float()
+        v = v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + self.eps)
+        return self.weight * v.to(x.dtype)
+
+    def folded(self, input_scale):
+        """weight / input_scale (reference QuantizedLlamaRMSNorm.from_float, models/llama.py:27-37):
+        the norm then emits activations already in int8 units for a per-tensor linear."""
+        n = RMSNorm(self.weight.numel(), self.eps)
+        n.weight = torch.nn.Parameter(self.weight.detach() / input_scale)
+        return n.to(self.weight.device, self.weight.dtype)
+
+
+def _rope(x, pos, theta=10000.0):
+    # x [B, H, S, D]
+    d = x.shape[-1]
+    inv = 1.0 / (theta ** (torch.arange(0, d, 2, device=x.device, dtype=torch.float32) / d))
+    ang = pos.float()[:, None] * inv[None, :]
+    cos, sin = torch.cos(ang)[None, None].to(x.dtype), torch.sin(ang)[None, None].to(x.dtype)
+    x1, x2 = x[..., : d // 2], x[..., d // 2:]
+    return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1)
+
+
+class LlamaLayer(torch.nn.Module):
+    """Float decoder layer (pre-norm, MHA/GQA with RoPE, SiLU-gated MLP)."""
+
+    def __init__(self, hidden=4096, inter=11008, heads=32, kv_heads=None, eps=1e-5):
+        super().__init__()
+        kv_heads = kv_heads or heads
+        self.hidden, self.heads, self.kv_heads, self.hd = hidden, heads, kv_heads, hidden // heads
+        L = torch.nn.Linear
+        self.input_layernorm, self.post_attention_layernorm = RMSNorm(hidden, eps), RMSNorm(hidden, eps)
+        self.q_proj, self.k_proj, self.v_proj = L(hidden, heads * self.hd, bias=False), L(hidden, kv_heads * self.hd, bias=False), L(hidden, kv_heads * self.hd, bias=False)
+        self.o_proj = L(heads * self.hd, hidden, bias=False)
+        self.gate_proj, self.up_proj, self.down_proj = L(hidden, inter, bias=False), L(hidden, inter, bias=False), L(inter, hidden, bias=False)
+
+    def attention(self, h, record=None):
+        B, S, _ = h.shape
+        x = self.input_layernorm(h)
+        if record is not None:
+            record["attn_in"] = x
+        q = self.q_proj(x).view(B, S, self.heads, self.hd).transpose(1, 2)
+        k = self.k_proj(x).view(B, S, self.kv_heads, self.hd).transpose(1, 2)
+        v = self.v_proj(x).view(B, S, self.kv_heads, self.hd).transpose(1, 2)
+        pos = torch.arange(S, device=h.device)
+        q, k = _rope(q, pos), _rope(k, pos)
+        if self.kv_heads != self.heads:
+            r = self.heads // self.kv_heads
+            k, v = k.repeat_interleave(r, dim=1), v.repeat_interleave(r, dim=1)
+        a = F.scaled_dot_product_attention(q, k, v, is_causal=True).transpose(1, 2).reshape(B, S, self.heads * self.hd)
+        if record is not None:
+            record["o_in"] = a
+        return h + self.o_proj(a)
+
+    def mlp(self, h, record=None):
+        x = self.post_attention_layernorm(h)
+        if record is not None:
+            record["mlp_in"] = x
+        g = F.silu(self.gate_proj(x)) * self.up_proj(x)
+        if record is not None:
+            record["down_in"] = g
+        return h + self.down_proj(g)
+
+    def forward(self, h, record=None):
+        return self.mlp(self.attention(h, record), record)
+
+
+@torch.no_grad()
+def init_llama_layer(layer, std=0.02, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    for name, p in layer.named_parameters():
+        if p.dim() == 2:
+            p.copy_(torch.randn(p.shape, generator=g) * std)
+    return layer
+
+
+@torch.no_grad()
+def calibrate(layer, h):
+    """Per-tensor absmax/127 input scales of the four linear groups on a calibration batch
+    (what quantize/calibration.py:185-244 collects with forward hooks)."""
+    rec = {}
+    layer(h, rec)
+    return {k: float(v.abs().max()) / 127.0 for k, v in rec.items()}
+
+
+@torch.no_grad()
+def to_w8a8(layer, scales, quant_config=None):
+    """Quantised copy of `layer`, composed exactly like the reference's
+    QuantizedLlamaDecoderLayer.from_float_to_int8 (models/llama.py:289-339):
+      q/k/v, gate/up : W8A8BFP32OFP32Linear(act_quant = cfg["qkv"] / cfg["fc1"]), norm weight folded iff per-tensor
+      o, down        : W8A8BFP32OFP32LinearWithQuantScale(act_quant = cfg["out"] / cfg["fc2"])."""
+    cfg = {"qkv": "per-tensor", "out": "per-token", "fc1": "per-tensor", "fc2": "per-token"}
+    cfg.update(quant_config or {})
+    dev = layer.q_proj.weight.device
+    q = LlamaLayer.__new__(LlamaLayer)
+    torch.nn.Module.__init__(q)
+    q.hidden, q.heads, q.kv_heads, q.hd = layer.hidden, layer.heads, layer.kv_heads, layer.hd
+
+    def conv(lin, cls, scale, aq):
+        src = torch.nn.Linear(lin.in_features, lin.out_features, bias=False)
+        src.weight = torch.nn.Parameter(lin.weight.detach().float().clone())  # from_float rounds an fp32 source in place
+        return cls.from_float(src, scale, save_device=dev, act_quant=aq).to(dev)
+
+    q.q_proj = conv(layer.q_proj, W8A8BFP32OFP32Linear, scales["attn_in"], cfg["qkv"])
+    q.k_proj = conv(layer.k_proj, W8A8BFP32OFP32Linear, scales["attn_in"], cfg["qkv"])
+    q.v_proj = conv(layer.v_proj, W8A8BFP32OFP32Linear, scales["attn_in"], cfg["qkv"])
+    q.o_proj = conv(layer.o_proj, W8A8BFP32OFP32LinearWithQuantScale, scales["o_in"], cfg["out"])
+    q.gate_proj = conv(layer.gate_proj, W8A8BFP32OFP32Linear, scales["mlp_in"], cfg["fc1"])
+    q.up_proj = conv(layer.up_proj, W8A8BFP32OFP32Linear, scales["mlp_in"], cfg["fc1"])
+    q.down_proj = conv(layer.down_proj, W8A8BFP32OFP32LinearWithQuantScale, scales["down_in"], cfg["fc2"])
+    q.input_layernorm = layer.input_layernorm.folded(scales["attn_in"]) if cfg["qkv"] == "per-tensor" else layer.input_layernorm
+    q.post_attention_layernorm = layer.post_attention_layernorm.folded(scales["mlp_in"]) if cfg["fc1"] == "per-tensor" else layer.post_attention_layernorm
+    return q

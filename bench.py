@@ -45,6 +45,10 @@ WORKLOADS = {
     "llama7b_decode_m32": ("LLaMA-2-7B attention-block W8A8 linears, decode batch 32 (M=32)", 32,
                            [("q", "linear", 4096, 4096, "per-tensor", False), ("k", "linear", 4096, 4096, "per-tensor", False),
                             ("v", "linear", 4096, 4096, "per-tensor", False), ("o", "quantscale", 4096, 4096, "per-token", False)]),
+    # whole-layer harness workloads (linears on the HIP path; RMSNorm / RoPE / causal SDPA / SiLU in stock torch-ROCm)
+    "llama7b_layer_b32_s128": ("LLaMA-2-7B decoder layer (W8A8 linears + torch RMSNorm/RoPE/SDPA/SiLU), batch 32 x 128 tok", 4096, "layer:32:128:1"),
+    "llama7b_attn_block_b1_s2048": ("LLaMA-2-7B decoder layer, batch 1 x 2048 tok (BASELINE configs[1] shape)", 2048, "layer:1:2048:1"),
+    "llama7b_decoder_b32_s2048": ("LLaMA-2-7B full decoder stack, 32 layers, batch 32 x 2048 tok (BASELINE configs[2])", 65536, "layer:32:2048:32"),
     "opt13b_fc2": ("OPT-13B fc2 W8A8BFP32OFP32LinearWithQuantScale 20480->5120 +bias, per-token, 256 rows per GPU", 256,
                    [("fc2", "quantscale", 20480, 5120, "per-token", True)]),
 }
@@ -88,6 +92,41 @@ def make_workload(spec, M, device, seed, dtype):
         if key not in xs:
             xs[key] = ((h / input_scale) if (aq == "per-tensor" and kind == "linear") else h).to(dtype)
     return mods.to(device), xs
+
+
+LLAMA7B_SPEC = [("q", "linear", 4096, 4096, "per-tensor", False), ("k", "linear", 4096, 4096, "per-tensor", False),
+                ("v", "linear", 4096, 4096, "per-tensor", False), ("o", "quantscale", 4096, 4096, "per-token", False),
+                ("gate", "linear", 4096, 11008, "per-tensor", False), ("up", "linear", 4096, 11008, "per-tensor", False),
+                ("down", "quantscale", 11008, 4096, "per-token", False)]
+
+
+def make_layer_workload(spec, device, seed, dtype):
+    """spec = "layer:B:S:L": L quantised LLaMA-2-7B decoder layers (distinct random-init weights) and a
+    [B,S,4096] hidden-state batch; calibration scales come from the float layer on that batch."""
+    from autosmoothquant_amd import harness
+    _, B, S, Lyr = spec.split(":")
+    B, S, Lyr = int(B), int(S), int(Lyr)
+    torch.manual_seed(seed)
+    h = torch.randn(min(B, 2), min(S, 256), 4096, device=device, dtype=torch.float32)   # small calibration batch
+    layers = []
+    for i in range(Lyr):
+        fl = harness.LlamaLayer(4096, 11008, 32).to(device)
+        with torch.no_grad():
+            for p in fl.parameters():
+                if p.dim() == 2:
+                    p.copy_(torch.randn(p.shape, device=device) * 0.02)
+        scales = harness.calibrate(fl, h)
+        layers.append(harness.to_w8a8(fl.to(dtype), scales))
+        del fl
+    x = torch.randn(B, S, 4096, device=device, dtype=torch.float32).to(dtype)
+    return torch.nn.ModuleList(layers), x
+
+
+@torch.no_grad()
+def run_layers(layers, x):
+    for l in layers:
+        x = l(x)
+    return x
 
 
 def run_step(mods, spec, xs):
@@ -224,7 +263,16 @@ def main():
     tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
 
     # rank 0 owns the quantised checkpoint; the other ranks start from different buffers and receive it
-    mods, xs = make_workload(spec, M, device, seed=1234 if rank == 0 else 99 + rank, dtype=tdt)
+    layer_mode = isinstance(spec, str)
+    if layer_mode:
+        mods, xs = make_layer_workload(spec, device, seed=1234 if rank == 0 else 99 + rank, dtype=tdt)
+        nlayers = len(mods)
+        spec = LLAMA7B_SPEC
+        step = lambda: run_layers(mods, xs)
+    else:
+        mods, xs = make_workload(spec, M, device, seed=1234 if rank == 0 else 99 + rank, dtype=tdt)
+        nlayers = 1
+        step = lambda: run_step(mods, spec, xs)
     bcast = None
     if world > 1:
         torch.cuda.synchronize()
@@ -244,11 +292,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        run_step(mods, spec, xs)
+        step()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run_step(mods, spec, xs)
+        step()
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -256,7 +304,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    ops_per_step = sum(2.0 * M * N * K for (_, _, K, N, _, _) in spec) * world
+    ops_per_step = sum(2.0 * M * N * K for (_, _, K, N, _, _) in spec) * world * nlayers
     ms_per_step = elapsed / args.steps * 1e3
     tops = ops_per_step * args.steps / elapsed / 1e12
     tokens_per_s = M * world * args.steps / elapsed
@@ -264,11 +312,17 @@ def main():
     if rank == 0:
         # dominant kernel: the largest GEMM of the step
         lbl, kind, K, N, aq, bias = max(spec, key=lambda s: s[2] * s[3])
-        avg_ms, min_ms, kname = measure_dominant_kernel(mods[lbl], xs[(K, aq, kind)])
-        ops_k = 2.0 * M * N * K
+        if layer_mode:
+            xin = (torch.randn(min(M, 8192), K, device=device) * 40).to(tdt)
+            avg_ms, min_ms, kname = measure_dominant_kernel(getattr(mods[0], lbl + "_proj"), xin)
+            M_k = xin.shape[0]
+        else:
+            avg_ms, min_ms, kname = measure_dominant_kernel(mods[lbl], xs[(K, aq, kind)])
+            M_k = M
+        ops_k = 2.0 * M_k * N * K
         esz = {"f16": 2, "bf16": 2, "f32": 4}[args.dtype]
         # algorithmic bytes of the fused GEMM launch: int8 activations in, int8 weights in, fp out (+ per-token scales, bias)
-        bytes_k = M * K + N * K + M * N * esz + (4 * M if aq == "per-token" else 0) + (4 * N if bias else 0)
+        bytes_k = M_k * K + N * K + M_k * N * esz + (4 * M_k if aq == "per-token" else 0) + (4 * N if bias else 0)
         if kname == "skinny":   # M <= 64: one pass over the weights, HBM-bound
             achieved, peak, unit, bound = bytes_k / (avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
         else:
@@ -284,8 +338,8 @@ def main():
                        "parallelism": f"replica x{world} (rows sharded, weights broadcast once)"},
             "roofline": {"bound": bound, "achieved": round(achieved, 1), "peak": peak, "unit": unit,
                          "frac": round(achieved / peak, 4),
-                         "traffic": pmc_traffic(f"gemm_i8_{kname}<asq::EpiDequant<{ {'f32': 0, 'f16': 1, 'bf16': 2}[args.dtype] }, {'true' if aq == 'per-token' else 'false'}, false, {'true' if bias else 'false'}>", M, N, K),
-                         "kernel": f"gemm_i8_{kname}<EpiDequant {args.dtype}> [{lbl}] M={M} N={N} K={K}",
+                         "traffic": pmc_traffic(f"gemm_i8_{kname}<asq::EpiDequant<{ {'f32': 0, 'f16': 1, 'bf16': 2}[args.dtype] }, {'true' if aq == 'per-token' else 'false'}, false, {'true' if bias else 'false'}>", M_k, N, K),
+                         "kernel": f"gemm_i8_{kname}<EpiDequant {args.dtype}> [{lbl}] M={M_k} N={N} K={K}",
                          "avg_us": round(avg_ms * 1e3, 2), "min_us": round(min_ms * 1e3, 2),
                          "algorithmic_ops": ops_k, "algorithmic_bytes": bytes_k,
                          "tops": round(ops_k / (avg_ms * 1e-3) / 1e12, 1),
@@ -293,6 +347,9 @@ def main():
         }
         if bcast:
             out["weight_broadcast"] = bcast
+        if layer_mode:
+            out["config"]["note"] = "TOPS counts the int8 linear ops only; tokens_per_s is the whole layer stack incl. the torch attention/norm glue"
+            out["config"]["layers"] = nlayers
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, min(M, 256), args.dtype)
         print(json.dumps(out), flush=True)
