@@ -89,3 +89,28 @@ extern "C" int asq_linear_w8a8(const int8_t *xq, const int8_t *w, void *out, int
     default: return launch_dequant<ASQ_BF16>(a, s);
     }
 }
+
+extern "C" int asq_linear_w8a8_grouped(const int8_t *xq, const int8_t *w, void *out, int out_dtype, const int32_t *group_offsets, int ngroups,
+                                       int64_t M, int64_t N, int64_t K, const float *s_group, const float *s_row, const float *bias, void *stream)
+{
+    int rc = check_gemm_args("asq_linear_w8a8_grouped", xq, w, out, M, N, K);
+    if (rc) return rc;
+    if (M == 0 || N == 0) return ASQ_OK;
+    ASQ_REQUIRE(group_offsets != nullptr && s_group != nullptr && ngroups > 0 && ngroups <= 4096, ASQ_ERR_NULL,
+                "asq_linear_w8a8_grouped: need group_offsets, s_group and 1 <= ngroups <= 4096");
+    ASQ_REQUIRE(out_dtype == ASQ_F32 || out_dtype == ASQ_F16 || out_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_linear_w8a8_grouped: bad out_dtype %d", out_dtype);
+    ASQ_REQUIRE(((uintptr_t)out % asq_dtype_size(out_dtype)) == 0 && ((((uintptr_t)s_row | (uintptr_t)s_group | (uintptr_t)bias | (uintptr_t)group_offsets) & 3) == 0),
+                ASQ_ERR_ALIGN, "asq_linear_w8a8_grouped: misaligned pointer");
+    const size_t vbytes = out_dtype == ASQ_F32 ? 16 : 8;
+    const bool vec_ok = (N % 4 == 0) && (((uintptr_t)out & (vbytes - 1)) == 0) && ((((uintptr_t)bias) & 15) == 0);
+    DequantArgs a{xq, w, out, M, N, K, 1.0f, s_row, nullptr, bias, ASQ_EPI_SCALE_FIRST, vec_ok, nullptr, 0};
+    a.s_group = s_group;
+    a.goffs = group_offsets;
+    a.ngroups = ngroups;
+    hipStream_t s = (hipStream_t)stream;
+    switch (out_dtype) {
+    case ASQ_F32: return launch_dequant<ASQ_F32>(a, s);
+    case ASQ_F16: return launch_dequant<ASQ_F16>(a, s);
+    default: return launch_dequant<ASQ_BF16>(a, s);
+    }
+}

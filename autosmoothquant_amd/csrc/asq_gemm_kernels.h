@@ -82,6 +82,7 @@ struct EpiI32 {
     int64_t N;
     bool vec_ok;
     __device__ __forceinline__ EpiI32 with_slab(int s, int64_t M, int64_t Ncols) const { return EpiI32{out + (int64_t)s * M * Ncols, N, vec_ok}; }
+    __device__ __forceinline__ const EpiI32 &with_group(int, int64_t) const { return *this; }
     __device__ __forceinline__ float row(int64_t) const { return 1.0f; }
     __device__ __forceinline__ void cols(int64_t, int64_t, v4f &, v4f &) const {}
     __device__ __forceinline__ void store4(int64_t m, int64_t n, const v4i &a, float, const v4f &, const v4f &, int64_t Ncols) const
@@ -111,8 +112,17 @@ template <int DT, bool HAS_ROW, bool HAS_COL, bool HAS_BIAS> struct EpiDequant {
     const float *bias;   // [N]   (HAS_BIAS)
     int order;
     bool vec_ok;
+    const float *s_group;  // grouped launches: per-group scalar dequant scale [ngroups] (device) or null
 
     __device__ __forceinline__ const EpiDequant &with_slab(int, int64_t, int64_t) const { return *this; }
+    __device__ __forceinline__ EpiDequant with_group(int e, int64_t Ncols) const
+    {
+        EpiDequant r = *this;
+        if (s_group) r.s_scalar = s_group[e];
+        if constexpr (HAS_COL) r.s_col += (int64_t)e * Ncols;
+        if constexpr (HAS_BIAS) r.bias += (int64_t)e * Ncols;
+        return r;
+    }
     __device__ __forceinline__ float row(int64_t m) const { return HAS_ROW ? s_row[m] : 1.0f; }
 
     __device__ __forceinline__ void cols(int64_t n, int64_t Ncols, v4f &sc, v4f &b) const
@@ -184,6 +194,7 @@ struct EpiI8 {  // out = sat_i8(rne(alpha*acc + beta*c)), c = previous out
     float alpha, beta;
     bool vec_ok;
     __device__ __forceinline__ const EpiI8 &with_slab(int, int64_t, int64_t) const { return *this; }
+    __device__ __forceinline__ const EpiI8 &with_group(int, int64_t) const { return *this; }
     __device__ __forceinline__ float row(int64_t) const { return 1.0f; }
     __device__ __forceinline__ void cols(int64_t, int64_t, v4f &, v4f &) const {}
     __device__ __forceinline__ int one(int acc, int c) const
@@ -227,6 +238,7 @@ template <int DT, bool HAS_BIAS, class MMA_ = MmaFp8> struct EpiFp8 {
     const float *bias;
     bool vec_ok;
     __device__ __forceinline__ const EpiFp8 &with_slab(int, int64_t, int64_t) const { return *this; }
+    __device__ __forceinline__ const EpiFp8 &with_group(int, int64_t) const { return *this; }
     __device__ __forceinline__ float row(int64_t m) const { return a_scale_dev ? (a_per_token ? a_scale_dev[m] : a_scale_dev[0]) : a_scale_host; }
     __device__ __forceinline__ void cols(int64_t n, int64_t Ncols, v4f &sc, v4f &b) const
     {
@@ -461,9 +473,23 @@ template <class Epi> void launch_skinny(const int8_t *x, const int8_t *w, int64_
 
 template <class Epi>
 int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, Epi epi, hipStream_t s, const char *what, void *ws = nullptr,
-                size_t ws_bytes = 0)
+                size_t ws_bytes = 0, const int *goffs = nullptr, int ngroups = 0)
 {
     if (M == 0 || N == 0) return ASQ_OK;
+    if (goffs != nullptr) {  // grouped: tiled kernel only; grid = host-side upper bound on the number of tiles
+        const bool ok = (((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0) && K % 128 == 0 && K >= 128 && K <= (1 << 24);
+        ASQ_REQUIRE(ok, ASQ_ERR_DIM, "%s: grouped launch needs K %% 128 == 0 and 16-B aligned operands", what);
+        const int64_t tn = (N + 255) / 256, tiles = (M / 256 + ngroups) * tn;
+        ASQ_REQUIRE(tiles < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
+        auto kfn = gemm_i8_p8<Epi>;
+        hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES);
+        if (e != hipSuccess) {
+            asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+            return (int)e;
+        }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, 0, (int)tn, 1, goffs, ngroups, epi);
+        return asq_after_launch(s, what);
+    }
     constexpr bool kInt = Epi::Mma::kIsInt;
     GemmKernel kern = pick_kernel(x, w, M, N, K);
     if (!kInt && kern == KERN_SKINNY) kern = KERN_P8;  // fp8: no weight-streaming variant yet
@@ -480,7 +506,7 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
                 asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
                 return (int)e;
             }
-            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn * ksplit)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, ksplit, slab);
+            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn * ksplit)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, ksplit, (const int *)nullptr, 0, slab);
             int64_t blocks = (M * (N / 4) + 255) / 256;
             if (blocks > 8192) blocks = 8192;
             hipLaunchKernelGGL((splitk_reduce<Epi>), dim3((unsigned)blocks), dim3(256), 0, s, (const int32_t *)ws, ksplit, M, N, epi);
@@ -492,7 +518,7 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
             return (int)e;
         }
-        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, epi);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, (const int *)nullptr, 0, epi);
     } else if (kern == KERN_SKINNY) {
         if constexpr (kInt) launch_skinny(x, w, M, N, K, epi, s);
     } else {
@@ -515,13 +541,16 @@ struct DequantArgs {
     bool vec_ok;
     void *ws;
     size_t ws_bytes;
+    const float *s_group = nullptr;  // grouped launch (asq_linear_w8a8_grouped)
+    const int *goffs = nullptr;
+    int ngroups = 0;
 };
 template <int DT> int launch_dequant(const DequantArgs &a, hipStream_t s);
 
 template <int DT, bool R, bool C, bool B> static inline int launch_dequant_one(const DequantArgs &a, hipStream_t s)
 {
-    return launch_gemm(a.xq, a.w, a.M, a.N, a.K, EpiDequant<DT, R, C, B>{a.out, a.N, a.s_scalar, a.s_row, a.s_col, a.bias, a.order, a.vec_ok}, s,
-                       "asq_linear_w8a8", a.ws, a.ws_bytes);
+    return launch_gemm(a.xq, a.w, a.M, a.N, a.K, EpiDequant<DT, R, C, B>{a.out, a.N, a.s_scalar, a.s_row, a.s_col, a.bias, a.order, a.vec_ok, a.s_group},
+                       s, "asq_linear_w8a8", a.ws, a.ws_bytes, a.goffs, a.ngroups);
 }
 
 template <int DT> static inline int launch_dequant_impl(const DequantArgs &a, hipStream_t s)

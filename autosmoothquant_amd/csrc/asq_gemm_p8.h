@@ -91,7 +91,8 @@ __device__ __forceinline__ void p8_dma16(const int8_t *sbase, unsigned voff, uns
 
 template <class Epi, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N,
-                                                     int64_t K, int tiles_m, int tiles_n, int ksplit, Epi epi_in)
+                                                     int64_t K, int tiles_m, int tiles_n, int ksplit, const int *__restrict__ goffs, int ngroups,
+                                                     Epi epi_in)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -101,18 +102,43 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
     P8_BLK(0);
     // split-K (ksplit > 1, int32 slabs only): logical id = split * ntiles + tile, so the blocks an XCD
     // receives share one K range and neighbouring tiles (operand panels stay L2-local)
+    // Grouped mode (goffs != null; Mixtral-style experts): x rows are sorted by group, goffs[0..ngroups]
+    // are the row offsets (device int32), w is [ngroups][N][K].  The grid is the host-side upper bound
+    // floor(M/256) + ngroups tile rows; each block finds its (group, tile) by a scalar scan, surplus blocks exit.
     constexpr int GM = 4;
-    const int nwg = tiles_m * tiles_n;
-    const int lid = xcd_remap(blockIdx.x, nwg * ksplit);
-    const int split = lid / nwg;
-    const int id = lid - split * nwg;
-    const Epi epi = epi_in.with_slab(split, M, N);
+    int split = 0, id;
+    int64_t m_base = 0;
+    Epi epi = epi_in;
+    if (goffs != nullptr) {
+        int gid = xcd_remap(blockIdx.x, gridDim.x), e = 0, r0 = 0, r1 = 0, tm_e = 0;
+        for (; e < ngroups; ++e) {
+            r0 = goffs[e];
+            r1 = goffs[e + 1];
+            tm_e = (r1 - r0 + 255) >> 8;
+            const int cnt = tm_e * tiles_n;
+            if (gid < cnt) break;
+            gid -= cnt;
+        }
+        if (e == ngroups) return;  // uniform for the whole block, before any barrier
+        id = gid;
+        tiles_m = tm_e;
+        m_base = r0;
+        M = r1;  // rows >= r1 belong to the next group: clamp loads, mask stores
+        w += (int64_t)e * N * K;
+        epi = epi_in.with_group(e, N);
+    } else {
+        const int nwg = tiles_m * tiles_n;
+        const int lid = xcd_remap(blockIdx.x, nwg * ksplit);
+        split = lid / nwg;
+        id = lid - split * nwg;
+        epi = epi_in.with_slab(split, M, N);
+    }
     const int per_group = GM * tiles_n;
     const int group = id / per_group, in_group = id - group * per_group;
     const int first_m = group * GM;
     const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
     const int tile_m = first_m + in_group % gm, tile_n = in_group / gm;
-    const int64_t m0 = (int64_t)tile_m * 256, n0 = (int64_t)tile_n * 256;
+    const int64_t m0 = m_base + (int64_t)tile_m * 256, n0 = (int64_t)tile_n * 256;
 
     // ---- DMA sources: uniform tile base (SGPR pair, + k advanced per K-tile) + 32-bit lane offset.
     // This wave fills row-groups 2*wave, 2*wave+1 (8 rows each) of every unit.

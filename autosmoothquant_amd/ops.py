@@ -120,6 +120,31 @@ def linear_w8a8(xq, w, out_dtype, s_scalar=1.0, s_row=None, s_col=None, bias=Non
     return out
 
 
+def linear_w8a8_grouped(xq, w, group_offsets, s_group, out_dtype, s_row=None, bias=None):
+    """ngroups independent W8A8 linears in one launch (Mixtral experts).  xq int8 [M,K] rows sorted by group,
+    w int8 [G,N,K], group_offsets int32 [G+1] on the device, s_group f32 [G] on the device (each expert's
+    dequant_scale), s_row f32 [M] (per-token) or None, bias f32 [G,N] or None.  Row m of the result is
+    bit-identical to linear_w8a8 on its group's slice."""
+    _dev(xq, "xq"), _dev(w, "weight"), _dev(group_offsets, "group_offsets"), _dev(s_group, "s_group")
+    if xq.dtype != torch.int8 or w.dtype != torch.int8 or xq.dim() != 2 or w.dim() != 3 or xq.shape[1] != w.shape[2]:
+        raise ValueError("xq [M,K] int8 and weight [G,N,K] int8 with equal K expected")
+    M, K = xq.shape
+    G, N = w.shape[0], w.shape[1]
+    if group_offsets.dtype != torch.int32 or group_offsets.numel() != G + 1 or s_group.dtype != torch.float32 or s_group.numel() != G:
+        raise ValueError("group_offsets must be int32 [G+1] and s_group float32 [G]")
+    for name, t, n in (("s_row", s_row, M), ("bias", bias, G * N)):
+        if t is not None:
+            _dev(t, name)
+            if t.dtype != torch.float32 or t.numel() != n:
+                raise ValueError(f"{name} must be float32 with {n} elements")
+    out = torch.empty((M, N), dtype=out_dtype, device=xq.device)
+    dev = _same_device(xq, w, group_offsets, s_group, s_row, bias)
+    with torch.cuda.device(dev):
+        L.check(L.lib().asq_linear_w8a8_grouped(xq.data_ptr(), w.data_ptr(), out.data_ptr(), _DT[out_dtype], group_offsets.data_ptr(), G, M, N, K,
+                                                s_group.data_ptr(), _ptr(s_row), _ptr(bias), _stream(xq)), "asq_linear_w8a8_grouped")
+    return out
+
+
 def linear_w8a8_forward(x2d, w, act_mode, quant_scale, s_scalar, s_col=None, bias=None):
     """Whole module forward on a 2-D activation: quantise -> GEMM + epilogue, one stream,
     no int32 round trip.  Returns out [M,N] in x's dtype."""

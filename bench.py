@@ -49,6 +49,8 @@ WORKLOADS = {
     "llama7b_layer_b32_s128": ("LLaMA-2-7B decoder layer (W8A8 linears + torch RMSNorm/RoPE/SDPA/SiLU), batch 32 x 128 tok", 4096, "layer:32:128:1"),
     "llama7b_attn_block_b1_s2048": ("LLaMA-2-7B decoder layer, batch 1 x 2048 tok (BASELINE configs[1] shape)", 2048, "layer:1:2048:1"),
     "llama7b_decoder_b32_s2048": ("LLaMA-2-7B full decoder stack, 32 layers, batch 32 x 2048 tok (BASELINE configs[2])", 65536, "layer:32:2048:32"),
+    "mixtral_experts": ("Mixtral-8x7B expert MLPs (w1,w3 per-tensor 4096->14336; w2 per-token 14336->4096), 4096 tokens x top-2 "
+                        "routed to 8 experts, ONE grouped launch per projection (BASELINE configs[4])", 8192, "moe"),
     "opt13b_fc2": ("OPT-13B fc2 W8A8BFP32OFP32LinearWithQuantScale 20480->5120 +bias, per-token, 256 rows per GPU", 256,
                    [("fc2", "quantscale", 20480, 5120, "per-token", True)]),
 }
@@ -92,6 +94,64 @@ def make_workload(spec, M, device, seed, dtype):
         if key not in xs:
             xs[key] = ((h / input_scale) if (aq == "per-tensor" and kind == "linear") else h).to(dtype)
     return mods.to(device), xs
+
+
+MIXTRAL_SPEC = [("w1", "linear", 4096, 14336, "per-tensor", False), ("w3", "linear", 4096, 14336, "per-tensor", False),
+                ("w2", "quantscale", 14336, 4096, "per-token", False)]
+
+
+def make_moe_workload(device, seed, dtype, skew=False):
+    """8 experts, 8192 routed rows (4096 tokens x top-2), counts from a seeded multinomial; weights are
+    random-init N(0,0.02^2) quantised per expert (absmax/127) on the device."""
+    from autosmoothquant_amd import ops
+    g = torch.Generator(device=device).manual_seed(seed)
+    E, H, F_, R = 8, 4096, 14336, 8192
+    p = torch.ones(E) if not skew else torch.tensor([4.0, 2.0, 1.0, 1.0, 0.5, 0.5, 0.0, 1.0])
+    counts = torch.bincount(torch.multinomial(p / p.sum(), R, replacement=True, generator=torch.Generator().manual_seed(seed)), minlength=E)
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)]).to(torch.int32).to(device)
+
+    def qstack(n, k):
+        w = torch.empty(E, n, k, dtype=torch.int8, device=device)
+        sc = torch.empty(E, dtype=torch.float32, device=device)
+        for e in range(E):
+            f = torch.randn(n, k, generator=g, device=device) * 0.02
+            s_ = f.abs().max() / 127
+            w[e] = (f / s_).round().to(torch.int8)
+            sc[e] = s_
+        return w, sc
+    w1, s1 = qstack(F_, H)
+    w3, s3 = qstack(F_, H)
+    w2, s2 = qstack(H, F_)
+    x = torch.randn(R, H, generator=g, device=device)
+    in_scale = float(x.abs().max()) / 127
+    st = dict(E=E, offs=offs, counts=counts.tolist(), w1=w1, w3=w3, w2=w2, s1=s1 * in_scale, s3=s3 * in_scale, s2=s2,
+              x=(x / in_scale).to(dtype))
+
+    def grouped():
+        xq, _ = ops.quantize_act(st["x"], "per-tensor-round")
+        h1 = ops.linear_w8a8_grouped(xq, st["w1"], st["offs"], st["s1"], dtype)
+        h3 = ops.linear_w8a8_grouped(xq, st["w3"], st["offs"], st["s3"], dtype)
+        a = torch.nn.functional.silu(h1) * h3
+        aq, srow = ops.quantize_act(a, "per-token")
+        return ops.linear_w8a8_grouped(aq, st["w2"], st["offs"], st["s2"], dtype, srow)
+
+    s1h, s3h, s2h = st["s1"].tolist(), st["s3"].tolist(), st["s2"].tolist()
+
+    def sequential():   # what the reference's Python expert loop amounts to (models/mixtral.py:142-145)
+        outs, o = [], 0
+        for e, c in enumerate(st["counts"]):
+            if c == 0:
+                continue
+            xe = st["x"][o:o + c]
+            xq, _ = ops.quantize_act(xe, "per-tensor-round")
+            h1 = ops.linear_w8a8(xq, st["w1"][e], dtype, s1h[e])
+            h3 = ops.linear_w8a8(xq, st["w3"][e], dtype, s3h[e])
+            a = torch.nn.functional.silu(h1) * h3
+            aq, srow = ops.quantize_act(a, "per-token")
+            outs.append(ops.linear_w8a8(aq, st["w2"][e], dtype, s2h[e], srow))
+            o += c
+        return torch.cat(outs)
+    return st, grouped, sequential
 
 
 LLAMA7B_SPEC = [("q", "linear", 4096, 4096, "per-tensor", False), ("k", "linear", 4096, 4096, "per-tensor", False),
@@ -263,8 +323,22 @@ def main():
     tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
 
     # rank 0 owns the quantised checkpoint; the other ranks start from different buffers and receive it
-    layer_mode = isinstance(spec, str)
-    if layer_mode:
+    layer_mode = isinstance(spec, str) and spec.startswith("layer")
+    moe_mode = spec == "moe"
+    moe_extra = None
+    if moe_mode:
+        st, step, seq_step = make_moe_workload(device, 1234, tdt)
+        assert torch.equal(step(), seq_step()), "grouped launch != per-expert calls"
+        mods, nlayers, spec = torch.nn.ModuleDict(), 1, MIXTRAL_SPEC
+        for _ in range(3):
+            seq_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            seq_step()
+        torch.cuda.synchronize()
+        moe_extra = {"sequential_per_expert_ms": round((time.perf_counter() - t0) / 10 * 1e3, 4), "rows_per_expert": st["counts"]}
+    elif layer_mode:
         mods, xs = make_layer_workload(spec, device, seed=1234 if rank == 0 else 99 + rank, dtype=tdt)
         nlayers = len(mods)
         spec = LLAMA7B_SPEC
@@ -312,7 +386,21 @@ def main():
     if rank == 0:
         # dominant kernel: the largest GEMM of the step
         lbl, kind, K, N, aq, bias = max(spec, key=lambda s: s[2] * s[3])
-        if layer_mode:
+        if moe_mode:
+            from autosmoothquant_amd import ops as _ops
+            xq_, _ = _ops.quantize_act(st["x"], "per-tensor-round")
+            for _ in range(3):
+                _ops.linear_w8a8_grouped(xq_, st["w1"], st["offs"], st["s1"], tdt)
+            torch.cuda.synchronize()
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record()
+            for _ in range(10):
+                _ops.linear_w8a8_grouped(xq_, st["w1"], st["offs"], st["s1"], tdt)
+            eb.record()
+            eb.synchronize()
+            avg_ms = min_ms = ea.elapsed_time(eb) / 10
+            kname, lbl, kind, K, N, aq, bias, M_k = "p8", "w1 grouped x8", "linear", 4096, 14336, "per-tensor", False, M
+        elif layer_mode:
             xin = (torch.randn(min(M, 8192), K, device=device) * 40).to(tdt)
             avg_ms, min_ms, kname = measure_dominant_kernel(getattr(mods[0], lbl + "_proj"), xin)
             M_k = xin.shape[0]
@@ -347,6 +435,9 @@ def main():
         }
         if bcast:
             out["weight_broadcast"] = bcast
+        if moe_extra:
+            out["config"].update(moe_extra)
+            out["config"]["note"] = "step = quantise + grouped w1, w3 + SiLU*mul (torch) + per-token quantise + grouped w2; TOPS counts the int8 ops"
         if layer_mode:
             out["config"]["note"] = "TOPS counts the int8 linear ops only; tokens_per_s is the whole layer stack incl. the torch attention/norm glue"
             out["config"]["layers"] = nlayers

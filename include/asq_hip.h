@@ -105,6 +105,19 @@ int asq_linear_w8a8(const int8_t *xq, const int8_t *w, void *out, int out_dtype,
                     float s_scalar, const float *s_row, const float *s_col, const float *bias,
                     int epi_order, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- grouped launch: ngroups independent linears (Mixtral experts, reference models/mixtral.py:99-145 runs
+ * them as a Python loop of Int8Linear calls) in ONE kernel launch.
+ *   xq  int8 [M,K]   rows sorted by group; group g owns rows group_offsets[g] .. group_offsets[g+1]-1
+ *   group_offsets    DEVICE int32 [ngroups+1] (prefix sums; stays on the device: no host sync for the routing)
+ *   w   int8 [ngroups][N][K];  s_group f32 [ngroups] (DEVICE): each expert's scalar dequant_scale
+ *   s_row f32 [M] | NULL (per-token);  bias f32 [ngroups][N] | NULL;  out [M,N] of out_dtype
+ * out[m,n] = (s_group[g(m)] [* s_row[m]]) * float(acc) (+ bias[g(m)][n]) -- per row identical to asq_linear_w8a8
+ * on that group's slice.  Needs K % 128 == 0 and 16-B aligned operands; empty groups are fine. */
+int asq_linear_w8a8_grouped(const int8_t *xq, const int8_t *w, void *out, int out_dtype,
+                            const int32_t *group_offsets, int ngroups,
+                            int64_t M, int64_t N, int64_t K,
+                            const float *s_group, const float *s_row, const float *bias, void *stream);
+
 /* ---- whole module forward: W8A8BFP32OFP32Linear / ...QKVLinear / ...LinearWithQuantScale .forward
  * (linear.py:83-106, :158-208, :278-302) = asq_quantize_act + asq_linear_w8a8 on `stream`.
  * out has x's dtype.  workspace: asq_linear_w8a8_workspace_bytes(M,N,K) bytes (int8 activations + row scales +

@@ -303,3 +303,28 @@ def test_full_size_fused_forward_matches_unfused(dev):
     ops.gemm_i8_i32(xq, wd, acc)
     ref = O.dequant_epilogue(acc.cpu().numpy(), np.float32(1.0 / 8192), None, None, "f16")
     assert np.array_equal(t_out(y), ref)
+
+
+@pytest.mark.parametrize("counts", [[300, 0, 17, 256, 1, 511], [40, 40], [0, 0, 5], [700]])
+@pytest.mark.parametrize("per_token", [False, True])
+def test_grouped_launch_equals_per_group_calls(counts, per_token, dev):
+    """Mixtral-style grouped launch (one kernel over all experts, routing offsets on the device) ==
+    one asq_linear_w8a8 call per expert, bit for bit; empty and ragged groups included."""
+    from autosmoothquant_amd import ops
+    G, N, K = len(counts), 320, 256
+    M = sum(counts)
+    xq = torch.from_numpy(detrng.int8_uniform(140, M + G, (M, K))).to(dev)
+    w = torch.from_numpy(detrng.int8_uniform(141, G, (G, N, K))).to(dev)
+    sg = torch.from_numpy((np.abs(detrng.normal(142, G, (G,))) * 1e-3 + 1e-4).astype(np.float32)).to(dev)
+    bias = torch.from_numpy(detrng.normal(143, G, (G, N)).astype(np.float32)).to(dev)
+    s_row = torch.from_numpy((np.abs(detrng.normal(144, M, (M,))) * 0.01 + 1e-3).astype(np.float32)).to(dev) if per_token else None
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device=dev)
+    for use_bias in (False, True):
+        got = ops.linear_w8a8_grouped(xq, w, offs, sg, torch.float16, s_row, bias if use_bias else None)
+        o = 0
+        for g, c in enumerate(counts):
+            if c:
+                ref = ops.linear_w8a8(xq[o:o + c].contiguous(), w[g], torch.float16, float(sg[g]), None if s_row is None else s_row[o:o + c].contiguous(),
+                                      None, bias[g] if use_bias else None)
+                assert torch.equal(got[o:o + c], ref), (g, c, use_bias)
+            o += c
