@@ -302,6 +302,7 @@ def main():
     ap.add_argument("--workload", default="llama7b_attn_linears", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="capture one step in a hipGraph and replay it in the timed loop (launch-bound decode shapes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -365,6 +366,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.graph:
+        # hipGraph capture of one whole step on a side stream (torch.cuda.CUDAGraph = hipGraph on ROCm); the C-ABI
+        # launches on torch's current stream, so its kernels are captured like any torch op
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            graph_out = step()
+        eager_step, step = step, graph.replay
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -423,7 +434,8 @@ def main():
             "data": "synthetic (random-init N(0,0.02^2) weights quantised by from_float; N(0,1) activations with 1% outlier channels x20)",
             "config": {"workload": f"{args.workload}: {desc}", "M_per_gpu": M, "act_dtype": args.dtype,
                        "linears": [f"{l}:{k}:{K_}x{N_}:{a}" for (l, k, K_, N_, a, _) in spec],
-                       "parallelism": f"replica x{world} (rows sharded, weights broadcast once)"},
+                       "parallelism": f"replica x{world} (rows sharded, weights broadcast once)",
+                       "launch": "hipGraph replay" if args.graph else "eager (one C-ABI call per linear)"},
             "roofline": {"bound": bound, "achieved": round(achieved, 1), "peak": peak, "unit": unit,
                          "frac": round(achieved / peak, 4),
                          "traffic": pmc_traffic(f"gemm_i8_{kname}<asq::EpiDequant<{ {'f32': 0, 'f16': 1, 'bf16': 2}[args.dtype] }, {'true' if aq == 'per-token' else 'false'}, false, {'true' if bias else 'false'}>", M_k, N, K),
