@@ -456,8 +456,9 @@ template <class Epi> void launch_skinny(const int8_t *x, const int8_t *w, int64_
 {
     const int mt = (int)((M + 15) / 16);
     const int64_t blocks = (N + 15) / 16;
-    // enough waves to cover 256 CUs x 16 wave slots; few blocks -> more waves per block
-    const int wpb = blocks * 4 >= 4096 ? 4 : (blocks * 8 >= 4096 ? 8 : 16);
+    // as many waves per block as still lets EVERY block be resident at once (256 CUs x 16 wave slots at
+    // <= 128 VGPRs): a second round of blocks would cost a whole extra memory round trip
+    const int wpb = blocks * 16 <= 4096 ? 16 : (blocks * 8 <= 4096 ? 8 : 4);
     dim3 grid((unsigned)blocks), block((unsigned)(wpb * 64));
 #define ASQ_SK(MT_, W_) hipLaunchKernelGGL((gemm_i8_skinny<Epi, MT_, W_>), grid, block, 0, s, x, w, M, N, K, epi)
 #define ASQ_SKW(MT_) do { if (wpb == 4) ASQ_SK(MT_, 4); else if (wpb == 8) ASQ_SK(MT_, 8); else ASQ_SK(MT_, 16); } while (0)

@@ -59,9 +59,18 @@ __global__ void __launch_bounds__(WPB * 64) gemm_i8_skinny(const int8_t *__restr
                 const int64_t kb = (int64_t)u * 128;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
+#ifdef SK_ABL_NOW   // probe-only ablations (tools/ubench/skinny_abl.hip): results invalid
+                    st.wf[i][h] = (v4i){lane, u, h, 1};
+#else
                     st.wf[i][h] = __builtin_nontemporal_load((const v4i *)(wp + kb + 64 * h));  // streamed once
+#endif
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) st.xf[i][h][mt] = *(const v4i *)(xp[mt] + kb + 64 * h);
+                    for (int mt = 0; mt < MT; ++mt)
+#ifdef SK_ABL_NOX
+                        st.xf[i][h][mt] = (v4i){lane, mt, u, h};
+#else
+                        st.xf[i][h][mt] = *(const v4i *)(xp[mt] + kb + 64 * h);
+#endif
                 }
             } else {
 #pragma unroll
