@@ -452,24 +452,39 @@ static inline int pick_ksplit(int64_t tiles, int64_t K, int64_t M, int64_t N, si
     return s < 1 ? 1 : (int)s;
 }
 
-template <class Epi> void launch_skinny(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, const Epi &epi, hipStream_t s)
+template <class Epi, int MT> int launch_skinny_mt(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, const Epi &epi, hipStream_t s)
 {
-    const int mt = (int)((M + 15) / 16);
-    const int64_t blocks = (N + 15) / 16;
-    // as many waves per block as still lets EVERY block be resident at once (256 CUs x 16 wave slots at
-    // <= 128 VGPRs): a second round of blocks would cost a whole extra memory round trip
-    const int wpb = blocks * 16 <= 4096 ? 16 : (blocks * 8 <= 4096 ? 8 : 4);
-    dim3 grid((unsigned)blocks), block((unsigned)(wpb * 64));
-#define ASQ_SK(MT_, W_) hipLaunchKernelGGL((gemm_i8_skinny<Epi, MT_, W_>), grid, block, 0, s, x, w, M, N, K, epi)
-#define ASQ_SKW(MT_) do { if (wpb == 4) ASQ_SK(MT_, 4); else if (wpb == 8) ASQ_SK(MT_, 8); else ASQ_SK(MT_, 16); } while (0)
-    switch (mt) {
-    case 1: ASQ_SKW(1); break;
-    case 2: ASQ_SKW(2); break;
-    case 3: ASQ_SKW(3); break;
-    default: ASQ_SKW(4); break;
+    constexpr int64_t LDS_CU = 160 * 1024;
+    const int64_t ntiles = (N + 15) / 16;
+    const int64_t perwave = SK_STAGES * (1 + MT) * 2048 + MT * 1024;  // DMA ring + reduction slot
+    // the most waves per block (K parallelism inside a channel tile) that still gives EVERY tile a resident block
+    int wpb = 8;
+    while (wpb > 1 && 256 * (LDS_CU / (wpb * perwave)) < ntiles) wpb >>= 1;
+    while (wpb > 1 && wpb * perwave > LDS_CU) wpb >>= 1;
+    int64_t per_cu = LDS_CU / (wpb * perwave);
+    if (per_cu > 16) per_cu = 16;
+    if (per_cu * wpb > 32) per_cu = 32 / wpb;
+    int64_t grid = 256 * per_cu;   // persistent beyond that: blocks walk the tiles grid-stride
+    if (grid > ntiles) grid = ntiles;
+    const size_t lds = (size_t)(wpb * perwave);
+    auto kfn = gemm_i8_skinny<Epi, MT>;
+    hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        asq_set_error("skinny: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return (int)e;
     }
-#undef ASQ_SKW
-#undef ASQ_SK
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)(wpb * 64)), lds, s, x, w, M, N, K, wpb, epi);
+    return ASQ_OK;
+}
+
+template <class Epi> int launch_skinny(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, const Epi &epi, hipStream_t s)
+{
+    switch ((int)((M + 15) / 16)) {
+    case 1: return launch_skinny_mt<Epi, 1>(x, w, M, N, K, epi, s);
+    case 2: return launch_skinny_mt<Epi, 2>(x, w, M, N, K, epi, s);
+    case 3: return launch_skinny_mt<Epi, 3>(x, w, M, N, K, epi, s);
+    default: return launch_skinny_mt<Epi, 4>(x, w, M, N, K, epi, s);
+    }
 }
 
 template <class Epi>
@@ -521,7 +536,10 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
         }
         hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, (const int *)nullptr, 0, epi);
     } else if (kern == KERN_SKINNY) {
-        if constexpr (kInt) launch_skinny(x, w, M, N, K, epi, s);
+        if constexpr (kInt) {
+            const int rc = launch_skinny(x, w, M, N, K, epi, s);
+            if (rc) return rc;
+        }
     } else {
         const bool fast = (K % 16 == 0) && (((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0);
         dim3 grid((unsigned)((N + GEN_T - 1) / GEN_T), (unsigned)((M + GEN_T - 1) / GEN_T));

@@ -1,123 +1,196 @@
 // "skinny": M <= 64 rows (decode / cfg1).  The problem is a weight stream: W [N,K] int8 is read
-// exactly once from HBM and nothing else matters (4096x4096 at M=32: 16.8 MB of W vs 0.13 MB
-// of X and 0.26 MB of output) -> the roofline is HBM bandwidth, not MFMA.
+// exactly once from HBM (4096x4096 at M=32: 16.8 MB of W vs 0.13 MB of X and 0.26 MB of output)
+// -> the roofline is HBM bandwidth, not MFMA.
 //
-// Decomposition: one block of WPB (4..16) waves per 16 output channels; the waves split
-// K in 128-byte units (wave v takes units v, v+WPB, ...: a block's waves sweep whole rows
-// contiguously and each 128-B line is consumed by exactly one wave).  Every unit is two
-// v_mfma_i32_16x16x64_i8 steps: W rows are the matrix-core A operand, X rows the B operand,
-// loaded STRAIGHT from global memory into VGPRs (no LDS round trip: the tile is never reused
-// inside the block), up to 4 units (8 x 16 B of W + 8*MT x 16 B of X per lane) in flight per
-// wave before the first MFMA -- at K = 4096 the whole problem is in flight at once.
-// The 16 partial accumulators are summed through LDS (integers: exact, order-free) and the
-// first MT waves run the fused epilogue.  No split-K across blocks, no workspace, no atomics.
+// Decomposition: one block of `wpb` waves per 16 output channels (grid-stride over channel tiles);
+// the waves split K in 128-byte units (wave v takes units v, v+wpb, ...).  Each unit is
+// 2 x v_mfma_i32_16x16x64_i8 per 16-token tile (W rows = matrix-core A operand, X rows = B operand).
 //
-// Requirements: K % 128 == 0, x / w 16-B aligned, M <= 64.  N, M arbitrary otherwise (rows are
-// clamped for loading and masked at the store).
+// Both operands travel HBM/L2 -> LDS by LDS-DMA in FULL 128-byte lines (8 rows x 128 B per
+// wave-instruction) into a WAVE-PRIVATE 3-stage ring, and are read back as MFMA fragments with
+// conflict-free swizzled ds_read_b128.  Measured reasons (tools/ubench, profiles/):
+//   * loading fragments straight to VGPRs makes every wave-load touch 16 rows x 64 B: half of each
+//     128-B line per instruction.  The W stream then tops out at 3.2-3.5 TB/s (full lines: 5.5-5.9),
+//     and the X operand -- which EVERY block re-reads from L2 -- became the bottleneck: X and W
+//     times added up instead of overlapping (OPT fc2, M=32: 33 us W-only + 37 us X-only = 65 us);
+//   * wave-private rings need no barrier: a wave reads only what it DMA'd itself, ordered by its
+//     own counted s_waitcnt vmcnt; two units stay in flight per wave (>= 100 KB per CU).
+// The wpb partial accumulators of a tile are summed through LDS (integers: exact, order-free) and
+// the first waves run the fused epilogue.  No split-K across blocks, no workspace, no atomics.
+// wpb (8/4/2/1) is chosen by the launcher so that every channel tile has a resident block.
+//
+// Requirements: K % 128 == 0, K <= 2^24, x / w 16-B aligned, M <= 64.  Ragged N, M: rows are clamped
+// for loading and masked at the store.
 #pragma once
+#include <type_traits>
 
 namespace asq {
 
-// waves per block: 16 when there are few blocks (N small: put the whole problem in flight at once),
-// 4 when N/16 blocks already oversubscribe the chip (4 independent blocks per CU overlap each
-// other's load latency, reduction and epilogue).
-template <class Epi, int MT, int WPB>  // MT = number of 16-row token tiles (1..4)
-__global__ void __launch_bounds__(WPB * 64) gemm_i8_skinny(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N,
-                                                            int64_t K, Epi epi)
+constexpr int SK_STAGES = 3;
+
+__device__ __forceinline__ void sk_dma16(const int8_t *sbase, unsigned voff, unsigned lds_dst)
 {
-    __shared__ __attribute__((aligned(16))) v4i red[WPB][MT][64];
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int N> __device__ __forceinline__ void sk_wait_vm()
+{
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+}
+
+template <class Epi, int MT>  // MT = number of 16-row token tiles (1..4)
+__global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
+                                                      int wpb, Epi epi)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int UNIT = (1 + MT) * 2048;  // one 128-byte K unit: 16 W rows + MT x 16 X rows
+    constexpr int D = 2 * (1 + MT);        // DMA instructions per unit per wave
+    static_assert(2 * D == 8 || 2 * D == 12 || 2 * D == 16 || 2 * D == 20, "sk_wait_vm literals");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, g = lane >> 4;
-    const int64_t n0 = (int64_t)blockIdx.x * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
+    const unsigned ring = lds0 + wave * SK_STAGES * UNIT;
+    v4i *const red = (v4i *)(lds + wpb * SK_STAGES * UNIT);  // [wpb][MT][64]
 
-    int64_t nrow = n0 + r;
-    nrow = nrow < N ? nrow : N - 1;
-    const int8_t *wp = w + nrow * K + 16 * g;
-    const int8_t *xp[MT];
+    const int nunits = (int)(K / 128);
+    const int upt = nunits > wave ? (nunits - wave + wpb - 1) / wpb : 0;  // this wave's units per tile
+    const int64_t ntiles = (N + 15) / 16;
+    const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    const int total = my_tiles * upt;  // work items of this wave, tile-major
+
+    // ---- DMA lane mapping: instruction i of a 16-row tile covers rows 8i .. 8i+7, 128 B each;
+    // lane = 8*row + physical 16-B chunk; the logical chunk it fetches is swizzled by (row>>1)&7
+    const int rr = lane >> 3, cp = lane & 7;
+    unsigned xoff[MT][2];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int64_t mrow = mt * 16 + r;
-        mrow = mrow < M ? mrow : M - 1;
-        xp[mt] = x + mrow * K + 16 * g;
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int64_t m = mt * 16 + 8 * i + rr;
+            m = m < M ? m : M - 1;
+            xoff[mt][i] = (unsigned)(m * K) + (unsigned)((cp ^ (((8 * i + rr) >> 1) & 7)) << 4);
+        }
+    // ---- fragment read addresses (per stage, per k-step): lane (r, g) reads row r, logical chunk 4h+g
+    const int fr = lane & 15, fg = lane >> 4;
+    unsigned faddr[SK_STAGES][2];
+#pragma unroll
+    for (int s = 0; s < SK_STAGES; ++s)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            faddr[s][h] = ring + s * UNIT + fr * 128 + (((4 * h + fg) ^ ((fr >> 1) & 7)) << 4);
+            asm volatile("" : "+v"(faddr[s][h]));  // keep as loop-invariant VGPRs
+        }
+
+    // issue cursor (runs two items ahead of the consume cursor)
+    int it_tile = 0, it_u = 0, issued = 0;
+    unsigned woff[2] = {0, 0};
+    int64_t wt_n0 = -1;
+    auto issue = [&](int stage) {
+        const int64_t n0 = ((int64_t)blockIdx.x + (int64_t)it_tile * gridDim.x) * 16;
+        if (n0 != wt_n0) {  // new tile: per-lane W offsets (clamped at the ragged edge)
+            wt_n0 = n0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int64_t r = 8 * i + rr;
+                r = (n0 + r) < N ? r : (N - 1 - n0);
+                woff[i] = (unsigned)(r * K) + (unsigned)((cp ^ (((8 * i + rr) >> 1) & 7)) << 4);
+            }
+        }
+        const int u = wave + it_u * wpb;
+        const int8_t *wb = w + n0 * K + (int64_t)u * 128;
+        const int8_t *xb = x + (int64_t)u * 128;
+        const unsigned dst = ring + stage * UNIT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) sk_dma16(wb, woff[i], dst + i * 1024);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) sk_dma16(xb, xoff[mt][i], dst + (1 + mt) * 2048 + i * 1024);
+        ++issued;
+        if (++it_u == upt) {
+            it_u = 0;
+            ++it_tile;
+        }
+    };
 
     v4i acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4i){0, 0, 0, 0};
 
-    const int nunits = (int)(K / 128);
-    constexpr int U = MT <= 2 ? 2 : 1;  // 128-B units per pipeline stage (2 stages live: VGPR budget 128 at 16 waves/CU)
-    struct Stage {
-        v4i wf[U][2], xf[U][2][MT];
-    };
-    auto load = [&](Stage &st, int u0) {
+    int done = 0, c_u = 0, c_tile = 0;
+    auto tile_end = [&]() {  // block-wide: sum the wpb partials of this channel tile, fused epilogue
 #pragma unroll
-        for (int i = 0; i < U; ++i) {
-            const int u = u0 + i * WPB;
-            if (u < nunits) {
-                const int64_t kb = (int64_t)u * 128;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-#ifdef SK_ABL_NOW   // probe-only ablations (tools/ubench/skinny_abl.hip): results invalid
-                    st.wf[i][h] = (v4i){lane, u, h, 1};
-#else
-                    st.wf[i][h] = __builtin_nontemporal_load((const v4i *)(wp + kb + 64 * h));  // streamed once
-#endif
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#ifdef SK_ABL_NOX
-                        st.xf[i][h][mt] = (v4i){lane, mt, u, h};
-#else
-                        st.xf[i][h][mt] = *(const v4i *)(xp[mt] + kb + 64 * h);
-#endif
-                }
-            } else {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    st.wf[i][h] = (v4i){0, 0, 0, 0};
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) st.xf[i][h][mt] = (v4i){0, 0, 0, 0};
-                }
+        for (int mt = 0; mt < MT; ++mt) {
+            red[(wave * MT + mt) * 64 + lane] = acc[mt];
+            acc[mt] = (v4i){0, 0, 0, 0};
+        }
+        __syncthreads();
+        const int64_t n0 = ((int64_t)blockIdx.x + (int64_t)c_tile * gridDim.x) * 16;
+        for (int mt = wave; mt < MT; mt += wpb) {
+            v4i s = red[mt * 64 + lane];
+            for (int v = 1; v < wpb; ++v) s += red[(v * MT + mt) * 64 + lane];
+            const int64_t m = mt * 16 + fr, n = n0 + 4 * fg;
+            if (m < M && n < N) {
+                const float sr = Epi::kHasRow ? epi.row(m) : 1.0f;
+                v4f sc = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
+                epi.cols(n, N, sc, bb);
+                epi.store4(m, n, s, sr, sc, bb, N);
             }
         }
-    };
-    auto mma = [&](const Stage &st) {
-#pragma unroll
-        for (int i = 0; i < U; ++i)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(st.wf[i][h], st.xf[i][h][mt], acc[mt], 0, 0, 0);
+        __syncthreads();
+        ++c_tile;
     };
 
-    // two register stages: the loads of stage B are in flight while stage A feeds the matrix core
-    constexpr int STEP = WPB * U;
-    Stage sa, sb;
-    load(sa, wave);
-    for (int u0 = wave; u0 < nunits; u0 += 2 * STEP) {
-        load(sb, u0 + STEP);
-        mma(sa);
-        load(sa, u0 + 2 * STEP);
-        mma(sb);
-    }
-
-    // D layout (16x16): lane owns token m = lane&15 and channels n = 4*(lane>>4) + reg
+    auto step = [&](auto stage_tag) {
+        constexpr int S = decltype(stage_tag)::value;
+        if (issued < total) issue((S + 2) % SK_STAGES);
+        const int newer = issued - done - 1;  // units issued after the one consumed now (0..2)
+        if (newer >= 2) sk_wait_vm<2 * D>();
+        else if (newer == 1) sk_wait_vm<D>();
+        else sk_wait_vm<0>();
+        v4i wf[2], xf[MT][2];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) red[wave][mt][lane] = acc[mt];
-    __syncthreads();
-    if (wave < MT) {
-        const int mt = wave;
-        v4i s = red[0][mt][lane];
+        for (int h = 0; h < 2; ++h) {
+            wf[h] = *(const __attribute__((address_space(3))) v4i *)(uintptr_t)(faddr[S][h]);
 #pragma unroll
-        for (int v = 1; v < WPB; ++v) s += red[v][mt][lane];
-        const int64_t m = mt * 16 + r, n = n0 + 4 * g;
-        if (m < M && n < N) {
-            const float sr = Epi::kHasRow ? epi.row(m) : 1.0f;
-            v4f sc = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
-            epi.cols(n, N, sc, bb);
-            epi.store4(m, n, s, sr, sc, bb, N);
+            for (int mt = 0; mt < MT; ++mt) xf[mt][h] = *(const __attribute__((address_space(3))) v4i *)(uintptr_t)(faddr[S][h] + (1 + mt) * 2048);
         }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[h], xf[mt][h], acc[mt], 0, 0, 0);
+        ++done;
+        if (++c_u == upt) {
+            c_u = 0;
+            tile_end();
+        }
+    };
+
+    if (upt == 0) {  // more waves than K units: this wave only takes part in the reductions
+        for (int t = 0; t < my_tiles; ++t) tile_end();
+        return;
+    }
+    issue(0);
+    if (total > 1) issue(1);
+    while (true) {
+        step(std::integral_constant<int, 0>{});
+        if (done >= total) break;
+        step(std::integral_constant<int, 1>{});
+        if (done >= total) break;
+        step(std::integral_constant<int, 2>{});
+        if (done >= total) break;
     }
 }
 
