@@ -26,6 +26,8 @@
 #include "asq_common.h"
 #include <string.h>
 #include <type_traits>
+#include <mutex>
+#include <unordered_map>
 
 namespace asq {
 
@@ -387,6 +389,23 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 
 namespace asq {
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, size) instead of once per launch
+static inline hipError_t ensure_dynamic_lds(const void *kfn, int bytes)
+{
+    static std::mutex mu;
+    static std::unordered_map<uintptr_t, int> done;  // key: kernel address ^ (device << 56): the attribute is per device
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uintptr_t key = (uintptr_t)kfn ^ ((uintptr_t)(dev + 1) << 56);
+    std::lock_guard<std::mutex> g(mu);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done[key] = bytes;
+    return e;
+}
+
 // ---------------------------------------------------------------------------------
 // split-K tail: sum S int32 slabs [S][M][N] (exact, order-free) and run the fused epilogue.
 // One thread per 4 consecutive channels of one token; N % 4 == 0 (enforced by the launcher).
@@ -468,7 +487,7 @@ template <class Epi, int MT> int launch_skinny_mt(const int8_t *x, const int8_t 
     if (grid > ntiles) grid = ntiles;
     const size_t lds = (size_t)(wpb * perwave);
     auto kfn = gemm_i8_skinny<Epi, MT>;
-    hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds((const void *)kfn, (int)lds);
     if (e != hipSuccess) {
         asq_set_error("skinny: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return (int)e;
@@ -498,7 +517,7 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
         const int64_t tn = (N + 255) / 256, tiles = (M / 256 + ngroups) * tn;
         ASQ_REQUIRE(tiles < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
         auto kfn = gemm_i8_p8<Epi>;
-        hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES);
+        hipError_t e = ensure_dynamic_lds((const void *)kfn, P8_LDS_BYTES);
         if (e != hipSuccess) {
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
             return (int)e;
@@ -517,7 +536,7 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
             // pass 1: int32 partial slabs; pass 2: reduce + the caller's epilogue
             EpiI32 slab{(int32_t *)ws, N, true};
             auto kfn = gemm_i8_p8<EpiI32>;
-            hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES);
+            hipError_t e = ensure_dynamic_lds((const void *)kfn, P8_LDS_BYTES);
             if (e != hipSuccess) {
                 asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
                 return (int)e;
@@ -529,7 +548,7 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
             return asq_after_launch(s, what);
         }
         auto kfn = gemm_i8_p8<Epi>;
-        hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES);
+        hipError_t e = ensure_dynamic_lds((const void *)kfn, P8_LDS_BYTES);
         if (e != hipSuccess) {
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
             return (int)e;
