@@ -223,6 +223,139 @@ template <int DT> int quantize_dt(const void *x, int mode, float quant_scale, in
     }
 }
 
+
+// ---------------------------------------------------------------------------------
+// N1: RMSNorm (or LayerNorm) with the SmoothQuant scale folded into its weight, emitting int8
+// directly -- the fused form of reference models/llama.py:27-37 (QuantizedLlamaRMSNorm: weight /
+// input_scale) followed by the per-tensor prologue of the next linears (linear.py:95-96), i.e. the
+// reference's own (dead) LayerNormQ idea, layers/nn/fused.py:10-15.  Arithmetic follows HF's
+// LlamaRMSNorm: var = mean(f32(x)^2); n = dt(f32(x) * rsqrt(var + eps)); y = dt(w * n);
+// xq = int8(clamp(rne(y))) -- or, per-token: s_row = dt(absmax(y)/127), xq = int8(clamp(rne(f32(y)/s_row))).
+// One block per row, the row lives in registers (one HBM read, K bytes written).  The fp32 sum order
+// differs from ATen's reduction, so y can differ from the unfused path in its last place: the int8
+// result equals the two-kernel path except at rounding boundaries (tests: <= 1e-3 of entries, +-1).
+// LAYERNORM additionally subtracts the mean and adds a bias (OPT, reference models/opt.py:20-29).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float *red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();  // red may still be read by the previous reduction
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <int DT> __device__ __forceinline__ void vec_unpack(const v4i &v, float (&f)[ElemT<DT>::VEC])
+{
+    if constexpr (DT == ASQ_F32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = __int_as_float(v[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t w = (uint32_t)v[i];
+            f[2 * i] = ElemT<DT>::load((uint16_t)(w & 0xFFFF));
+            f[2 * i + 1] = ElemT<DT>::load((uint16_t)(w >> 16));
+        }
+    }
+}
+
+template <int DT, int NV, bool LAYERNORM, bool PER_TOKEN>
+__global__ void __launch_bounds__(256) norm_quant_cached(const void *__restrict__ xv, const void *__restrict__ wv, const void *__restrict__ bv, float eps,
+                                                         int8_t *__restrict__ xq, float *__restrict__ s_row, int K)
+{
+    constexpr int VEC = ElemT<DT>::VEC;
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const char *xrow = (const char *)xv + row * (int64_t)K * (16 / VEC);
+    const int nvec = K / VEC;
+    float f[NV][VEC];
+    float sum = 0.f, sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = i * 256 + threadIdx.x;
+        if (idx < nvec) {
+            vec_unpack<DT>(*(const v4i *)(xrow + (int64_t)idx * 16), f[i]);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                sum += f[i][j];
+                sq += f[i][j] * f[i][j];
+            }
+        }
+    }
+    float mean = 0.f;
+    if constexpr (LAYERNORM) {
+        mean = block_sum_256(sum, red) / (float)K;
+        sq = 0.f;  // two-pass variance, as ATen's layer_norm
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (i * 256 + threadIdx.x < nvec)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) sq += (f[i][j] - mean) * (f[i][j] - mean);
+    }
+    const float var = block_sum_256(sq, red) / (float)K;
+    const float rs = rsqrtf(var + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = i * 256 + threadIdx.x;
+        if (idx < nvec) {
+            float wf[VEC], bf[VEC];
+            vec_unpack<DT>(*(const v4i *)((const char *)wv + (int64_t)idx * 16), wf);
+            if constexpr (LAYERNORM) vec_unpack<DT>(*(const v4i *)((const char *)bv + (int64_t)idx * 16), bf);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float y;
+                if constexpr (LAYERNORM) {
+                    y = ElemT<DT>::round(__fadd_rn(__fmul_rn(__fmul_rn(f[i][j] - mean, rs), wf[j]), bf[j]));
+                } else {
+                    const float n = ElemT<DT>::round(__fmul_rn(f[i][j], rs));  // hidden_states.to(input_dtype)
+                    y = ElemT<DT>::round(__fmul_rn(wf[j], n));                 // self.weight * ...
+                }
+                f[i][j] = y;
+                if constexpr (PER_TOKEN) amax = nanmax(amax, fabsf(y));
+            }
+        }
+    }
+    float qs = 1.0f;
+    if constexpr (PER_TOKEN) {
+        __syncthreads();
+        amax = block_max_256(amax, red);
+        qs = ElemT<DT>::round(amax / 127.0f);
+        if (threadIdx.x == 0) s_row[row] = qs;
+    }
+    int8_t *orow = xq + row * (int64_t)K;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = i * 256 + threadIdx.x;
+        if (idx < nvec) {
+            int q[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) q[j] = PER_TOKEN ? quant_i8(f[i][j] / qs) : quant_i8(f[i][j]);
+            if constexpr (DT == ASQ_F32) {
+                *(uint32_t *)(orow + (int64_t)idx * 4) = pack4(q[0], q[1], q[2], q[3]);
+            } else {
+                *(uint2 *)(orow + (int64_t)idx * 8) = make_uint2(pack4(q[0], q[1], q[2], q[3]), pack4(q[4], q[5], q[6], q[7]));
+            }
+        }
+    }
+}
+
+template <int DT, bool LN, bool PT>
+int launch_norm_quant(const void *x, const void *w, const void *b, float eps, int8_t *xq, float *s_row, int64_t M, int64_t K, hipStream_t s)
+{
+    constexpr int VEC = ElemT<DT>::VEC;
+    const int64_t nvec = K / VEC;
+    dim3 grid((unsigned)M), block(256);
+#define ASQ_NQ(NV) hipLaunchKernelGGL((norm_quant_cached<DT, NV, LN, PT>), grid, block, 0, s, x, w, b, eps, xq, s_row, (int)K)
+    if (nvec <= 256 * 1) ASQ_NQ(1);
+    else if (nvec <= 256 * 2) ASQ_NQ(2);
+    else if (nvec <= 256 * 4) ASQ_NQ(4);
+    else ASQ_NQ(8);
+#undef ASQ_NQ
+    return asq_after_launch(s, "asq_norm_quantize");
+}
 }  // namespace asq
 using namespace asq;
 
@@ -243,4 +376,29 @@ extern "C" int asq_quantize_act(const void *x, int x_dtype, int mode, float quan
     case ASQ_F16: return quantize_dt<ASQ_F16>(x, mode, quant_scale, xq, s_row, M, K, s);
     default: return quantize_dt<ASQ_BF16>(x, mode, quant_scale, xq, s_row, M, K, s);
     }
+}
+
+extern "C" int asq_norm_quantize(const void *x, int x_dtype, const void *weight, const void *bias, float eps, int per_token, int8_t *xq,
+                                 float *s_row, int64_t M, int64_t K, void *stream)
+{
+    ASQ_REQUIRE(M >= 0 && K > 0 && M < (1ll << 31), ASQ_ERR_DIM, "asq_norm_quantize: bad dims");
+    ASQ_REQUIRE(x_dtype == ASQ_F32 || x_dtype == ASQ_F16 || x_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_norm_quantize: bad x_dtype %d", x_dtype);
+    if (M == 0) return ASQ_OK;
+    ASQ_REQUIRE(x && weight && xq && (!per_token || s_row), ASQ_ERR_NULL, "asq_norm_quantize: NULL pointer");
+    const int vec = x_dtype == ASQ_F32 ? 4 : 8;
+    ASQ_REQUIRE(K % vec == 0 && K / vec <= 256 * 8, ASQ_ERR_DIM, "asq_norm_quantize: K must be a multiple of %d and <= %d", vec, 256 * 8 * vec);
+    ASQ_REQUIRE(((((uintptr_t)x | (uintptr_t)weight | (uintptr_t)bias) & 15) == 0) && (((uintptr_t)xq & (vec - 1)) == 0), ASQ_ERR_ALIGN,
+                "asq_norm_quantize: x / weight / bias must be 16-B aligned");
+    hipStream_t s = (hipStream_t)stream;
+#define ASQ_NQD(DT_)                                                                                                           \
+    (bias ? (per_token ? launch_norm_quant<DT_, true, true>(x, weight, bias, eps, xq, s_row, M, K, s)                          \
+                       : launch_norm_quant<DT_, true, false>(x, weight, bias, eps, xq, s_row, M, K, s))                         \
+          : (per_token ? launch_norm_quant<DT_, false, true>(x, weight, bias, eps, xq, s_row, M, K, s)                         \
+                       : launch_norm_quant<DT_, false, false>(x, weight, bias, eps, xq, s_row, M, K, s)))
+    switch (x_dtype) {
+    case ASQ_F32: return ASQ_NQD(ASQ_F32);
+    case ASQ_F16: return ASQ_NQD(ASQ_F16);
+    default: return ASQ_NQD(ASQ_BF16);
+    }
+#undef ASQ_NQD
 }

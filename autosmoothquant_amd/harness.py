@@ -59,7 +59,7 @@ class LlamaLayer(torch.nn.Module):
 
     def attention(self, h, record=None):
         B, S, _ = h.shape
-        x = self.input_layernorm(h)
+        x = self.input_layernorm(h)   # a float tensor, or a QuantizedActivation when the norm is fused (N1)
         if record is not None:
             record["attn_in"] = x
         q = self.q_proj(x).view(B, S, self.heads, self.hd).transpose(1, 2)
@@ -107,7 +107,7 @@ def calibrate(layer, h):
 
 
 @torch.no_grad()
-def to_w8a8(layer, scales, quant_config=None):
+def to_w8a8(layer, scales, quant_config=None, fuse_norm=False):
     """Quantised copy of `layer`, composed exactly like the reference's
     QuantizedLlamaDecoderLayer.from_float_to_int8 (models/llama.py:289-339):
       q/k/v, gate/up : W8A8BFP32OFP32Linear(act_quant = cfg["qkv"] / cfg["fc1"]), norm weight folded iff per-tensor
@@ -131,6 +131,11 @@ def to_w8a8(layer, scales, quant_config=None):
     q.gate_proj = conv(layer.gate_proj, W8A8BFP32OFP32Linear, scales["mlp_in"], cfg["fc1"])
     q.up_proj = conv(layer.up_proj, W8A8BFP32OFP32Linear, scales["mlp_in"], cfg["fc1"])
     q.down_proj = conv(layer.down_proj, W8A8BFP32OFP32LinearWithQuantScale, scales["down_in"], cfg["fc2"])
+    if fuse_norm:  # the norms emit int8 directly; q/k/v and gate/up share one quantised activation
+        from .layers.nn.fused import RMSNormQ
+        q.input_layernorm = RMSNormQ.from_float(layer.input_layernorm, scales["attn_in"], per_token=cfg["qkv"] == "per-token")
+        q.post_attention_layernorm = RMSNormQ.from_float(layer.post_attention_layernorm, scales["mlp_in"], per_token=cfg["fc1"] == "per-token")
+        return q
     q.input_layernorm = layer.input_layernorm.folded(scales["attn_in"]) if cfg["qkv"] == "per-tensor" else layer.input_layernorm
     q.post_attention_layernorm = layer.post_attention_layernorm.folded(scales["mlp_in"]) if cfg["fc1"] == "per-tensor" else layer.post_attention_layernorm
     return q

@@ -1,0 +1,78 @@
+"""Norm -> int8 fusion: the built counterpart of the reference's ``LayerNormQ``
+(reference autosmoothquant/layers/nn/fused.py:10-15, which imports native symbols its extension
+never exported) and of the scale-folded norms ``QuantizedLlamaRMSNorm`` / ``Int8OPTLayerNorm``
+(reference models/llama.py:27-37, models/opt.py:20-29).
+
+``RMSNormQ`` / ``LayerNormQ`` return a :class:`QuantizedActivation` (int8 tensor [+ per-token scales])
+that the W8A8 linears accept in place of a floating tensor, so the q/k/v (or gate/up) projections
+share ONE quantised activation and the fp16 norm output never touches HBM."""
+import torch
+
+from ... import ops
+
+
+class QuantizedActivation:
+    """int8 activation [.., K] (+ per-token scales) produced by a fused norm; `out_dtype` is the
+    floating dtype the consuming linear should emit (the dtype of the norm's input)."""
+    __slots__ = ("xq", "s_row", "out_dtype", "lead")
+
+    def __init__(self, xq, s_row, out_dtype, lead):
+        self.xq, self.s_row, self.out_dtype, self.lead = xq, s_row, out_dtype, lead
+
+    @property
+    def shape(self):
+        return (*self.lead, self.xq.shape[-1])
+
+
+class _NormQ(torch.nn.Module):
+    def __init__(self, dim, eps, per_token, with_bias):
+        super().__init__()
+        self.eps, self.per_token = eps, per_token
+        self.register_buffer("weight", torch.ones(dim))
+        if with_bias:
+            self.register_buffer("bias", torch.zeros(dim))
+        else:
+            self.bias = None
+
+    @torch.no_grad()
+    def forward(self, x):
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        w = self.weight if self.weight.dtype == x.dtype else self.weight.to(x.dtype)
+        b = None if self.bias is None else (self.bias if self.bias.dtype == x.dtype else self.bias.to(x.dtype))
+        xq, s_row = ops.norm_quantize(x2, w, b, self.eps, self.per_token)
+        return QuantizedActivation(xq, s_row, x.dtype, lead)
+
+
+class RMSNormQ(_NormQ):
+    """RMSNorm with weight / input_scale, emitting int8 (per-tensor) or int8 + row scales (per-token)."""
+
+    def __init__(self, dim, eps=1e-5, per_token=False):
+        super().__init__(dim, eps, per_token, with_bias=False)
+
+    @staticmethod
+    def from_float(norm, input_scale=1.0, per_token=False):
+        """`norm` has .weight and .eps / .variance_epsilon.  per-tensor: weight / input_scale (reference
+        models/llama.py:27-37); per-token: weight unchanged (reference :326-339 folds only for per-tensor)."""
+        eps = getattr(norm, "variance_epsilon", getattr(norm, "eps", 1e-5))
+        q = RMSNormQ(norm.weight.numel(), eps, per_token)
+        w = norm.weight.detach()
+        q.weight = (w if per_token else w / input_scale).clone()
+        return q.to(w.device)
+
+
+class LayerNormQ(_NormQ):
+    """LayerNorm with weight and bias / output_scale emitting int8 (the reference's LayerNormQ, fused.py:10-32)."""
+
+    def __init__(self, dim, eps=1e-5, per_token=False):
+        super().__init__(dim, eps, per_token, with_bias=True)
+
+    @staticmethod
+    def from_float(module: torch.nn.LayerNorm, output_scale: float, per_token=False):
+        assert module.normalized_shape[0] == module.weight.numel() == module.bias.numel()
+        q = LayerNormQ(module.normalized_shape[0], module.eps, per_token)
+        s = 1.0 if per_token else output_scale
+        q.weight = (module.weight.detach() / s).clone()
+        q.bias = (module.bias.detach() / s).clone()
+        return q.to(module.weight.device)

@@ -21,6 +21,7 @@ from .. import functional as _F  # noqa: F401  (package marker)
 from ..functional.quantization import quantize_per_tensor_absmax
 from ... import ops
 from ..._CUDA import I8CUGEMM
+from .fused import QuantizedActivation
 
 _ACT_QUANT = ("per-token", "per-tensor")
 
@@ -107,6 +108,17 @@ class _W8A8Base(torch.nn.Module):
         return self.bias
 
 
+def _prequantized_forward(mod, qa, s_scalar, s_col):
+    """Forward on an activation already quantised by a fused norm (layers/nn/fused.py): no prologue launch."""
+    per_token = mod.act_quant == "per-token"
+    if per_token != (qa.s_row is not None):
+        raise ValueError(f"{type(mod).__name__}(act_quant={mod.act_quant!r}) got a {'per-token' if qa.s_row is not None else 'per-tensor'} QuantizedActivation")
+    if qa.xq.shape[-1] != mod.in_features:
+        raise ValueError(f"expected last dim {mod.in_features}, got {tuple(qa.shape)}")
+    out = ops.linear_w8a8(qa.xq, mod.weight, qa.out_dtype, s_scalar, qa.s_row, s_col, mod._bias_on(qa.xq.device))
+    return out.view(*qa.lead, mod.out_features)
+
+
 class W8A8BFP32OFP32Linear(_W8A8Base):
     """int8 weight, int8 activation, fp32 bias, output in the input's dtype.
     per-tensor: the input is already in int8 units (1/input_scale folded into the preceding
@@ -115,6 +127,8 @@ class W8A8BFP32OFP32Linear(_W8A8Base):
 
     @torch.no_grad()
     def forward(self, x):
+        if isinstance(x, QuantizedActivation):
+            return _prequantized_forward(self, x, self._scalar("dequant_scale"), None)
         lead = x.shape[:-1]
         mode = "per-token" if self.act_quant == "per-token" else "per-tensor-round"
         out = ops.linear_w8a8_forward(self._flatten(x), self.weight, mode, 1.0, self._scalar("dequant_scale"),
@@ -159,6 +173,8 @@ class W8A8BFP32OFP32QKVLinear(_W8A8Base):
 
     @torch.no_grad()
     def forward(self, x):
+        if isinstance(x, QuantizedActivation):
+            return _prequantized_forward(self, x, 1.0, self._scale_vector(x.xq.device))
         lead = x.shape[:-1]
         mode = "per-token" if self.act_quant == "per-token" else "per-tensor-round"
         out = ops.linear_w8a8_forward(self._flatten(x), self.weight, mode, 1.0, 1.0, self._scale_vector(x.device),

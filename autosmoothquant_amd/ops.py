@@ -92,6 +92,25 @@ def quantize_act(x, mode, quant_scale=1.0):
     return xq, s_row
 
 
+def norm_quantize(x, weight, bias=None, eps=1e-5, per_token=False):
+    """Fused (scale-folded) RMSNorm / LayerNorm -> int8 activation.  x [M,K]; weight (and bias for
+    LayerNorm) [K] in x's dtype.  Returns (xq int8 [M,K], s_row f32 [M] or None)."""
+    _dev(x, "x"), _dev(weight, "weight")
+    if x.dtype not in _DT or x.dim() != 2 or weight.dtype != x.dtype or weight.numel() != x.shape[1]:
+        raise ValueError("x must be 2-D float and weight a [K] tensor of the same dtype")
+    if bias is not None:
+        _dev(bias, "bias")
+        if bias.dtype != x.dtype or bias.numel() != x.shape[1]:
+            raise ValueError("bias must match weight")
+    M, K = x.shape
+    xq = torch.empty((M, K), dtype=torch.int8, device=x.device)
+    s_row = torch.empty((M,), dtype=torch.float32, device=x.device) if per_token else None
+    with torch.cuda.device(x.device):
+        L.check(L.lib().asq_norm_quantize(x.data_ptr(), _DT[x.dtype], weight.data_ptr(), _ptr(bias), float(eps), 1 if per_token else 0,
+                                          xq.data_ptr(), _ptr(s_row), M, K, _stream(x)), "asq_norm_quantize")
+    return xq, s_row
+
+
 def linear_w8a8(xq, w, out_dtype, s_scalar=1.0, s_row=None, s_col=None, bias=None, order="scale_first", out=None):
     """Fused GEMM + dequant/bias epilogue: out[M,N] = (s_col|s_scalar)[*s_row] * f32(xq.w^T) + bias."""
     _dev(xq, "xq"), _dev(w, "weight")

@@ -94,6 +94,16 @@ int asq_gemm_i8_i8(const int8_t *x, const int8_t *w, int8_t *out,
 int asq_quantize_act(const void *x, int x_dtype, int mode, float quant_scale,
                      int8_t *xq, float *s_row, int64_t M, int64_t K, void *stream);
 
+/* ---- N1: norm -> int8 fusion.  RMSNorm (bias == NULL; HF LlamaRMSNorm arithmetic) or LayerNorm
+ * (bias != NULL; OPT) whose weight (and bias) already carry 1/input_scale (reference models/llama.py:27-37,
+ * models/opt.py:20-29), fused with the activation quantiser of the linears that consume it -- the reference's
+ * own unbuilt LayerNormQ (layers/nn/fused.py:10-15).  x, weight, bias share x_dtype; K <= 8192 (16-bit) / 4096 (f32).
+ * per_token = 0: xq = int8(clamp(rne(y)));  1: s_row[m] = absmax(y)/127 (in x_dtype), xq = int8(clamp(rne(y / s_row))).
+ * Equal to "norm in PyTorch, then asq_quantize_act" except where the fp32 reduction order moves y across a
+ * rounding boundary (a +-1 difference in < 1e-3 of the entries). */
+int asq_norm_quantize(const void *x, int x_dtype, const void *weight, const void *bias, float eps, int per_token,
+                      int8_t *xq, float *s_row, int64_t M, int64_t K, void *stream);
+
 /* ---- fused GEMM + dequant/bias epilogue (replaces the i32 round trip of linear.py:97-105;
  * subsumes csrc/kernels/linear.cu:201-291 `linear_a8_w8_bfp32_ofp32`)
  * out[M,N] (out_dtype) = epi(acc[m,n]) where acc = xq . w^T (int32, exact)
