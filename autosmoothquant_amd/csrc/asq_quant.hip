@@ -356,6 +356,79 @@ int launch_norm_quant(const void *x, const void *w, const void *b, float eps, in
 #undef ASQ_NQ
     return asq_after_launch(s, "asq_norm_quantize");
 }
+
+// ---------------------------------------------------------------------------------
+// SiLU(gate) * up -> int8: the activation between gate/up and down_proj (LLaMA / Mixtral MLP) fused with
+// down_proj's quantiser (W8A8BFP32OFP32LinearWithQuantScale: per-token, or per-tensor x / quant_scale,
+// reference linear.py:283-292).  a = dt(dt(g / (1 + exp(-g))) * u) as the two ATen ops compute it; the
+// [M, K] fp16 product never reaches HBM (reads 2 x s_in, writes 1 B per element instead of
+// reading 3 x and writing s_in + 1).  exp() differs in the last ulp between libraries, so -- like the
+// norm fusion -- the int8 result can differ by +-1 at rounding boundaries.
+// ---------------------------------------------------------------------------------
+template <int DT, int NV, bool PER_TOKEN>
+__global__ void __launch_bounds__(256) silu_mul_quant_cached(const void *__restrict__ gv, const void *__restrict__ uv, float quant_scale,
+                                                             int8_t *__restrict__ xq, float *__restrict__ s_row, int K)
+{
+    constexpr int VEC = ElemT<DT>::VEC;
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const char *grow = (const char *)gv + row * (int64_t)K * (16 / VEC);
+    const char *urow = (const char *)uv + row * (int64_t)K * (16 / VEC);
+    const int nvec = K / VEC;
+    float a[NV][VEC];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = i * 256 + threadIdx.x;
+        if (idx < nvec) {
+            float g[VEC], u[VEC];
+            vec_unpack<DT>(*(const v4i *)(grow + (int64_t)idx * 16), g);
+            vec_unpack<DT>(*(const v4i *)(urow + (int64_t)idx * 16), u);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float sl = ElemT<DT>::round(g[j] / (1.0f + expf(-g[j])));
+                a[i][j] = ElemT<DT>::round(__fmul_rn(sl, u[j]));
+                amax = nanmax(amax, fabsf(a[i][j]));
+            }
+        }
+    }
+    float qs = quant_scale;
+    if constexpr (PER_TOKEN) {
+        amax = block_max_256(amax, red);
+        qs = ElemT<DT>::round(amax / 127.0f);
+        if (threadIdx.x == 0) s_row[row] = qs;
+    }
+    int8_t *orow = xq + row * (int64_t)K;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = i * 256 + threadIdx.x;
+        if (idx < nvec) {
+            int q[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) q[j] = PER_TOKEN ? quant_i8(a[i][j] / qs) : quant_i8(ElemT<DT>::round(a[i][j] / qs));
+            if constexpr (DT == ASQ_F32) {
+                *(uint32_t *)(orow + (int64_t)idx * 4) = pack4(q[0], q[1], q[2], q[3]);
+            } else {
+                *(uint2 *)(orow + (int64_t)idx * 8) = make_uint2(pack4(q[0], q[1], q[2], q[3]), pack4(q[4], q[5], q[6], q[7]));
+            }
+        }
+    }
+}
+
+template <int DT, bool PT>
+int launch_silu_mul_quant(const void *g, const void *u, float qs, int8_t *xq, float *s_row, int64_t M, int64_t K, hipStream_t s)
+{
+    constexpr int VEC = ElemT<DT>::VEC;
+    const int64_t nvec = K / VEC;
+    dim3 grid((unsigned)M), block(256);
+#define ASQ_SM(NV) hipLaunchKernelGGL((silu_mul_quant_cached<DT, NV, PT>), grid, block, 0, s, g, u, qs, xq, s_row, (int)K)
+    if (nvec <= 256 * 2) ASQ_SM(2);
+    else if (nvec <= 256 * 4) ASQ_SM(4);
+    else if (nvec <= 256 * 6) ASQ_SM(6);
+    else ASQ_SM(8);
+#undef ASQ_SM
+    return asq_after_launch(s, "asq_silu_mul_quantize");
+}
 }  // namespace asq
 using namespace asq;
 
@@ -401,4 +474,25 @@ extern "C" int asq_norm_quantize(const void *x, int x_dtype, const void *weight,
     default: return ASQ_NQD(ASQ_BF16);
     }
 #undef ASQ_NQD
+}
+
+extern "C" int asq_silu_mul_quantize(const void *gate, const void *up, int x_dtype, int per_token, float quant_scale, int8_t *xq, float *s_row,
+                                     int64_t M, int64_t K, void *stream)
+{
+    ASQ_REQUIRE(M >= 0 && K > 0 && M < (1ll << 31), ASQ_ERR_DIM, "asq_silu_mul_quantize: bad dims");
+    ASQ_REQUIRE(x_dtype == ASQ_F32 || x_dtype == ASQ_F16 || x_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_silu_mul_quantize: bad x_dtype %d", x_dtype);
+    if (M == 0) return ASQ_OK;
+    ASQ_REQUIRE(gate && up && xq && (!per_token || s_row), ASQ_ERR_NULL, "asq_silu_mul_quantize: NULL pointer");
+    const int vec = x_dtype == ASQ_F32 ? 4 : 8;
+    ASQ_REQUIRE(K % vec == 0 && K / vec <= 256 * 8, ASQ_ERR_DIM, "asq_silu_mul_quantize: K must be a multiple of %d and <= %d", vec, 256 * 8 * vec);
+    ASQ_REQUIRE(((((uintptr_t)gate | (uintptr_t)up) & 15) == 0) && (((uintptr_t)xq & (vec - 1)) == 0), ASQ_ERR_ALIGN,
+                "asq_silu_mul_quantize: gate / up must be 16-B aligned");
+    hipStream_t s = (hipStream_t)stream;
+#define ASQ_SMD(DT_) (per_token ? launch_silu_mul_quant<DT_, true>(gate, up, quant_scale, xq, s_row, M, K, s) : launch_silu_mul_quant<DT_, false>(gate, up, quant_scale, xq, s_row, M, K, s))
+    switch (x_dtype) {
+    case ASQ_F32: return ASQ_SMD(ASQ_F32);
+    case ASQ_F16: return ASQ_SMD(ASQ_F16);
+    default: return ASQ_SMD(ASQ_BF16);
+    }
+#undef ASQ_SMD
 }

@@ -79,6 +79,9 @@ class LlamaLayer(torch.nn.Module):
         x = self.post_attention_layernorm(h)
         if record is not None:
             record["mlp_in"] = x
+        if getattr(self, "fuse_act", False):  # SiLU * up quantised in one pass; the fp product never reaches HBM
+            from .layers.nn.fused import silu_mul_q
+            return h + self.down_proj(silu_mul_q(self.gate_proj(x), self.up_proj(x), self.down_proj))
         g = F.silu(self.gate_proj(x)) * self.up_proj(x)
         if record is not None:
             record["down_in"] = g
@@ -135,6 +138,7 @@ def to_w8a8(layer, scales, quant_config=None, fuse_norm=False):
         from .layers.nn.fused import RMSNormQ
         q.input_layernorm = RMSNormQ.from_float(layer.input_layernorm, scales["attn_in"], per_token=cfg["qkv"] == "per-token")
         q.post_attention_layernorm = RMSNormQ.from_float(layer.post_attention_layernorm, scales["mlp_in"], per_token=cfg["fc1"] == "per-token")
+        q.fuse_act = True
         return q
     q.input_layernorm = layer.input_layernorm.folded(scales["attn_in"]) if cfg["qkv"] == "per-tensor" else layer.input_layernorm
     q.post_attention_layernorm = layer.post_attention_layernorm.folded(scales["mlp_in"]) if cfg["fc1"] == "per-tensor" else layer.post_attention_layernorm

@@ -213,6 +213,8 @@ class W8A8BFP32OFP32LinearWithQuantScale(_W8A8Base):
 
     @torch.no_grad()
     def forward(self, x):
+        if isinstance(x, QuantizedActivation):  # already quantised for this module (fused.silu_mul_q)
+            return _prequantized_forward(self, x, self._scalar("dequant_scale"), None)
         lead = x.shape[:-1]
         if self.act_quant == "per-token":
             mode, qs = "per-token", 1.0

@@ -111,6 +111,20 @@ def norm_quantize(x, weight, bias=None, eps=1e-5, per_token=False):
     return xq, s_row
 
 
+def silu_mul_quantize(gate, up, per_token=True, quant_scale=1.0):
+    """int8(quantise(silu(gate) * up)) in one pass; returns (xq int8 [M,K], s_row f32 [M] or None)."""
+    _dev(gate, "gate"), _dev(up, "up")
+    if gate.dtype not in _DT or gate.dim() != 2 or up.dtype != gate.dtype or up.shape != gate.shape:
+        raise ValueError("gate and up must be 2-D float tensors of equal shape and dtype")
+    M, K = gate.shape
+    xq = torch.empty((M, K), dtype=torch.int8, device=gate.device)
+    s_row = torch.empty((M,), dtype=torch.float32, device=gate.device) if per_token else None
+    with torch.cuda.device(gate.device):
+        L.check(L.lib().asq_silu_mul_quantize(gate.data_ptr(), up.data_ptr(), _DT[gate.dtype], 1 if per_token else 0, float(quant_scale),
+                                              xq.data_ptr(), _ptr(s_row), M, K, _stream(gate)), "asq_silu_mul_quantize")
+    return xq, s_row
+
+
 def linear_w8a8(xq, w, out_dtype, s_scalar=1.0, s_row=None, s_col=None, bias=None, order="scale_first", out=None):
     """Fused GEMM + dequant/bias epilogue: out[M,N] = (s_col|s_scalar)[*s_row] * f32(xq.w^T) + bias."""
     _dev(xq, "xq"), _dev(w, "weight")

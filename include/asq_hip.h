@@ -104,6 +104,12 @@ int asq_quantize_act(const void *x, int x_dtype, int mode, float quant_scale,
 int asq_norm_quantize(const void *x, int x_dtype, const void *weight, const void *bias, float eps, int per_token,
                       int8_t *xq, float *s_row, int64_t M, int64_t K, void *stream);
 
+/* SiLU(gate) * up fused with the quantiser of the linear that consumes it (LLaMA / Mixtral down_proj / w2,
+ * a W8A8BFP32OFP32LinearWithQuantScale): per_token = 1 -> dynamic row scales (linear.py:283-287),
+ * per_token = 0 -> x / quant_scale in x_dtype (linear.py:289-292).  gate, up [M,K] of x_dtype; K <= 16384 (16-bit). */
+int asq_silu_mul_quantize(const void *gate, const void *up, int x_dtype, int per_token, float quant_scale,
+                          int8_t *xq, float *s_row, int64_t M, int64_t K, void *stream);
+
 /* ---- fused GEMM + dequant/bias epilogue (replaces the i32 round trip of linear.py:97-105;
  * subsumes csrc/kernels/linear.cu:201-291 `linear_a8_w8_bfp32_ofp32`)
  * out[M,N] (out_dtype) = epi(acc[m,n]) where acc = xq . w^T (int32, exact)

@@ -86,3 +86,21 @@ def test_fused_norm_layer_close_to_unfused_layer():
             b = harness.to_w8a8(layer, scales, cfg, fuse_norm=True)(h)
         err = ((a - h).float() - (b - h).float()).norm() / (a - h).float().norm()
         assert torch.isfinite(b).all() and err < 2e-2, float(err)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("per_token", [True, False])
+def test_silu_mul_quant_matches_two_step_path(dt, per_token):
+    from autosmoothquant_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    M, K = 200, 11008 if dt != torch.float32 else 4096
+    g = (torch.randn(M, K, device=dev) * 2).to(dt)
+    u = (torch.randn(M, K, device=dev) * 2).to(dt)
+    a = (torch.nn.functional.silu(g) * u).contiguous()
+    rq, rs = ops.quantize_act(a, "per-token" if per_token else "per-tensor-div", 0.05)
+    xq, s_row = ops.silu_mul_quantize(g, u, per_token, 0.05)
+    diff = (xq.int() - rq.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) < 2e-3
+    if per_token:
+        assert torch.allclose(s_row, rs, rtol=4e-3)
