@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(256) splitk_reduce(const int32_t *__restrict__
 // ---------------------------------------------------------------------------------
 enum GemmKernel { KERN_GENERIC = 0, KERN_SKINNY = 1, KERN_P8 = 2 };
 
-int forced_kernel();  // env ASQ_GEMM_KERNEL=generic|p8 (development / A-B aid), asq_gemm.hip
+int forced_kernel();  // env ASQ_GEMM_KERNEL=generic|skinny|p8 (development / A-B aid), asq_gemm.hip
 
 static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, int64_t N, int64_t K)
 {
@@ -440,8 +440,15 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
     const int f = forced_kernel();
     if (f == KERN_GENERIC) return KERN_GENERIC;
     if (tiled_ok && f == KERN_P8) return KERN_P8;
-    if (tiled_ok && M <= 64 && (f == KERN_SKINNY || f < 0)) return KERN_SKINNY;
-    if (tiled_ok && M > 64 && f < 0) return KERN_P8;
+    if (tiled_ok && M <= 1024 && f == KERN_SKINNY) return KERN_SKINNY;
+    if (tiled_ok && f < 0) {
+        // measured crossover (tools/kbench.py grid, 16..512 rows x 9 LLaMA/OPT weight shapes): the
+        // weight-streaming kernel re-reads X from L2 once per 16 channels, so it wins while the
+        // (channel tile, 64-row block) items all fit on the chip at once and the total work is small
+        const int64_t items = ((N + 15) / 16) * ((M + 63) / 64);
+        const double work = (double)N * (double)K * (double)M;
+        return ((M <= 64 || items <= 1024) && work <= 5.5e9) ? KERN_SKINNY : KERN_P8;
+    }
     return KERN_GENERIC;
 }
 
@@ -471,20 +478,21 @@ static inline int pick_ksplit(int64_t tiles, int64_t K, int64_t M, int64_t N, si
     return s < 1 ? 1 : (int)s;
 }
 
-template <class Epi, int MT> int launch_skinny_mt(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, const Epi &epi, hipStream_t s)
+template <class Epi, int MT> int launch_skinny_mt(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, int mblocks, const Epi &epi, hipStream_t s)
 {
     constexpr int64_t LDS_CU = 160 * 1024;
     const int64_t ntiles = (N + 15) / 16;
+    const int64_t nitems = ((ntiles + 7) / 8) * 8 * mblocks;  // tiles padded to groups of 8 so m-blocks of a tile share an XCD
     const int64_t perwave = SK_STAGES * (1 + MT) * 2048 + MT * 1024;  // DMA ring + reduction slot
-    // the most waves per block (K parallelism inside a channel tile) that still gives EVERY tile a resident block
+    // the most waves per block (K parallelism inside a work item) that still gives EVERY item a resident block
     int wpb = 8;
-    while (wpb > 1 && 256 * (LDS_CU / (wpb * perwave)) < ntiles) wpb >>= 1;
-    while (wpb > 1 && wpb * perwave > LDS_CU) wpb >>= 1;
+    while (wpb > 1 && (wpb * perwave > LDS_CU || 256 * (LDS_CU / (wpb * perwave)) < nitems)) wpb >>= 1;
     int64_t per_cu = LDS_CU / (wpb * perwave);
     if (per_cu > 16) per_cu = 16;
     if (per_cu * wpb > 32) per_cu = 32 / wpb;
-    int64_t grid = 256 * per_cu;   // persistent beyond that: blocks walk the tiles grid-stride
-    if (grid > ntiles) grid = ntiles;
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = 256 * per_cu;   // persistent beyond that: blocks walk the items grid-stride
+    if (grid > nitems) grid = nitems;
     const size_t lds = (size_t)(wpb * perwave);
     auto kfn = gemm_i8_skinny<Epi, MT>;
     hipError_t e = ensure_dynamic_lds((const void *)kfn, (int)lds);
@@ -492,17 +500,19 @@ template <class Epi, int MT> int launch_skinny_mt(const int8_t *x, const int8_t 
         asq_set_error("skinny: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return (int)e;
     }
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)(wpb * 64)), lds, s, x, w, M, N, K, wpb, epi);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)(wpb * 64)), lds, s, x, w, M, N, K, wpb, mblocks, epi);
     return ASQ_OK;
 }
 
 template <class Epi> int launch_skinny(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, const Epi &epi, hipStream_t s)
 {
-    switch ((int)((M + 15) / 16)) {
-    case 1: return launch_skinny_mt<Epi, 1>(x, w, M, N, K, epi, s);
-    case 2: return launch_skinny_mt<Epi, 2>(x, w, M, N, K, epi, s);
-    case 3: return launch_skinny_mt<Epi, 3>(x, w, M, N, K, epi, s);
-    default: return launch_skinny_mt<Epi, 4>(x, w, M, N, K, epi, s);
+    const int mblocks = (int)((M + 63) / 64);                       // m-blocks of <= 64 rows, balanced
+    const int mt = (int)(((M + mblocks - 1) / mblocks + 15) / 16);  // 16-row tiles per m-block
+    switch (mt) {
+    case 1: return launch_skinny_mt<Epi, 1>(x, w, M, N, K, mblocks, epi, s);
+    case 2: return launch_skinny_mt<Epi, 2>(x, w, M, N, K, mblocks, epi, s);
+    case 3: return launch_skinny_mt<Epi, 3>(x, w, M, N, K, mblocks, epi, s);
+    default: return launch_skinny_mt<Epi, 4>(x, w, M, N, K, mblocks, epi, s);
     }
 }
 

@@ -1,6 +1,6 @@
-// "skinny": M <= 64 rows (decode / cfg1).  The problem is a weight stream: W [N,K] int8 is read
-// exactly once from HBM (4096x4096 at M=32: 16.8 MB of W vs 0.13 MB of X and 0.26 MB of output)
-// -> the roofline is HBM bandwidth, not MFMA.
+// "skinny": few rows (decode / cfg1 / short prefill).  The problem is a weight stream: W [N,K]
+// int8 is read once (per block of <= 64 rows) from HBM (4096x4096 at M=32: 16.8 MB of W vs 0.13 MB of X
+// and 0.26 MB of output) -> the roofline is HBM / L2 bandwidth, not MFMA.
 //
 // Decomposition: one block of `wpb` waves per 16 output channels (grid-stride over channel tiles);
 // the waves split K in 128-byte units (wave v takes units v, v+wpb, ...).  Each unit is
@@ -19,8 +19,14 @@
 // the first waves run the fused epilogue.  No split-K across blocks, no workspace, no atomics.
 // wpb (8/4/2/1) is chosen by the launcher so that every channel tile has a resident block.
 //
-// Requirements: K % 128 == 0, K <= 2^24, x / w 16-B aligned, M <= 64.  Ragged N, M: rows are clamped
-// for loading and masked at the store.
+// Rows are processed in "m-blocks" of MT*16 <= 64 rows: a work item is (channel tile, m-block); the
+// m-blocks of one channel tile are mapped to the same XCD so the later ones find W in that L2.
+// (Measured: 128-row m-blocks (MT = 8) leave room for only 2 waves per CU and lose to 2 x 64.)
+// Each item re-reads its X rows from L2, so this kernel is L2-bandwidth bound (~10-13 TB/s
+// measured) once M x N grows: the dispatcher (pick_kernel) hands larger problems to the tiled kernel.
+//
+// Requirements: K % 128 == 0, K <= 2^24, x / w 16-B aligned.  Ragged N, M: rows are clamped for loading
+// and masked at the store.
 #pragma once
 #include <type_traits>
 
@@ -37,27 +43,23 @@ __device__ __forceinline__ void sk_dma16(const int8_t *sbase, unsigned voff, uns
                  : "memory");
 }
 
+#define SK_VM_CASE(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 template <int N> __device__ __forceinline__ void sk_wait_vm()
 {
-    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    static_assert(N >= 0 && N <= 63 && N % 2 == 0, "vmcnt is a 6-bit counter; unit sizes are even");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    SK_VM_CASE(4); SK_VM_CASE(6); SK_VM_CASE(8); SK_VM_CASE(10); SK_VM_CASE(12); SK_VM_CASE(14); SK_VM_CASE(16); SK_VM_CASE(18);
+    SK_VM_CASE(20); SK_VM_CASE(24); SK_VM_CASE(28); SK_VM_CASE(32); SK_VM_CASE(36);
 }
+#undef SK_VM_CASE
 
-template <class Epi, int MT>  // MT = number of 16-row token tiles (1..4)
+template <class Epi, int MT>  // MT = 16-row token tiles per m-block (1..4)
 __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
-                                                      int wpb, Epi epi)
+                                                      int wpb, int mblocks, Epi epi)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int UNIT = (1 + MT) * 2048;  // one 128-byte K unit: 16 W rows + MT x 16 X rows
     constexpr int D = 2 * (1 + MT);        // DMA instructions per unit per wave
-    static_assert(2 * D == 8 || 2 * D == 12 || 2 * D == 16 || 2 * D == 20, "sk_wait_vm literals");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
@@ -66,22 +68,22 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
 
     const int nunits = (int)(K / 128);
     const int upt = nunits > wave ? (nunits - wave + wpb - 1) / wpb : 0;  // this wave's units per tile
-    const int64_t ntiles = (N + 15) / 16;
-    const int my_tiles = (int)((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x);
-    const int total = my_tiles * upt;  // work items of this wave, tile-major
+    // work item i of this block = global item (blockIdx.x + i * gridDim.x) -> (channel tile, m-block);
+    // items g and g+8 (same XCD under round-robin dispatch) are the m-blocks of one tile
+    const int64_t nitems = (((N + 15) / 16 + 7) / 8) * 8 * mblocks;  // tiles padded to groups of 8 (padding items store nothing)
+    const int my_tiles = (int)((nitems - blockIdx.x + gridDim.x - 1) / gridDim.x);
+    const int total = my_tiles * upt;  // (item, unit) pairs of this wave, item-major
+    auto decode = [&](int i, int64_t &n0, int &mb) {
+        const int64_t gidx = (int64_t)blockIdx.x + (int64_t)i * gridDim.x;
+        const int64_t grp = gidx / (8 * mblocks), rem = gidx - grp * (8 * mblocks);
+        mb = (int)(rem >> 3);
+        n0 = (grp * 8 + (rem & 7)) * 16;
+    };
 
     // ---- DMA lane mapping: instruction i of a 16-row tile covers rows 8i .. 8i+7, 128 B each;
     // lane = 8*row + physical 16-B chunk; the logical chunk it fetches is swizzled by (row>>1)&7
     const int rr = lane >> 3, cp = lane & 7;
-    unsigned xoff[MT][2];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int64_t m = mt * 16 + 8 * i + rr;
-            m = m < M ? m : M - 1;
-            xoff[mt][i] = (unsigned)(m * K) + (unsigned)((cp ^ (((8 * i + rr) >> 1) & 7)) << 4);
-        }
+    unsigned xoff[MT][2];  // refreshed per work item (depends on the m-block)
     // ---- fragment read addresses (per stage, per k-step): lane (r, g) reads row r, logical chunk 4h+g
     const int fr = lane & 15, fg = lane >> 4;
     unsigned faddr[SK_STAGES][2];
@@ -96,18 +98,30 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
     // issue cursor (runs two items ahead of the consume cursor)
     int it_tile = 0, it_u = 0, issued = 0;
     unsigned woff[2] = {0, 0};
-    int64_t wt_n0 = -1;
+    int cur_item = -1;
+    int64_t it_n0 = 0;
     auto issue = [&](int stage) {
-        const int64_t n0 = ((int64_t)blockIdx.x + (int64_t)it_tile * gridDim.x) * 16;
-        if (n0 != wt_n0) {  // new tile: per-lane W offsets (clamped at the ragged edge)
-            wt_n0 = n0;
+        if (it_tile != cur_item) {  // new work item: per-lane W / X offsets (clamped at the ragged edges)
+            cur_item = it_tile;
+            int mb;
+            decode(it_tile, it_n0, mb);
+            if (it_n0 >= N) it_n0 = ((N - 1) / 16) * 16;  // padding item of the last 8-tile group: harmless reload
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 int64_t r = 8 * i + rr;
-                r = (n0 + r) < N ? r : (N - 1 - n0);
+                r = (it_n0 + r) < N ? r : (N - 1 - it_n0);
                 woff[i] = (unsigned)(r * K) + (unsigned)((cp ^ (((8 * i + rr) >> 1) & 7)) << 4);
             }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    int64_t m = (int64_t)mb * (MT * 16) + mt * 16 + 8 * i + rr;
+                    m = m < M ? m : M - 1;
+                    xoff[mt][i] = (unsigned)(m * K) + (unsigned)((cp ^ (((8 * i + rr) >> 1) & 7)) << 4);
+                }
         }
+        const int64_t n0 = it_n0;
         const int u = wave + it_u * wpb;
         const int8_t *wb = w + n0 * K + (int64_t)u * 128;
         const int8_t *xb = x + (int64_t)u * 128;
@@ -137,11 +151,13 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
             acc[mt] = (v4i){0, 0, 0, 0};
         }
         __syncthreads();
-        const int64_t n0 = ((int64_t)blockIdx.x + (int64_t)c_tile * gridDim.x) * 16;
+        int64_t n0;
+        int mb;
+        decode(c_tile, n0, mb);
         for (int mt = wave; mt < MT; mt += wpb) {
             v4i s = red[mt * 64 + lane];
             for (int v = 1; v < wpb; ++v) s += red[(v * MT + mt) * 64 + lane];
-            const int64_t m = mt * 16 + fr, n = n0 + 4 * fg;
+            const int64_t m = (int64_t)mb * (MT * 16) + mt * 16 + fr, n = n0 + 4 * fg;
             if (m < M && n < N) {
                 const float sr = Epi::kHasRow ? epi.row(m) : 1.0f;
                 v4f sc = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};

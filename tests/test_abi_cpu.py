@@ -42,6 +42,11 @@ def test_argument_errors_without_gpu():
     assert h.asq_gemm_workspace_bytes(256, 5120, 20480) == 9 * 256 * 5120 * 4   # OPT-13B fc2: 20 tiles -> 9 K splits
     assert h.asq_gemm_workspace_bytes(32, 4096, 4096) == 0              # skinny path
     assert h.asq_gemm_kernel_name(4096, 4096, 4096) == b"p8"
+    assert h.asq_gemm_kernel_name(64, 14336, 4096) == b"skinny"          # decode batch: weight stream
+    assert h.asq_gemm_kernel_name(256, 4096, 4096) == b"skinny"          # 4 m-blocks x 256 channel tiles still fit the chip
+    assert h.asq_gemm_kernel_name(320, 4096, 4096) == b"p8"
+    assert h.asq_gemm_kernel_name(128, 11008, 4096) == b"p8"             # measured crossover: work > 5.5e9
+    assert h.asq_gemm_kernel_name(64, 5120, 20480) == b"p8"
     assert h.asq_gemm_kernel_name(4, 4096, 4095) == b"generic"
 
 
