@@ -34,11 +34,22 @@ namespace asq {
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
+// Pin a wave-uniform pointer into an SGPR pair.  The LDS-DMA inline asm takes its base as an "s"
+// operand; LLVM may otherwise decide to evaluate a uniform 64-bit address chain on the VALU (seen with
+// one fp8 instantiation), which no constraint can repair afterwards.
+__device__ __forceinline__ const int8_t *uniform_ptr(const int8_t *p)
+{
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const int8_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
 // ---------------------------------------------------------------------------------
 // matrix-core policies: one "MMA step" consumes 16 k-bytes per lane of each operand (a v4i)
 // ---------------------------------------------------------------------------------
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef long v2l __attribute__((ext_vector_type(2)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 struct MmaI8 {  // int8 x int8 -> int32, exact: one v_mfma_i32_32x32x32_i8
     using acc_t = v16i;
@@ -80,6 +91,8 @@ struct MmaBf8 {  // OCP e5m2 x e5m2 -> fp32
 struct EpiI32 {
     using Mma = MmaI8;
     static constexpr bool kHasRow = false, kHasCol = false, kHasBias = false;
+    static constexpr int kOutBytes = 4;
+    __device__ __forceinline__ v4i pack(const v4i &a, float, const v4f &, const v4f &) const { return a; }
     int32_t *out;
     int64_t N;
     bool vec_ok;
@@ -106,6 +119,7 @@ struct EpiI32 {
 template <int DT, bool HAS_ROW, bool HAS_COL, bool HAS_BIAS> struct EpiDequant {
     using Mma = MmaI8;
     static constexpr bool kHasRow = HAS_ROW, kHasCol = HAS_COL, kHasBias = HAS_BIAS;
+    static constexpr int kOutBytes = (DT == ASQ_F32) ? 4 : 2;
     void *out;
     int64_t N;
     float s_scalar;
@@ -165,6 +179,19 @@ template <int DT, bool HAS_ROW, bool HAS_COL, bool HAS_BIAS> struct EpiDequant {
         return v;
     }
 
+    // 4 finished outputs in their storage encoding: v4i of fp32 bit patterns, or uint2 of 4 x 16-bit
+    __device__ __forceinline__ auto pack(const v4i &a, float sr, const v4f &sc, const v4f &b) const
+    {
+        using E = ElemT<DT>;
+        const float v0 = one(a[0], sc[0], sr, b[0]), v1 = one(a[1], sc[1], sr, b[1]);
+        const float v2 = one(a[2], sc[2], sr, b[2]), v3 = one(a[3], sc[3], sr, b[3]);
+        if constexpr (DT == ASQ_F32) {
+            return __builtin_bit_cast(v4i, (v4f){v0, v1, v2, v3});
+        } else {
+            return (v2u){(uint32_t)E::store(v0) | ((uint32_t)E::store(v1) << 16), (uint32_t)E::store(v2) | ((uint32_t)E::store(v3) << 16)};
+        }
+    }
+
     __device__ __forceinline__ void store4(int64_t m, int64_t n, const v4i &a, float sr, const v4f &sc, const v4f &b, int64_t Ncols) const
     {
         using E = ElemT<DT>;
@@ -191,6 +218,7 @@ template <int DT, bool HAS_ROW, bool HAS_COL, bool HAS_BIAS> struct EpiDequant {
 struct EpiI8 {  // out = sat_i8(rne(alpha*acc + beta*c)), c = previous out
     using Mma = MmaI8;
     static constexpr bool kHasRow = false, kHasCol = false, kHasBias = false;
+    static constexpr int kOutBytes = 1;  // read-modify-write of C: stays on the direct (unstaged) store path
     int8_t *out;
     int64_t N;
     float alpha, beta;
@@ -232,6 +260,22 @@ struct EpiI8 {  // out = sat_i8(rne(alpha*acc + beta*c)), c = previous out
 template <int DT, bool HAS_BIAS, class MMA_ = MmaFp8> struct EpiFp8 {
     using Mma = MMA_;
     static constexpr bool kHasRow = true, kHasCol = false, kHasBias = HAS_BIAS;
+    static constexpr int kOutBytes = (DT == ASQ_F32) ? 4 : 2;
+    __device__ __forceinline__ auto pack(const v4f &a, float sr, const v4f &sc, const v4f &b) const
+    {
+        using E = ElemT<DT>;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = __fmul_rn(a[i], __fmul_rn(sr, sc[i]));
+            if constexpr (HAS_BIAS) v[i] = __fadd_rn(v[i], b[i]);
+        }
+        if constexpr (DT == ASQ_F32) {
+            return __builtin_bit_cast(v4i, (v4f){v[0], v[1], v[2], v[3]});
+        } else {
+            return (v2u){(uint32_t)E::store(v[0]) | ((uint32_t)E::store(v[1]) << 16), (uint32_t)E::store(v[2]) | ((uint32_t)E::store(v[3]) << 16)};
+        }
+    }
     void *out;
     int64_t N;
     const float *a_scale_dev;
@@ -321,6 +365,99 @@ __device__ __forceinline__ void epilogue_wave(const Epi &epi, Get get, MOff moff
                 if (n < N)
                     epi.store4(mrow[im], n, (typename Epi::Mma::acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g], N);
             }
+        }
+    }
+}
+
+// Coalescing epilogue of the 256x256 kernel (wave tile 128(m) x 64(n): NTN = 2, NTM = 4).
+// In the matrix-core layout a lane owns ONE token and 4 consecutive channels, so a direct store
+// instruction touches 32 different output rows with 16 B each: measured ~10-12 B/clk per CU, 12.9k
+// cycles for the fp16 tile and 26k for an int32 split-K slab.  Here the finished (scaled, biased,
+// converted) values go through a WAVE-PRIVATE 16 KiB LDS image first and leave as whole rows: 8
+// lanes x 16 B = one 128-B line (2-byte outputs; 16 lanes x 16 B = 256 B for 4-byte outputs), 8 (4)
+// full rows per store instruction.  16-B chunks are XOR-swizzled by the row so the transposing
+// ds_write and the lane-linear ds_read_b128 stay (nearly) conflict-free.  No block barrier: each
+// wave only re-reads what it wrote; LDS operations of one wave execute in order.
+// Needs: out 16-B aligned and N * sizeof(out element) % 16 == 0 (then a 16-B chunk is never ragged).
+template <class Epi, class Get>
+__device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, int64_t M, int64_t N, unsigned stage)
+{
+    constexpr int EB = Epi::kOutBytes;
+    static_assert(EB == 2 || EB == 4, "staged epilogue: 2- or 4-byte outputs");
+    typedef __attribute__((address_space(3))) v4i *lds_v4i;
+    typedef __attribute__((address_space(3))) v2u *lds_u2;
+    const int ml = lane & 31, hi = lane >> 5;
+    float sr[4];
+#pragma unroll
+    for (int im = 0; im < 4; ++im) {
+        const int64_t m = mw0 + im * 32 + ml;
+        sr[im] = 1.0f;
+        if constexpr (Epi::kHasRow) {
+            if (m < M) sr[im] = epi.row(m);
+        }
+    }
+    v4f sc[2][4], bb[2][4];
+#pragma unroll
+    for (int in = 0; in < 2; ++in)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t n = nw0 + in * 32 + 8 * g + 4 * hi;
+            sc[in][g] = (v4f){0.f, 0.f, 0.f, 0.f};
+            bb[in][g] = (v4f){0.f, 0.f, 0.f, 0.f};
+            if (n < N) epi.cols(n, N, sc[in][g], bb[in][g]);
+        }
+    char *const outb = (char *)epi.out;
+    using acc4_t = typename Epi::Mma::acc4_t;
+    if constexpr (EB == 2) {
+#pragma unroll
+        for (int im = 0; im < 4; ++im) {
+            const int row = 32 * im + ml;
+#pragma unroll
+            for (int in = 0; in < 2; ++in) {
+                const typename Epi::Mma::acc_t a = get(in, im);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const v2u v = epi.pack((acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g]);
+                    *(lds_u2)(uintptr_t)(stage + row * 128 + (((in * 4 + g) ^ ((row >> 1) & 7)) << 4) + 8 * hi) = v;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = 8 * i + (lane >> 3);
+            const v4i v = *(lds_v4i)(uintptr_t)(stage + i * 1024 + lane * 16);
+            const int64_t m = mw0 + row, n = nw0 + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+            if (m < M && n < N) *(v4i *)(outb + (m * N + n) * 2) = v;
+        }
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int imh = 0; imh < 2; ++imh) {
+                const int im = 2 * h + imh, row = 32 * imh + ml;
+#pragma unroll
+                for (int in = 0; in < 2; ++in) {
+                    const typename Epi::Mma::acc_t a = get(in, im);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const v4i v = epi.pack((acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g]);
+                        *(lds_v4i)(uintptr_t)(stage + row * 256 + (((in * 8 + 2 * g + hi) ^ (row & 15)) << 4)) = v;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = 4 * i + (lane >> 4);
+                const v4i v = *(lds_v4i)(uintptr_t)(stage + i * 1024 + lane * 16);
+                const int64_t m = mw0 + 64 * h + row, n = nw0 + (((lane & 15) ^ (row & 15)) << 2);
+                if (m < M && n < N) *(v4i *)(outb + (m * N + n) * 4) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
         }
     }
 }

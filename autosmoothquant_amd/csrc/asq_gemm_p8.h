@@ -144,8 +144,8 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
     // This wave fills row-groups 2*wave, 2*wave+1 (8 rows each) of every unit.
     const int nt_all = (int)(K / 128);
     const int kt0 = (int)((int64_t)nt_all * split / ksplit), kt1 = (int)((int64_t)nt_all * (split + 1) / ksplit);
-    const int8_t *const xbase = x + m0 * K + (int64_t)kt0 * 128;  // wave-uniform
-    const int8_t *const wbase = w + n0 * K + (int64_t)kt0 * 128;
+    const int8_t *const xbase = uniform_ptr(x + m0 * K + (int64_t)kt0 * 128);  // wave-uniform, SGPR pair
+    const int8_t *const wbase = uniform_ptr(w + n0 * K + (int64_t)kt0 * 128);
     const int64_t mrem = M - m0 - 1, nrem = N - n0 - 1;  // last valid local row
     unsigned voff[4][2];  // [kind][i]
 #pragma unroll
@@ -344,9 +344,17 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
     if (wm == 0) P8_BAR();  // balance the stagger barrier
 
     // accumulator tile (in = n-half, im = 2*m-half + j) -> rows m0 + wm*128 + 32*im, cols n0 + wn*64 + 32*in
-    epilogue_wave<2, 4>(
-        epi, [&](int in, int im) -> const acc_t & { return acc[im >> 1][in][im & 1]; }, [](int im) { return im * 32; }, m0 + wm * 128, n0 + wn * 64, lane,
-        M, N);
+    auto get = [&](int in, int im) -> const acc_t & { return acc[im >> 1][in][im & 1]; };
+    bool staged = false;
+    if constexpr (Epi::kOutBytes >= 2) staged = ((((uintptr_t)epi.out) & 15) == 0) && ((N * Epi::kOutBytes) % 16 == 0);
+    if (staged) {
+        if constexpr (Epi::kOutBytes >= 2) {
+            P8_BAR();  // every wave's ring reads are done and every wave's (dead) DMAs have landed: the ring becomes staging space
+            epilogue_wave_staged(epi, get, m0 + wm * 128, n0 + wn * 64, lane, M, N, lds0 + wave * 16384);
+        }
+    } else {
+        epilogue_wave<2, 4>(epi, get, [](int im) { return im * 32; }, m0 + wm * 128, n0 + wn * 64, lane, M, N);
+    }
     if constexpr (ABL & 128) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         P8_BLK(3);

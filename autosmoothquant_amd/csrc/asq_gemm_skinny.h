@@ -123,8 +123,8 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
         }
         const int64_t n0 = it_n0;
         const int u = wave + it_u * wpb;
-        const int8_t *wb = w + n0 * K + (int64_t)u * 128;
-        const int8_t *xb = x + (int64_t)u * 128;
+        const int8_t *wb = uniform_ptr(w + n0 * K + (int64_t)u * 128);
+        const int8_t *xb = uniform_ptr(x + (int64_t)u * 128);
         const unsigned dst = ring + stage * UNIT;
 #pragma unroll
         for (int i = 0; i < 2; ++i) sk_dma16(wb, woff[i], dst + i * 1024);
