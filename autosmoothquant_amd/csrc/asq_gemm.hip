@@ -13,6 +13,7 @@ int forced_kernel()
         if (e) {
             if (!strcmp(e, "generic")) v = KERN_GENERIC;
             else if (!strcmp(e, "p8")) v = KERN_P8;
+            else if (!strcmp(e, "p8h")) v = KERN_P8H;
             else if (!strcmp(e, "skinny")) v = KERN_SKINNY;
         }
     }
@@ -37,6 +38,7 @@ extern "C" const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K)
 {
     switch (pick_kernel(nullptr, nullptr, M, N, K)) {
     case KERN_P8: return "p8";
+    case KERN_P8H: return "p8h";
     case KERN_SKINNY: return "skinny";
     default: return "generic";
     }
@@ -44,9 +46,11 @@ extern "C" const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K)
 
 extern "C" size_t asq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K)
 {
-    if (M <= 0 || N <= 0 || K <= 0 || pick_kernel(nullptr, nullptr, M, N, K) != KERN_P8) return 0;
-    const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
-    const int s = pick_ksplit(tiles, K, M, N, (size_t)-1);
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const GemmKernel kern = pick_kernel(nullptr, nullptr, M, N, K);
+    if (kern != KERN_P8 && kern != KERN_P8H) return 0;
+    const int s = kern == KERN_P8 ? pick_ksplit(((M + 255) / 256) * ((N + 255) / 256), K, M, N, (size_t)-1)
+                                  : pick_ksplit_p8h(((M + 127) / 128) * ((N + 255) / 256), K, M, N, (size_t)-1);
     return s > 1 ? (size_t)s * (size_t)M * (size_t)N * 4 : 0;
 }
 

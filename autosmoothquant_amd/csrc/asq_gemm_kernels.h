@@ -379,17 +379,18 @@ __device__ __forceinline__ void epilogue_wave(const Epi &epi, Get get, MOff moff
 // ds_write and the lane-linear ds_read_b128 stay (nearly) conflict-free.  No block barrier: each
 // wave only re-reads what it wrote; LDS operations of one wave execute in order.
 // Needs: out 16-B aligned and N * sizeof(out element) % 16 == 0 (then a 16-B chunk is never ragged).
-template <class Epi, class Get>
+template <int NTM, class Epi, class Get>  // NTM = 32-row token tiles of the wave tile: 4 (256-row block tile) or 2 (128-row)
 __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, int64_t M, int64_t N, unsigned stage)
 {
     constexpr int EB = Epi::kOutBytes;
+    static_assert(NTM == 2 || NTM == 4, "wave tile of 64 or 128 rows");
     static_assert(EB == 2 || EB == 4, "staged epilogue: 2- or 4-byte outputs");
     typedef __attribute__((address_space(3))) v4i *lds_v4i;
     typedef __attribute__((address_space(3))) v2u *lds_u2;
     const int ml = lane & 31, hi = lane >> 5;
-    float sr[4];
+    float sr[NTM];
 #pragma unroll
-    for (int im = 0; im < 4; ++im) {
+    for (int im = 0; im < NTM; ++im) {
         const int64_t m = mw0 + im * 32 + ml;
         sr[im] = 1.0f;
         if constexpr (Epi::kHasRow) {
@@ -410,7 +411,7 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
     using acc4_t = typename Epi::Mma::acc4_t;
     if constexpr (EB == 2) {
 #pragma unroll
-        for (int im = 0; im < 4; ++im) {
+        for (int im = 0; im < NTM; ++im) {
             const int row = 32 * im + ml;
 #pragma unroll
             for (int in = 0; in < 2; ++in) {
@@ -425,7 +426,7 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 4 * NTM; ++i) {
             const int row = 8 * i + (lane >> 3);
             const v4i v = *(lds_v4i)(uintptr_t)(stage + i * 1024 + lane * 16);
             const int64_t m = mw0 + row, n = nw0 + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
@@ -433,7 +434,7 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
         }
     } else {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NTM / 2; ++h) {
 #pragma unroll
             for (int imh = 0; imh < 2; ++imh) {
                 const int im = 2 * h + imh, row = 32 * imh + ml;
@@ -522,6 +523,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 }  // namespace asq
 
 #include "asq_gemm_p8.h"
+#include "asq_gemm_p8h.h"
 #include "asq_gemm_skinny.h"
 
 namespace asq {
@@ -566,9 +568,9 @@ __global__ void __launch_bounds__(256) splitk_reduce(const int32_t *__restrict__
 // ---------------------------------------------------------------------------------
 // dispatch + launch
 // ---------------------------------------------------------------------------------
-enum GemmKernel { KERN_GENERIC = 0, KERN_SKINNY = 1, KERN_P8 = 2 };
+enum GemmKernel { KERN_GENERIC = 0, KERN_SKINNY = 1, KERN_P8 = 2, KERN_P8H = 3 };
 
-int forced_kernel();  // env ASQ_GEMM_KERNEL=generic|skinny|p8 (development / A-B aid), asq_gemm.hip
+int forced_kernel();  // env ASQ_GEMM_KERNEL=generic|skinny|p8|p8h (development / A-B aid), asq_gemm.hip
 
 static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, int64_t N, int64_t K)
 {
@@ -576,7 +578,7 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
     const bool tiled_ok = aligned && K % 128 == 0 && K >= 128 && K <= (1 << 24);
     const int f = forced_kernel();
     if (f == KERN_GENERIC) return KERN_GENERIC;
-    if (tiled_ok && f == KERN_P8) return KERN_P8;
+    if (tiled_ok && (f == KERN_P8 || f == KERN_P8H)) return (GemmKernel)f;
     if (tiled_ok && M <= 1024 && f == KERN_SKINNY) return KERN_SKINNY;
     if (tiled_ok && f < 0) {
         // measured crossover (tools/kbench.py grid, 16..512 rows x 9 LLaMA/OPT weight shapes): the
@@ -584,9 +586,23 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
         // (channel tile, 64-row block) items all fit on the chip at once and the total work is small
         const int64_t items = ((N + 15) / 16) * ((M + 63) / 64);
         const double work = (double)N * (double)K * (double)M;
-        return ((M <= 64 || items <= 1024) && work <= 5.5e9) ? KERN_SKINNY : KERN_P8;
+        if ((M <= 64 || items <= 1024) && work <= 4.0e9) return KERN_SKINNY;
+        // 128-row tiles when the 256-row tiling cannot fill 256 CUs (or wastes half a tile row).  Measured
+        // (tools/ksplit_sweep.sh): p8h is ~14 % slower per op on a full chip but wins up to 1.45x below ~144 tiles
+        const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
+        return t256 < 144 ? KERN_P8H : KERN_P8;
     }
     return KERN_GENERIC;
+}
+
+static inline int forced_ksplit()  // env ASQ_KSPLIT=n forces a split count (development / tuning aid)
+{
+    static int forced = -2;
+    if (forced == -2) {
+        const char *e = getenv("ASQ_KSPLIT");
+        forced = e ? atoi(e) : -1;
+    }
+    return forced;
 }
 
 // number of K splits for the tiled kernel: fill the 256 CUs when the M x N tile grid cannot
@@ -594,12 +610,8 @@ static inline int pick_ksplit(int64_t tiles, int64_t K, int64_t M, int64_t N, si
 {
     if (N % 4 != 0) return 1;
     const int64_t nt = K / 128;
-    {   // env ASQ_KSPLIT=n forces a split count (development / tuning aid)
-        static int forced = -2;
-        if (forced == -2) {
-            const char *e = getenv("ASQ_KSPLIT");
-            forced = e ? atoi(e) : -1;
-        }
+    {
+        const int forced = forced_ksplit();
         if (forced > 0) {
             int64_t f = forced > nt ? nt : forced;
             while (f > 1 && (size_t)f * (size_t)M * (size_t)N * 4 > ws_bytes) --f;
@@ -611,6 +623,25 @@ static inline int pick_ksplit(int64_t tiles, int64_t K, int64_t M, int64_t N, si
     if (tiles >= 118) return 1;
     int64_t s = (176 + tiles / 2) / tiles;
     if (s > nt / 4) s = nt / 4;              // >= 4 K-tiles (512 k) per split: keep the pipeline efficient
+    while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ws_bytes) --s;
+    return s < 1 ? 1 : (int)s;
+}
+
+// K splits for the 128-row kernel (tiles = its block count at one split).  Measured optimum: fill ~192 CUs,
+// but never leave a split fewer than 12 K-tiles (the int32 slab write + reduce pass must stay small next to the K loop)
+static inline int pick_ksplit_p8h(int64_t tiles, int64_t K, int64_t M, int64_t N, size_t ws_bytes)
+{
+    if (N % 4 != 0) return 1;
+    const int64_t nt = K / 128;
+    const int forced = forced_ksplit();
+    int64_t s;
+    if (forced > 0) {
+        s = forced > nt ? nt : forced;
+    } else {
+        if (tiles >= 80) return 1;
+        s = 192 / tiles;
+        if (s > nt / 12) s = nt / 12;
+    }
     while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ws_bytes) --s;
     return s < 1 ? 1 : (int)s;
 }
@@ -701,6 +732,31 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
             return (int)e;
         }
         hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, (const int *)nullptr, 0, epi);
+    } else if (kern == KERN_P8H) {
+        const int64_t tm = (M + 127) / 128, tn = (N + 255) / 256;
+        ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
+        const int ksplit = (kInt && ws != nullptr && (((uintptr_t)ws) & 15) == 0) ? pick_ksplit_p8h(tm * tn, K, M, N, ws_bytes) : 1;
+        if constexpr (kInt) if (ksplit > 1) {
+            EpiI32 slab{(int32_t *)ws, N, true};
+            auto kfn = gemm_i8_p8h<EpiI32>;
+            hipError_t e = ensure_dynamic_lds((const void *)kfn, P8H_LDS_BYTES);
+            if (e != hipSuccess) {
+                asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+                return (int)e;
+            }
+            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn * ksplit)), dim3(512), P8H_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, ksplit, slab);
+            int64_t blocks = (M * (N / 4) + 255) / 256;
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL((splitk_reduce<Epi>), dim3((unsigned)blocks), dim3(256), 0, s, (const int32_t *)ws, ksplit, M, N, epi);
+            return asq_after_launch(s, what);
+        }
+        auto kfn = gemm_i8_p8h<Epi>;
+        hipError_t e = ensure_dynamic_lds((const void *)kfn, P8H_LDS_BYTES);
+        if (e != hipSuccess) {
+            asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+            return (int)e;
+        }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8H_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, epi);
     } else if (kern == KERN_SKINNY) {
         if constexpr (kInt) {
             const int rc = launch_skinny(x, w, M, N, K, epi, s);

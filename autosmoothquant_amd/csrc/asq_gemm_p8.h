@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
     if (staged) {
         if constexpr (Epi::kOutBytes >= 2) {
             P8_BAR();  // every wave's ring reads are done and every wave's (dead) DMAs have landed: the ring becomes staging space
-            epilogue_wave_staged(epi, get, m0 + wm * 128, n0 + wn * 64, lane, M, N, lds0 + wave * 16384);
+            epilogue_wave_staged<4>(epi, get, m0 + wm * 128, n0 + wn * 64, lane, M, N, lds0 + wave * 16384);
         }
     } else {
         epilogue_wave<2, 4>(epi, get, [](int im) { return im * 32; }, m0 + wm * 128, n0 + wn * 64, lane, M, N);

@@ -39,14 +39,16 @@ def test_argument_errors_without_gpu():
     assert h.asq_gemm_i8_i32(None, None, None, 0, 4, 4, None, 0, None) == 0            # empty problem is a no-op
     assert h.asq_linear_w8a8_workspace_bytes(3, 7, 5) == 256 + 256
     assert h.asq_gemm_workspace_bytes(4096, 4096, 4096) == 0            # 256 tiles fill the chip: no split-K
-    assert h.asq_gemm_workspace_bytes(256, 5120, 20480) == 9 * 256 * 5120 * 4   # OPT-13B fc2: 20 tiles -> 9 K splits
+    assert h.asq_gemm_workspace_bytes(256, 5120, 20480) == 4 * 256 * 5120 * 4   # OPT-13B fc2: 40 tiles of 128 rows -> 4 K splits
     assert h.asq_gemm_workspace_bytes(32, 4096, 4096) == 0              # skinny path
     assert h.asq_gemm_kernel_name(4096, 4096, 4096) == b"p8"
     assert h.asq_gemm_kernel_name(64, 14336, 4096) == b"skinny"          # decode batch: weight stream
-    assert h.asq_gemm_kernel_name(256, 4096, 4096) == b"skinny"          # 4 m-blocks x 256 channel tiles still fit the chip
-    assert h.asq_gemm_kernel_name(320, 4096, 4096) == b"p8"
-    assert h.asq_gemm_kernel_name(128, 11008, 4096) == b"p8"             # measured crossover: work > 5.5e9
-    assert h.asq_gemm_kernel_name(64, 5120, 20480) == b"p8"
+    assert h.asq_gemm_kernel_name(192, 4096, 4096) == b"skinny"          # 3 m-blocks x 256 channel tiles still fit the chip
+    assert h.asq_gemm_kernel_name(320, 4096, 4096) == b"p8h"             # too few 256-row tiles for 256 CUs: 128-row tiles
+    assert h.asq_gemm_kernel_name(128, 11008, 4096) == b"p8h"            # measured crossover: work > 4e9
+    assert h.asq_gemm_kernel_name(64, 5120, 20480) == b"p8h"
+    assert h.asq_gemm_kernel_name(2048, 4096, 4096) == b"p8h"            # 128 tiles of 256 rows
+    assert h.asq_gemm_kernel_name(2048, 5120, 5120) == b"p8"             # 160 tiles: the 256-row kernel is the more efficient one
     assert h.asq_gemm_kernel_name(4, 4096, 4095) == b"generic"
 
 

@@ -137,8 +137,10 @@ GEMM_SHAPES = [
     # 64 < M on a small weight: weight-streaming kernel with several 64-row m-blocks (balanced, ragged M and N,
     # channel-tile count not a multiple of 8 -> padding items)
     (65, 256, 128), (100, 200, 384), (129, 257, 1024), (200, 1000, 256), (256, 4096, 512), (300, 520, 384),
-    # same row counts on weights past the work threshold -> tiled kernel with a partial tile / split-K
-    (100, 11008, 4096), (160, 4096, 11008),
+    # same row counts on weights past the work threshold -> 128-row tiled kernel (p8h) with a partial tile / split-K
+    (100, 11008, 4096), (160, 4096, 11008), (256, 512, 6144),
+    # >= 144 tiles of 256 x 256: the 256-row kernel (p8); everything tiled above runs p8h
+    (3072, 3072, 256), (2900, 3300, 384),
 ]
 
 
