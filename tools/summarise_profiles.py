@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/ (written by tools/collect_profiles.sh on the GPU box) into the tracked
+summaries under profiles/:
+  <tag>_bench.json, <tag>_bench_under_rocprof.json   the bench lines
+  <tag>_bench_kernel_stats.csv                        rocprofv3 --stats per-kernel summary
+  <tag>_pmc_traffic.json                              HBM-side bytes per launch per kernel
+FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch; on gfx950 FETCH_SIZE under-reports 16-B/lane
+streams by 2x (MI355X_MICROARCH.md, HBM section) -- calibrated on quant_flat_vec, whose traffic is known exactly.
+usage: python tools/summarise_profiles.py r1"""
+import collections, csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out", f"prof_{tag}"), os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def last_json_line(path):
+    for line in reversed(open(path).read().strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise SystemExit(f"no JSON line in {path}")
+
+
+for name in ("bench", "bench_under_rocprof"):
+    json.dump(last_json_line(os.path.join(src, name + ".json")), open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
+
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+shutil.copy(stats, os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
+
+
+def pmc_means(counter):
+    f = glob.glob(os.path.join(src, f"pmc_{counter}", "**", "*counter_collection.csv"), recursive=True)[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            acc[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+fetch, write = pmc_means("FETCH_SIZE"), pmc_means("WRITE_SIZE")
+bench = last_json_line(os.path.join(src, "bench.json"))
+out = {
+    "command": "rocprofv3 --kernel-trace --pmc <C> --output-format csv -- python bench.py --no-cpu-baseline --steps 5 --warmup 2  (one pass per counter, C in {FETCH_SIZE, WRITE_SIZE})",
+    "units": "rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KiB per dispatch",
+    "gfx950_correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md 'HBM'); check: quant_flat_vec reads exactly M*K*2 B and writes M*K B",
+    "workload": bench["config"]["workload"],
+    "kernels": {},
+}
+for key in sorted(fetch, key=lambda k: -fetch[k][0]):
+    name, grid = key
+    if "asq::" not in name:
+        continue
+    short = name.split("(")[0].replace("void ", "")
+    f_kib, n = fetch[key]
+    w_kib = write.get(key, (0.0, 0))[0]
+    e = {"grid_size": grid, "dispatches_sampled": n, "FETCH_SIZE_KiB_raw": round(f_kib, 1), "WRITE_SIZE_KiB_raw": round(w_kib, 1),
+         "fetch_bytes_corrected": int(f_kib * 1024 * 2), "write_bytes": int(w_kib * 1024)}
+    e["traffic_bytes_per_launch"] = e["fetch_bytes_corrected"] + e["write_bytes"]
+    if "gemm_i8_p8<" in short and grid == 256 * 512:  # 256 tiles of 256x256: the M=N=K=4096 launches of the default workload
+        e["shape"] = [4096, 4096, 4096]
+        e["algorithmic_bytes_per_launch"] = 4096 * 4096 * (1 + 1 + 2)
+        e["traffic_over_algorithmic"] = round(e["traffic_bytes_per_launch"] / e["algorithmic_bytes_per_launch"], 2)
+        e["note"] = ("every X panel is fetched by 2 XCD L2s and every W panel by 4 (each XCD owns a 4x8 block of 256x256 tiles), so memory-side reads are "
+                     "~3x the 33.5 MB of operands; they are served by the 256 MiB Infinity Cache (FETCH_SIZE counts those hits)")
+    out["kernels"][f"{short} grid={grid}"] = e
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read())
+print(json.dumps(out["kernels"], indent=1)[:3000])
