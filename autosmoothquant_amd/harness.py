@@ -143,3 +143,100 @@ def to_w8a8(layer, scales, quant_config=None, fuse_norm=False):
     q.input_layernorm = layer.input_layernorm.folded(scales["attn_in"]) if cfg["qkv"] == "per-tensor" else layer.input_layernorm
     q.post_attention_layernorm = layer.post_attention_layernorm.folded(scales["mlp_in"]) if cfg["fc1"] == "per-tensor" else layer.post_attention_layernorm
     return q
+
+
+# ---------------------------------------------------------------------------------------------
+# Baichuan-architecture layer: the one decoder-layer composition the reference can execute without the
+# pinned HF version (models/baichuan.py), hence the one pinned by golden vectors (tests/golden/g7_block.npz).
+# ---------------------------------------------------------------------------------------------
+class BaichuanRMSNorm(torch.nn.Module):
+    """thirdparty/baichuan/modeling_baichuan.py:161-176: x * rsqrt(mean(x^2) + eps), cast to the weight's
+    half dtype if it has one, times weight."""
+
+    def __init__(self, hidden, eps=1e-6):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.ones(hidden))
+        self.epsilon = eps
+
+    def forward(self, x):
+        v = x * torch.rsqrt(x.to(torch.float32).pow(2).mean(-1, keepdim=True) + self.epsilon)
+        if self.weight.dtype in (torch.float16, torch.bfloat16):
+            v = v.to(self.weight.dtype)
+        return self.weight * v
+
+
+class BaichuanLayer(torch.nn.Module):
+    """Float layer: pre-norm, fused W_pack QKV projection, eager softmax attention (no mask: the "ALIBI" branch
+    with attention_mask=None, the only one the reference's int8 layer runs on CPU), SiLU-gated MLP."""
+
+    def __init__(self, hidden=256, inter=704, heads=4, eps=1e-6):
+        super().__init__()
+        self.hidden, self.heads, self.hd = hidden, heads, hidden // heads
+        L = torch.nn.Linear
+        self.input_layernorm, self.post_attention_layernorm = BaichuanRMSNorm(hidden, eps), BaichuanRMSNorm(hidden, eps)
+        self.W_pack, self.o_proj = L(hidden, 3 * hidden, bias=False), L(hidden, hidden, bias=False)
+        self.gate_proj, self.up_proj, self.down_proj = L(hidden, inter, bias=False), L(hidden, inter, bias=False), L(inter, hidden, bias=False)
+        self.int8 = False
+
+    def _attend(self, proj):
+        B, S, _ = proj.shape
+        q, k, v = [t.view(B, S, self.heads, self.hd).transpose(1, 2) for t in proj.split(self.hidden, dim=-1)]
+        w = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(self.hd)
+        w = torch.nn.functional.softmax(w, dim=-1).to(v.dtype)
+        return torch.matmul(w, v).transpose(1, 2).reshape(B, S, self.hidden)
+
+    def forward(self, h, record=None):
+        x = self.input_layernorm(h)
+        if record is not None:
+            record["attn_in"] = x
+        proj = self.W_pack(x)
+        if self.int8:
+            proj = proj.to(torch.float16)  # models/baichuan.py:120
+        a = self._attend(proj)
+        if record is not None:
+            record["o_in"] = a
+        h = h + self.o_proj(a).to(h.dtype)
+        x = self.post_attention_layernorm(h)
+        if record is not None:
+            record["mlp_in"] = x
+        g = self.gate_proj(x)
+        if self.int8:
+            g = g.to(torch.float16)        # models/baichuan.py:227
+        g = F.silu(g) * self.up_proj(x)
+        if record is not None:
+            record["down_in"] = g
+        return h + self.down_proj(g).to(h.dtype)
+
+
+@torch.no_grad()
+def to_w8a8_baichuan(layer, scales, quant_config=None):
+    """Quantised copy composed like Int8BaichuanLayer.from_float (models/baichuan.py:258-287):
+    W_pack -> W8A8BFP32OFP32QKVLinear (three per-segment scales), gate/up -> W8A8BFP32OFP32Linear,
+    o/down -> W8A8BFP32OFP32LinearWithQuantScale; norm weights divided by the input scale iff per-tensor."""
+    from .layers.nn.linear import W8A8BFP32OFP32QKVLinear
+    cfg = {"qkv": "per-tensor", "out": "per-token", "fc1": "per-tensor", "fc2": "per-token"}
+    cfg.update(quant_config or {})
+    dev = layer.W_pack.weight.device
+    q = BaichuanLayer.__new__(BaichuanLayer)
+    torch.nn.Module.__init__(q)
+    q.hidden, q.heads, q.hd, q.int8 = layer.hidden, layer.heads, layer.hd, True
+
+    def src(lin):
+        s = torch.nn.Linear(lin.in_features, lin.out_features, bias=False)
+        s.weight = torch.nn.Parameter(lin.weight.detach().float().clone())  # from_float rounds an fp32 source in place
+        return s
+
+    q.W_pack = W8A8BFP32OFP32QKVLinear.from_float(src(layer.W_pack), scales["attn_in"], [layer.hidden] * 3, save_device=dev, act_quant=cfg["qkv"]).to(dev)
+    q.o_proj = W8A8BFP32OFP32LinearWithQuantScale.from_float(src(layer.o_proj), scales["o_in"], save_device=dev, act_quant=cfg["out"]).to(dev)
+    q.gate_proj = W8A8BFP32OFP32Linear.from_float(src(layer.gate_proj), scales["mlp_in"], save_device=dev, act_quant=cfg["fc1"]).to(dev)
+    q.up_proj = W8A8BFP32OFP32Linear.from_float(src(layer.up_proj), scales["mlp_in"], save_device=dev, act_quant=cfg["fc1"]).to(dev)
+    q.down_proj = W8A8BFP32OFP32LinearWithQuantScale.from_float(src(layer.down_proj), scales["down_in"], save_device=dev, act_quant=cfg["fc2"]).to(dev)
+
+    def norm(n, scale, fold):
+        m = BaichuanRMSNorm(n.weight.numel(), n.epsilon)
+        m.weight = torch.nn.Parameter(n.weight.detach() / scale if fold else n.weight.detach().clone())
+        return m.to(dev)
+
+    q.input_layernorm = norm(layer.input_layernorm, scales["attn_in"], cfg["qkv"] == "per-tensor")
+    q.post_attention_layernorm = norm(layer.post_attention_layernorm, scales["mlp_in"], cfg["fc1"] == "per-tensor")
+    return q

@@ -78,3 +78,26 @@ def g4_inputs(c):
     bias = (detrng.normal(42, ci, (c["N"],)) * np.float32(0.5)).astype(np.float32) if c["use_bias"] else None
     x = O.round_to(detrng.act_like(43, ci, (c["M"], c["K"]), scale=40.0), c["dt"])
     return x, wq, bias
+
+
+def load_g6():
+    z = np.load(os.path.join(GOLDEN, "g6_smooth.npz"))
+    cases = []
+    for line in z["index"]:
+        ci, kind, mt, alpha, dt, nfc = str(line).split("|")
+        k = f"c{ci}"
+        cases.append(dict(id=int(ci), kind=kind, model_type=mt, alpha=float(alpha), dt=dt, ln_w=z[k + "_ln_w"], ln_w_out=z[k + "_ln_w_out"],
+                          ln_b=z[k + "_ln_b"] if kind == "layernorm" else None, ln_b_out=z[k + "_ln_b_out"] if kind == "layernorm" else None,
+                          act=z[k + "_act"], fcs=[z[k + f"_fc{j}"] for j in range(int(nfc))], fcs_out=[z[k + f"_fc{j}_out"] for j in range(int(nfc))]))
+    return cases
+
+
+def load_g7():
+    z = np.load(os.path.join(GOLDEN, "g7_block.npz"))
+    H, heads, inter, B, S = [int(v) for v in z["dims"]]
+    cases = []
+    for line in z["index"]:
+        ci, a, b, c, d = str(line).split("|")
+        cases.append(dict(id=int(ci), qc={"qkv": a, "out": b, "fc1": c, "fc2": d}, y=z[f"c{ci}_y"]))
+    return dict(H=H, heads=heads, inter=inter, B=B, S=S, eps=float(z["eps"]), x=z["x"], y_float=z["y_float"], scales=z["scales"],
+                W={k[2:]: z[k] for k in z.files if k.startswith("W_")}, cases=cases)

@@ -104,3 +104,72 @@ def test_silu_mul_quant_matches_two_step_path(dt, per_token):
     assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) < 2e-3
     if per_token:
         assert torch.allclose(s_row, rs, rtol=4e-3)
+
+
+def _baichuan_from_golden(g, dev):
+    from autosmoothquant_amd import harness
+    layer = harness.BaichuanLayer(hidden=g["H"], inter=g["inter"], heads=g["heads"], eps=g["eps"])
+    W = g["W"]
+    with torch.no_grad():
+        for name, key in (("W_pack", "W_pack"), ("o_proj", "o_proj"), ("gate_proj", "gate_proj"), ("up_proj", "up_proj"), ("down_proj", "down_proj")):
+            getattr(layer, name).weight.copy_(torch.from_numpy(W[key]))
+        layer.input_layernorm.weight.copy_(torch.from_numpy(W["ln1"]))
+        layer.post_attention_layernorm.weight.copy_(torch.from_numpy(W["ln2"]))
+    return layer.to(dev)
+
+
+def test_baichuan_block_matches_reference_golden():
+    """The HIP-backed layer, composed like Int8BaichuanLayer.from_float, against the REFERENCE's own outputs
+    (tests/golden/g7_block.npz).  The linears are bit-exact; the fp16 attention matmuls run on the GPU's BLAS
+    here and on the CPU in the reference, so a handful of activations land on the other side of an int8
+    rounding boundary: tolerance 2e-3 of max |y| (north-star rtol 1e-3 on the linears themselves)."""
+    import numpy as np
+    from autosmoothquant_amd import harness
+    from autosmoothquant_amd.layers.nn.linear import W8A8BFP32OFP32QKVLinear
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import goldenio
+    dev = torch.device("cuda:0")
+    g = goldenio.load_g7()
+    layer = _baichuan_from_golden(g, dev)
+    x = torch.from_numpy(g["x"]).to(dev)
+    with torch.no_grad():
+        yf = layer(x).cpu().numpy()
+    assert np.abs(yf - g["y_float"]).max() <= 1e-4 * np.abs(g["y_float"]).max()   # the float harness layer == the reference's float layer
+    scales = dict(zip(("attn_in", "o_in", "mlp_in", "down_in"), (float(s) for s in g["scales"])))
+    for c in g["cases"]:
+        q = harness.to_w8a8_baichuan(layer, scales, c["qc"])
+        assert isinstance(q.W_pack, W8A8BFP32OFP32QKVLinear) and q.W_pack.act_quant == c["qc"]["qkv"] and q.down_proj.act_quant == c["qc"]["fc2"]
+        with torch.no_grad():
+            y = q(x).cpu().numpy()
+        assert np.abs(y - c["y"]).max() <= 2e-3 * np.abs(c["y"]).max(), (c["qc"], float(np.abs(y - c["y"]).max() / np.abs(c["y"]).max()))
+
+
+def test_baichuan_block_matches_oracle_on_fresh_inputs():
+    """Same composition, other sizes / seeds than the fixture: HIP layer vs oracle/block.py."""
+    import numpy as np
+    from autosmoothquant_amd import harness
+    from oracle import block as OB
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    H, inter, heads = 384, 1024, 6
+    layer = harness.BaichuanLayer(hidden=H, inter=inter, heads=heads)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(torch.randn(p.shape) * 0.04 if p.dim() == 2 else 1 + 0.1 * torch.randn(p.shape))
+    layer = layer.to(dev)
+    x = torch.randn(3, 40, H)
+    x[..., 7] *= 10
+    rec = {}
+    with torch.no_grad():
+        layer(x.to(dev), rec)
+    scales = {k: float(v.abs().max()) / 127.0 for k, v in rec.items()}
+    W = {"W_pack": layer.W_pack.weight, "o_proj": layer.o_proj.weight, "gate_proj": layer.gate_proj.weight, "up_proj": layer.up_proj.weight,
+         "down_proj": layer.down_proj.weight, "ln1": layer.input_layernorm.weight, "ln2": layer.post_attention_layernorm.weight}
+    W = {k: v.detach().cpu().numpy() for k, v in W.items()}
+    for qc in (OB.DEFAULT_QC, {"qkv": "per-token", "out": "per-tensor", "fc1": "per-token", "fc2": "per-tensor"}):
+        P = OB.convert(W, [scales["attn_in"], scales["o_in"], scales["mlp_in"], scales["down_in"]], qc)
+        ref = OB.layer_forward(x.numpy(), P, heads)
+        with torch.no_grad():
+            y = harness.to_w8a8_baichuan(layer, scales, qc)(x.to(dev)).cpu().numpy()
+        assert np.abs(y - ref).max() <= 2e-3 * np.abs(ref).max(), qc

@@ -154,3 +154,58 @@ def test_fp8_codecs_match_torch_casts():
     for enc, dec, tdt in ((F8.f32_to_e4m3fn, F8.e4m3fn_to_f32, torch.float8_e4m3fn), (F8.f32_to_e5m2, F8.e5m2_to_f32, torch.float8_e5m2)):
         ref = t.to(tdt).float().numpy()
         assert np.array_equal(dec(enc(r)), ref, equal_nan=True)
+
+
+# ---- G7: the reference's executable decoder-layer composition (Int8BaichuanLayer) ---------------
+def test_g7_block_oracle_matches_reference_outputs():
+    """oracle/block.py against the reference's Int8BaichuanLayer outputs.  The linears are bit-exact
+    restatements; the fp16 attention / SiLU glue is torch CPU arithmetic with unspecified summation order,
+    so the stated tolerance is 1e-6 of max |y| (observed: bit-identical for 2 of the 3 configs, 1.2e-8 for the third)."""
+    from oracle import block as B
+    g = goldenio.load_g7()
+    for c in g["cases"]:
+        P = B.convert(g["W"], g["scales"], c["qc"])
+        y = B.layer_forward(g["x"], P, g["heads"], g["eps"])
+        assert np.abs(y - c["y"]).max() <= 1e-6 * np.abs(c["y"]).max(), c["qc"]
+        # and the int8 layer stays within quantisation error of the float layer (SURVEY 8c: ~1e-2 observed)
+        assert np.abs(c["y"] - g["y_float"]).max() <= 2e-2 * np.abs(g["y_float"]).max()
+
+
+# ---- G6: smooth_ln_fcs (weight-side conversion, SURVEY 8f N2) --------------------------------------
+def test_g6_smooth_ln_fcs_matches_reference():
+    import torch
+    from autosmoothquant_amd.quantize import smooth_ln_fcs
+    from autosmoothquant_amd.harness import RMSNorm
+    for c in goldenio.load_g6():
+        tdt = torch.float16 if c["dt"] == "f16" else torch.float32
+        H = c["ln_w"].size
+        if c["kind"] == "layernorm":
+            ln = torch.nn.LayerNorm(H)
+            ln.bias.data = torch.from_numpy(c["ln_b"].copy())
+        else:
+            ln = RMSNorm(H)
+        ln.weight.data = torch.from_numpy(c["ln_w"].copy())
+        fcs = []
+        for W in c["fcs"]:
+            fc = torch.nn.Linear(H, W.shape[0], bias=False)
+            fc.weight.data = torch.from_numpy(W.copy())
+            fcs.append(fc)
+        ln, fcs = ln.to(tdt), [fc.to(tdt) for fc in fcs]
+        smooth_ln_fcs(ln, fcs if len(fcs) > 1 else fcs[0], torch.from_numpy(c["act"].copy()), c["model_type"], c["alpha"])
+        # elementwise torch ops; pow() may differ in the last place between CPU vector ISAs
+        tol = dict(rtol=2e-3, atol=0) if c["dt"] == "f16" else dict(rtol=2e-6, atol=0)
+        np.testing.assert_allclose(ln.weight.detach().float().numpy(), c["ln_w_out"], **tol)
+        if c["kind"] == "layernorm":
+            np.testing.assert_allclose(ln.bias.detach().float().numpy(), c["ln_b_out"], **tol)
+        for fc, ref in zip(fcs, c["fcs_out"]):
+            np.testing.assert_allclose(fc.weight.detach().float().numpy(), ref, **tol)
+
+
+def test_smooth_ln_fcs_rejects_mismatched_modules():
+    import torch
+    from autosmoothquant_amd.quantize import smooth_ln_fcs
+    ln, fc = torch.nn.LayerNorm(8), torch.nn.Linear(8, 4)
+    with pytest.raises(ValueError):
+        smooth_ln_fcs(ln, fc, torch.ones(7))
+    with pytest.raises(TypeError):
+        smooth_ln_fcs(ln, torch.nn.Identity(), torch.ones(8))
