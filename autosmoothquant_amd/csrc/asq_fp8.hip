@@ -3,114 +3,70 @@
 // quantisers), layers/nn/linear.py:336-369 (easy_fp8_gemm), :373-452 (FP8LinearDynamic),
 // :503-580 (FP8LinearStatic).  The reference has native_fp8_support = False hard-coded and
 // runs a full-precision F.linear on dequantised operands; here the product runs on the fp8
-// matrix cores (v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulate) and the two scales are applied once
-// in the epilogue.
+// matrix cores (v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales, fp32 accumulate) and the two
+// scales are applied once in the epilogue.
 #include "asq_gemm_kernels.h"
 
 namespace asq {
 
-// fp32 -> e4m3fn bits, round-to-nearest-even, unsaturated (values that round past 448 give NaN),
-// bit-identical to tensor.to(torch.float8_e4m3fn) (checked exhaustively in oracle/fp8.py's tests).
-__device__ __forceinline__ uint32_t f32_to_e4m3fn_bits(float f)
+// fp32 -> fp8 bytes: the hardware converts (v_cvt_pk_fp8_f32 = OCP e4m3fn, v_cvt_pk_bf8_f32 = e5m2 on gfx950;
+// round-to-nearest-even; e4m3 overflow -> NaN, e5m2 overflow -> inf with the default MODE.FP16_OVFL = 0).
+// tools/ubench/fp8_cvt_check.hip sweeps ALL 2^32 fp32 inputs against the software encoders that the oracle
+// pins to tensor.to(torch.float8_*): 0 mismatches in every class (in range, overflow boundary, inf, NaN).
+template <bool E5M2> __device__ __forceinline__ uint32_t f8_pack4(float a, float b, float c, float d)
 {
-    const uint32_t u = __float_as_uint(f);
-    const uint32_t sign = (u >> 24) & 0x80u;
-    const uint32_t a = u & 0x7FFFFFFFu;
-    uint32_t r;
-    if (a >= 0x43F00000u) {  // |f| >= 480 (or inf / NaN): above the rounding boundary of the max finite 448
-        r = 0x7Fu;
-    } else if (a < 0x3C800000u) {  // |f| < 2^-6: result is subnormal (or zero): align to 2^-9 steps with an fp32 add (RNE)
-        const float t = __uint_as_float(a) + 16384.0f;  // 2^14: ulp = 2^-9
-        r = __float_as_uint(t) - 0x46800000u;
-    } else {  // normal: rebias exponent (127 -> 7), round mantissa 23 -> 3 bits to nearest even
-        uint32_t v = a - (120u << 23);
-        v += 0x7FFFFu + ((v >> 20) & 1u);
-        r = v >> 20;
-    }
-    return r | sign;
+    if constexpr (E5M2) return (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(c, d, __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false), true);
+    else return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false), true);
 }
-
-// fp32 -> e5m2 bits, round-to-nearest-even, IEEE-like (overflow -> inf), = tensor.to(torch.float8_e5m2)
-__device__ __forceinline__ uint32_t f32_to_e5m2_bits(float f)
-{
-    const uint32_t u = __float_as_uint(f);
-    const uint32_t sign = (u >> 24) & 0x80u;
-    const uint32_t a = u & 0x7FFFFFFFu;
-    uint32_t r;
-    if (a > 0x7F800000u) {  // NaN
-        r = 0x7Fu;
-    } else if (a >= 0x47800000u) {  // |f| >= 65536 = 2^16 (incl. inf): beyond the rounding boundary of 57344
-        r = 0x7Cu;
-    } else if (a < 0x38800000u) {  // |f| < 2^-14: subnormal, ulp 2^-16
-        const float t = __uint_as_float(a) + 128.0f;  // 2^7: ulp = 2^-16
-        r = __float_as_uint(t) - 0x43000000u;
-    } else {
-        uint32_t v = a - (112u << 23);  // rebias 127 -> 15
-        v += 0xFFFFFu + ((v >> 21) & 1u);
-        r = v >> 21;  // may round up to 0x7C = inf, as IEEE
-    }
-    return r | sign;
-}
-
-struct F8CastE5M2 {
-    __device__ __forceinline__ uint32_t operator()(float x) const { return f32_to_e5m2_bits(x); }
-};
+template <bool E5M2> __device__ __forceinline__ uint32_t f8_one(float a) { return f8_pack4<E5M2>(a, a, a, a) & 0xFFu; }
 
 __device__ __forceinline__ float clamp448(float v) { return (v != v) ? v : fminf(fmaxf(v, -448.0f), 448.0f); }
 
+// value functors: the fp32 number that is then cast to fp8
+struct F8CastE5M2 {
+    static constexpr bool kE5M2 = true;
+    __device__ __forceinline__ float operator()(float x) const { return x; }
+};
 template <int DT> struct F8Tok {  // per-token: x / f32 scale promotes to fp32
+    static constexpr bool kE5M2 = false;
     float s;
-    __device__ __forceinline__ uint32_t operator()(float x) const { return f32_to_e4m3fn_bits(clamp448(x / s)); }
+    __device__ __forceinline__ float operator()(float x) const { return clamp448(x / s); }
+};
+// The 5-op division returns +0 for a -0 numerator; fp8 keeps the sign of zero (0x80), and the divisor is
+// positive on the fast path, so the quotient always carries x's sign: copysign restores exactly that case.
+struct F8TokFast {  // same quotient by the exact 5-op row division (asq_common.h RowDivisor)
+    static constexpr bool kE5M2 = false;
+    QRowFast d;
+    __device__ __forceinline__ float operator()(float x) const { return clamp448(__builtin_copysignf(d.div(x), x)); }
 };
 template <int DT> struct F8Div {  // per-tensor (dynamic or static): quotient stays in x's dtype
+    static constexpr bool kE5M2 = false;
     float s;
-    __device__ __forceinline__ uint32_t operator()(float x) const { return f32_to_e4m3fn_bits(clamp448(ElemT<DT>::round(x / s))); }
+    __device__ __forceinline__ float operator()(float x) const { return clamp448(ElemT<DT>::round(x / s)); }
+};
+
+template <int DT> struct F8DivFast {  // F8Div's quotient by the exact 5-op division (all x known finite: dynamic mode with a finite absmax)
+    static constexpr bool kE5M2 = false;
+    QRowFast d;
+    __device__ __forceinline__ float operator()(float x) const { return clamp448(ElemT<DT>::round(__builtin_copysignf(d.div(x), x))); }
 };
 
 template <int DT, class Q> __device__ __forceinline__ void f8_quant_vec(const v4i &v, const Q &q, uint32_t (&o)[2])
 {
     if constexpr (DT == ASQ_F32) {
-        o[0] = q(__int_as_float(v[0])) | (q(__int_as_float(v[1])) << 8) | (q(__int_as_float(v[2])) << 16) | (q(__int_as_float(v[3])) << 24);
+        o[0] = f8_pack4<Q::kE5M2>(q(__int_as_float(v[0])), q(__int_as_float(v[1])), q(__int_as_float(v[2])), q(__int_as_float(v[3])));
         o[1] = 0;
     } else {
-        uint32_t r[8];
+        float r[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t w = (uint32_t)v[i];
             r[2 * i] = q(ElemT<DT>::load((uint16_t)(w & 0xFFFF)));
             r[2 * i + 1] = q(ElemT<DT>::load((uint16_t)(w >> 16)));
         }
-        o[0] = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24);
-        o[1] = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
+        o[0] = f8_pack4<Q::kE5M2>(r[0], r[1], r[2], r[3]);
+        o[1] = f8_pack4<Q::kE5M2>(r[4], r[5], r[6], r[7]);
     }
-}
-
-__device__ __forceinline__ float f8_nanmax(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
-
-template <int DT> __device__ __forceinline__ float f8_vec_absmax(const v4i &v)
-{
-    float m = 0.0f;
-    if constexpr (DT == ASQ_F32) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) m = f8_nanmax(m, fabsf(__int_as_float(v[i])));
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t w = (uint32_t)v[i];
-            m = f8_nanmax(m, fabsf(ElemT<DT>::load((uint16_t)(w & 0xFFFF))));
-            m = f8_nanmax(m, fabsf(ElemT<DT>::load((uint16_t)(w >> 16))));
-        }
-    }
-    return m;
-}
-
-__device__ __forceinline__ float f8_block_max(float m, float *red)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = f8_nanmax(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    return f8_nanmax(f8_nanmax(red[0], red[1]), f8_nanmax(red[2], red[3]));
 }
 
 // per-token: one block per row, two passes over the row (second pass hits L1/L2); any K
@@ -124,44 +80,59 @@ __global__ void __launch_bounds__(256) fp8_quant_per_token(const void *__restric
     const int64_t row = blockIdx.x;
     const T *xrow = (const T *)xv + row * K;
     uint8_t *orow = xq + row * K;
-    float m = 0.0f;
+    uint32_t mb;  // |x| maximum as an fp32 bit pattern (asq_common.h AbsMax: NaN-propagating integer max)
     if (vec) {
-        for (int64_t i = threadIdx.x; i < K / VEC; i += 256) m = f8_nanmax(m, f8_vec_absmax<DT>(*(const v4i *)((const char *)xrow + i * 16)));
+        AbsMax<DT> am;
+        for (int64_t i = threadIdx.x; i < K / VEC; i += 256) am.add(*(const v4i *)((const char *)xrow + i * 16));
+        mb = am.f32bits();
     } else {
-        for (int64_t k = threadIdx.x; k < K; k += 256) m = f8_nanmax(m, fabsf(ElemT<DT>::load(xrow[k])));
+        mb = 0;
+        for (int64_t k = threadIdx.x; k < K; k += 256) mb = umax32(mb, absbits(ElemT<DT>::load(xrow[k])));
     }
-    m = f8_block_max(m, red);
+    const float m = block_absmax_256(mb, red);
     const float s = ElemT<DT>::round(m / 448.0f);  // rowabsmax.div(finfo.max) in x's dtype, then .to(float32)
     if (threadIdx.x == 0) scale[row] = s;
-    F8Tok<DT> q{s};
-    if (vec) {
-        for (int64_t i = threadIdx.x; i < K / VEC; i += 256) {
-            uint32_t o[2];
-            f8_quant_vec<DT>(*(const v4i *)((const char *)xrow + i * 16), q, o);
-            if constexpr (DT == ASQ_F32) *(uint32_t *)(orow + i * 4) = o[0];
-            else *(uint2 *)(orow + i * 8) = make_uint2(o[0], o[1]);
+    auto emit = [&](auto q) {
+        if (vec) {
+            for (int64_t i = threadIdx.x; i < K / VEC; i += 256) {
+                uint32_t o[2];
+                f8_quant_vec<DT>(*(const v4i *)((const char *)xrow + i * 16), q, o);
+                if constexpr (DT == ASQ_F32) *(uint32_t *)(orow + i * 4) = o[0];
+                else *(uint2 *)(orow + i * 8) = make_uint2(o[0], o[1]);
+            }
+        } else {
+            for (int64_t k = threadIdx.x; k < K; k += 256) orow[k] = (uint8_t)f8_one<false>(q(ElemT<DT>::load(xrow[k])));
         }
-    } else {
-        for (int64_t k = threadIdx.x; k < K; k += 256) orow[k] = (uint8_t)q(ElemT<DT>::load(xrow[k]));
-    }
+    };
+    const RowDivisor d(s, m);
+    if (d.fast) emit(F8TokFast{QRowFast{d.s, d.y}});
+    else emit(F8Tok<DT>{s});
 }
 
-// dynamic per-tensor, pass 1: absmax into a device word (non-negative floats order like their bit patterns)
+// dynamic per-tensor, pass 1: absmax into a device word (non-negative floats order like their bit patterns,
+// NaN patterns above +inf: the integer atomicMax propagates NaN as torch's aminmax does)
 template <int DT> __global__ void __launch_bounds__(256) fp8_absmax(const void *__restrict__ xv, int64_t n, bool vec, unsigned *__restrict__ amax_bits)
 {
     using T = typename ElemT<DT>::type;
     constexpr int VEC = ElemT<DT>::VEC;
     __shared__ float red[4];
-    float m = 0.0f;
+    uint32_t mb = 0;
     const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (vec) {
-        for (int64_t i = t0; i < n / VEC; i += stride) m = f8_nanmax(m, f8_vec_absmax<DT>(*((const v4i *)xv + i)));
-        for (int64_t k = (n / VEC) * VEC + t0; k < n; k += stride) m = f8_nanmax(m, fabsf(ElemT<DT>::load(((const T *)xv)[k])));
+        AbsMax<DT> am;
+        for (int64_t i = t0; i < n / VEC; i += stride) am.add(*((const v4i *)xv + i));
+        mb = am.f32bits();
+        for (int64_t k = (n / VEC) * VEC + t0; k < n; k += stride) mb = umax32(mb, absbits(ElemT<DT>::load(((const T *)xv)[k])));
     } else {
-        for (int64_t k = t0; k < n; k += stride) m = f8_nanmax(m, fabsf(ElemT<DT>::load(((const T *)xv)[k])));
+        for (int64_t k = t0; k < n; k += stride) mb = umax32(mb, absbits(ElemT<DT>::load(((const T *)xv)[k])));
     }
-    m = f8_block_max(m, red);
-    if (threadIdx.x == 0) atomicMax(amax_bits, __float_as_uint(m));  // NaN (0x7fc00000) also wins, as torch's aminmax propagates it
+    const float m = block_absmax_256(mb, red);
+    // 4096 blocks hammering one word serialise in L2 (measured: ~45 us of a 65 us call).  Only record-breakers
+    // need the atomic: a possibly stale (lower) peek merely costs a redundant atomicMax
+    if (threadIdx.x == 0) {
+        const unsigned mine = __float_as_uint(m);
+        if (mine > __hip_atomic_load(amax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_bits, mine);
+    }
 }
 
 // per-tensor pass 2 (and the static mode): scale from the device word or the host value
@@ -171,22 +142,29 @@ __global__ void __launch_bounds__(256) fp8_quant_per_tensor(const void *__restri
 {
     using T = typename ElemT<DT>::type;
     constexpr int VEC = ElemT<DT>::VEC;
-    float s = host_scale;
-    if (amax_bits) s = ElemT<DT>::round(__uint_as_float(*amax_bits) / 448.0f);  // amax / finfo.max in x's dtype
-    if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
-    F8Div<DT> q{s};
-    const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (vec) {
-        for (int64_t i = t0; i < n / VEC; i += stride) {
-            uint32_t o[2];
-            f8_quant_vec<DT>(*((const v4i *)xv + i), q, o);
-            if constexpr (DT == ASQ_F32) *((uint32_t *)xq + i) = o[0];
-            else *((uint2 *)xq + i) = make_uint2(o[0], o[1]);
-        }
-        for (int64_t k = (n / VEC) * VEC + t0; k < n; k += stride) xq[k] = (uint8_t)q(ElemT<DT>::load(((const T *)xv)[k]));
-    } else {
-        for (int64_t k = t0; k < n; k += stride) xq[k] = (uint8_t)q(ElemT<DT>::load(((const T *)xv)[k]));
+    float s = host_scale, amax = __builtin_inff();  // static mode: nothing is known about x -> plain division
+    if (amax_bits) {
+        amax = __uint_as_float(*amax_bits);
+        s = ElemT<DT>::round(amax / 448.0f);  // amax / finfo.max in x's dtype
     }
+    if (scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
+    const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    auto emit = [&](auto q) {
+        if (vec) {
+            for (int64_t i = t0; i < n / VEC; i += stride) {
+                uint32_t o[2];
+                f8_quant_vec<DT>(*((const v4i *)xv + i), q, o);
+                if constexpr (DT == ASQ_F32) *((uint32_t *)xq + i) = o[0];
+                else *((uint2 *)xq + i) = make_uint2(o[0], o[1]);
+            }
+            for (int64_t k = (n / VEC) * VEC + t0; k < n; k += stride) xq[k] = (uint8_t)f8_one<false>(q(ElemT<DT>::load(((const T *)xv)[k])));
+        } else {
+            for (int64_t k = t0; k < n; k += stride) xq[k] = (uint8_t)f8_one<false>(q(ElemT<DT>::load(((const T *)xv)[k])));
+        }
+    };
+    const RowDivisor d(s, amax);
+    if (d.fast) emit(F8DivFast<DT>{QRowFast{d.s, d.y}});
+    else emit(F8Div<DT>{s});
 }
 
 template <int DT>
@@ -241,9 +219,9 @@ template <int DT> __global__ void __launch_bounds__(256) cast_e5m2_kernel(const 
             if constexpr (DT == ASQ_F32) *((uint32_t *)xq + i) = o[0];
             else *((uint2 *)xq + i) = make_uint2(o[0], o[1]);
         }
-        for (int64_t k = (n / VEC) * VEC + t0; k < n; k += stride) xq[k] = (uint8_t)q(ElemT<DT>::load(((const T *)xv)[k]));
+        for (int64_t k = (n / VEC) * VEC + t0; k < n; k += stride) xq[k] = (uint8_t)f8_one<true>(q(ElemT<DT>::load(((const T *)xv)[k])));
     } else {
-        for (int64_t k = t0; k < n; k += stride) xq[k] = (uint8_t)q(ElemT<DT>::load(((const T *)xv)[k]));
+        for (int64_t k = t0; k < n; k += stride) xq[k] = (uint8_t)f8_one<true>(q(ElemT<DT>::load(((const T *)xv)[k])));
     }
 }
 

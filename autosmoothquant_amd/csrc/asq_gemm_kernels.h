@@ -51,20 +51,44 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef long v2l __attribute__((ext_vector_type(2)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
+typedef int v8i __attribute__((ext_vector_type(8)));
+
+// mma():  one step over 16 k-bytes per lane.   mma2(): two consecutive steps (32 k-bytes per lane) -- the
+// form the tiled kernels use for fp8 so that it can run on the K = 64 block-scaled instruction.
 struct MmaI8 {  // int8 x int8 -> int32, exact: one v_mfma_i32_32x32x32_i8
     using acc_t = v16i;
     using acc4_t = v4i;
     static constexpr bool kIsInt = true;
+    static __device__ __forceinline__ acc_t mma2(const v4i &a0, const v4i &a1, const v4i &b0, const v4i &b1, const acc_t &c)
+    {
+        return mma(a1, b1, mma(a0, b0, c));  // (the tiled kernels keep their own per-step issue order for int8)
+    }
     static __device__ __forceinline__ acc_t mma(const v4i &a, const v4i &b, const acc_t &c)
     {
         return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
     }
 };
 
-struct MmaFp8 {  // OCP e4m3fn x e4m3fn -> fp32: two v_mfma_f32_32x32x16_fp8_fp8 on the low / high 8 k-bytes
+// fp8 at full rate: the non-scaled v_mfma_f32_32x32x16_fp8_fp8 runs at the bf16 rate on gfx950; only the
+// block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 reaches the fp8 peak.  With both E8M0 scales = 127 (2^0) it is
+// the plain fp8 product sum; A and B fragments use the same (lane-half, byte) -> k assignment, so feeding two
+// consecutive 16-byte fragments as the 32-byte operand pairs every k-byte with its partner.
+template <int FMT>  // 0 = e4m3fn, 1 = e5m2 (cbsz / blgp encoding)
+__device__ __forceinline__ v16f mma_fp8_k64(const v4i &a0, const v4i &a1, const v4i &b0, const v4i &b1, const v16f &c)
+{
+    const v8i A = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    const v8i B = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, FMT, FMT, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
+struct MmaFp8 {  // OCP e4m3fn x e4m3fn -> fp32
     using acc_t = v16f;
     using acc4_t = v4f;
     static constexpr bool kIsInt = false;
+    static __device__ __forceinline__ acc_t mma2(const v4i &a0, const v4i &a1, const v4i &b0, const v4i &b1, const acc_t &c)
+    {
+        return mma_fp8_k64<0>(a0, a1, b0, b1, c);
+    }
     static __device__ __forceinline__ acc_t mma(const v4i &a, const v4i &b, const acc_t &c)
     {
         const v2l al = __builtin_bit_cast(v2l, a), bl = __builtin_bit_cast(v2l, b);
@@ -77,6 +101,10 @@ struct MmaBf8 {  // OCP e5m2 x e5m2 -> fp32
     using acc_t = v16f;
     using acc4_t = v4f;
     static constexpr bool kIsInt = false;
+    static __device__ __forceinline__ acc_t mma2(const v4i &a0, const v4i &a1, const v4i &b0, const v4i &b1, const acc_t &c)
+    {
+        return mma_fp8_k64<1>(a0, a1, b0, b1, c);
+    }
     static __device__ __forceinline__ acc_t mma(const v4i &a, const v4i &b, const acc_t &c)
     {
         const v2l al = __builtin_bit_cast(v2l, a), bl = __builtin_bit_cast(v2l, b);

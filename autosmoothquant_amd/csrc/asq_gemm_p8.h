@@ -70,6 +70,16 @@ template <int ABL, class MMA> __device__ __forceinline__ typename MMA::acc_t p8_
         return MMA::mma(a, b, c);
     }
 }
+template <int ABL, class MMA>
+__device__ __forceinline__ typename MMA::acc_t p8_mfma2(const v4i &a0, const v4i &a1, const v4i &b0, const v4i &b1, const typename MMA::acc_t &c)
+{
+    if constexpr (ABL & 4) {
+        asm volatile("" ::"v"(a0), "v"(a1), "v"(b0), "v"(b1));  // keep the fragment loads alive
+        return c;
+    } else {
+        return MMA::mma2(a0, a1, b0, b1, c);
+    }
+}
 typedef const __attribute__((address_space(3))) v4i *p8_lds_v4i;
 template <int ABL> __device__ __forceinline__ v4i p8_ldfrag(unsigned lds_addr, int lane)
 {
@@ -239,10 +249,17 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(5);
         P8_PRIO(1);
+if constexpr (MMA::kIsInt) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[0][0][j] = p8_mfma<ABL, MMA>(wa[ks], xf[j][ks], acc[0][0][j]);
+                for (int j = 0; j < 2; ++j) acc[0][0][j] = p8_mfma<ABL, MMA>(wa[ks], xf[j][ks], acc[0][0][j]);
+        } else {  // fp8: K = 64 block-scaled instruction over two consecutive fragments
+#pragma unroll
+            for (int kp = 0; kp < 4; kp += 2)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[0][0][j] = p8_mfma2<ABL, MMA>(wa[kp], wa[kp + 1], xf[j][kp], xf[j][kp + 1], acc[0][0][j]);
+        }
         P8_PRIO(0);
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(6);
@@ -265,10 +282,17 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(5);
         P8_PRIO(1);
+if constexpr (MMA::kIsInt) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[0][1][j] = p8_mfma<ABL, MMA>(wb[ks], xf[j][ks], acc[0][1][j]);
+                for (int j = 0; j < 2; ++j) acc[0][1][j] = p8_mfma<ABL, MMA>(wb[ks], xf[j][ks], acc[0][1][j]);
+        } else {  // fp8: K = 64 block-scaled instruction over two consecutive fragments
+#pragma unroll
+            for (int kp = 0; kp < 4; kp += 2)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[0][1][j] = p8_mfma2<ABL, MMA>(wb[kp], wb[kp + 1], xf[j][kp], xf[j][kp + 1], acc[0][1][j]);
+        }
         P8_PRIO(0);
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(6);
@@ -292,10 +316,17 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(5);
         P8_PRIO(1);
+if constexpr (MMA::kIsInt) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[1][1][j] = p8_mfma<ABL, MMA>(wb[ks], xf[j][ks], acc[1][1][j]);
+                for (int j = 0; j < 2; ++j) acc[1][1][j] = p8_mfma<ABL, MMA>(wb[ks], xf[j][ks], acc[1][1][j]);
+        } else {  // fp8: K = 64 block-scaled instruction over two consecutive fragments
+#pragma unroll
+            for (int kp = 0; kp < 4; kp += 2)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[1][1][j] = p8_mfma2<ABL, MMA>(wb[kp], wb[kp + 1], xf[j][kp], xf[j][kp + 1], acc[1][1][j]);
+        }
         P8_PRIO(0);
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(6);
@@ -315,10 +346,17 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(5);
         P8_PRIO(1);
+if constexpr (MMA::kIsInt) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[1][0][j] = p8_mfma<ABL, MMA>(wa[ks], xf[j][ks], acc[1][0][j]);
+                for (int j = 0; j < 2; ++j) acc[1][0][j] = p8_mfma<ABL, MMA>(wa[ks], xf[j][ks], acc[1][0][j]);
+        } else {  // fp8: K = 64 block-scaled instruction over two consecutive fragments
+#pragma unroll
+            for (int kp = 0; kp < 4; kp += 2)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[1][0][j] = p8_mfma2<ABL, MMA>(wa[kp], wa[kp + 1], xf[j][kp], xf[j][kp + 1], acc[1][0][j]);
+        }
         P8_PRIO(0);
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(6);

@@ -131,10 +131,17 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8h(const int8_t *__restrict__
         P8_WAIT_LGKM0();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
+if constexpr (MMA::kIsInt) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[0][j] = MMA::mma(wf[ks], xf[j][ks], acc[0][j]);
+                for (int j = 0; j < 2; ++j) acc[0][j] = MMA::mma(wf[ks], xf[j][ks], acc[0][j]);
+        } else {  // fp8: K = 64 block-scaled instruction over two consecutive fragments
+#pragma unroll
+            for (int kp = 0; kp < 4; kp += 2)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[0][j] = MMA::mma2(wf[kp], wf[kp + 1], xf[j][kp], xf[j][kp + 1], acc[0][j]);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -148,10 +155,17 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8h(const int8_t *__restrict__
         P8_WAIT_LGKM0();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
+if constexpr (MMA::kIsInt) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[1][j] = MMA::mma(wf[ks], xf[j][ks], acc[1][j]);
+                for (int j = 0; j < 2; ++j) acc[1][j] = MMA::mma(wf[ks], xf[j][ks], acc[1][j]);
+        } else {  // fp8: K = 64 block-scaled instruction over two consecutive fragments
+#pragma unroll
+            for (int kp = 0; kp < 4; kp += 2)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[1][j] = MMA::mma2(wf[kp], wf[kp + 1], xf[j][kp], xf[j][kp + 1], acc[1][j]);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();

@@ -21,33 +21,6 @@ template <int DT> struct QDivF32 {  // x / f32 tensor promotes to fp32
     __device__ __forceinline__ int operator()(float x) const { return quant_i8(x / s); }
 };
 
-// The IEEE quotient RN(x / s) for a divisor shared by a whole row, in 5 VALU ops instead of the
-// ~11 of the generic expansion (which re-derives 1/s per element; the per-token kernels were
-// issue-bound on it).  Markstein's sequence: y = RN(1/s) by ONE true division per row, then
-//     q0 = RN(x*y); r0 = x - s*q0 (exact, fma); q1 = RN(q0 + r0*y)   -> faithful
-//     r1 = x - s*q1 (exact, fma);               q2 = RN(q1 + r1*y)   -> correctly rounded
-// Valid when x is finite and nothing over-/underflows: `fast` (block-uniform) requires a finite row
-// maximum and 2^-60 < s < 2^60 (then |x/s| <= 127.5 and every remainder is a normal number or exactly
-// 0); other rows take the plain division.  A -0 numerator comes back as +0, which quantises to the same 0.
-// Checked bit-for-bit against x / s on 2 x 10^11 operand pairs incl. all near-half-integer quotients
-// (tools/ubench/exact_div_check.hip: 0 mismatches).
-struct RowDivisor {
-    float s, y;
-    bool fast;
-    __device__ __forceinline__ RowDivisor(float s_, float row_absmax)
-        : s(s_), y(1.0f / s_), fast(row_absmax < 3.0e38f && s_ > 0x1p-60f && s_ < 0x1p60f) {}
-};
-struct QRowFast {
-    float s, y;
-    __device__ __forceinline__ float div(float x) const
-    {
-        const float q0 = __fmul_rn(x, y);
-        const float q1 = __fmaf_rn(__fmaf_rn(-s, q0, x), y, q0);
-        return __fmaf_rn(__fmaf_rn(-s, q1, x), y, q1);
-    }
-    __device__ __forceinline__ int operator()(float x) const { return quant_i8(div(x)); }
-};
-
 __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d)
 {
     return (uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) | ((uint32_t)(d & 0xFF) << 24);
@@ -70,48 +43,6 @@ template <int DT, class Q> __device__ __forceinline__ void quant_vec(const v4i &
         o[0] = pack4(r[0], r[1], r[2], r[3]);
         o[1] = pack4(r[4], r[5], r[6], r[7]);
     }
-}
-
-// |x| maximum with torch.max's NaN propagation, carried as BIT PATTERNS: for non-negative IEEE values
-// (fp32, fp16 and bf16 alike) the unsigned-integer order of the patterns IS the numeric order, and every
-// NaN pattern lies above +inf.  One v_and + one integer max per element (a packed pair for the 16-bit
-// types) instead of a compare/select chain.  (Measured: the chain made the fp16 per-token quantiser
-// issue-bound, 238 us for 65536 x 4096 against 157 us for the per-tensor kernel.)
-typedef unsigned short v2us __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)
-{
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2us, a), __builtin_bit_cast(v2us, b)));
-}
-__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
-__device__ __forceinline__ uint32_t absbits(float x) { return __float_as_uint(x) & 0x7FFFFFFFu; }
-
-template <int DT> struct AbsMax {  // running |x| maximum of raw DT vectors
-    uint32_t acc = 0;              // fp32: |bits|;  16-bit types: two packed 15-bit patterns
-    __device__ __forceinline__ void add(const v4i &v)
-    {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if constexpr (DT == ASQ_F32) acc = umax32(acc, (uint32_t)v[i] & 0x7FFFFFFFu);
-            else acc = pk_max_u16(acc, (uint32_t)v[i] & 0x7FFF7FFFu);
-        }
-    }
-    __device__ __forceinline__ uint32_t f32bits() const  // the maximum as an fp32 bit pattern (widening 16-bit -> fp32 is monotonic, NaN stays NaN)
-    {
-        if constexpr (DT == ASQ_F32) return acc;
-        else return __float_as_uint(ElemT<DT>::load((uint16_t)umax32(acc & 0xFFFFu, acc >> 16)));
-    }
-};
-
-// block-wide maximum of fp32 |x| bit patterns (256 threads) -> float (NaN if any NaN)
-__device__ __forceinline__ float block_absmax_256(uint32_t m, float *red_f)
-{
-    uint32_t *red = (uint32_t *)red_f;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = umax32(m, (uint32_t)__shfl_xor((int)m, off, 64));
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) red[wave] = m;
-    __syncthreads();
-    return __uint_as_float(umax32(umax32(red[0], red[1]), umax32(red[2], red[3])));
 }
 
 // ---- per-token: one 256-thread block per row, row cached in registers ---------------

@@ -44,6 +44,7 @@ def test_fp8_quantisers_bit_exact(dt, shape, dev):
     M, K = shape
     x = O.round_to(detrng.act_like(201, M + K, (M, K), scale=3.0), dt)
     x[M // 2, K // 3] = 900.0
+    x[0, 1], x[M - 1, K - 1] = -0.0, -0.0   # fp8 keeps the sign of zero (0x80)
     if M > 2:
         x[1] = 0.0   # zero row: per-token scale 0 -> 0/0 -> NaN codes, as the reference
     xt = t_in(x, dt, dev)
