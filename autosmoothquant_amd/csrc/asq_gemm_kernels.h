@@ -63,6 +63,11 @@ struct MmaI8 {  // int8 x int8 -> int32, exact: one v_mfma_i32_32x32x32_i8
     {
         return mma(a1, b1, mma(a0, b0, c));  // (the tiled kernels keep their own per-step issue order for int8)
     }
+    // 16x16 tile, 32 k-bytes per lane (the weight-streaming kernel's unit): two v_mfma_i32_16x16x64_i8
+    static __device__ __forceinline__ acc4_t mma16(const v4i &a0, const v4i &a1, const v4i &b0, const v4i &b1, const acc4_t &c)
+    {
+        return __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, c, 0, 0, 0), 0, 0, 0);
+    }
     static __device__ __forceinline__ acc_t mma(const v4i &a, const v4i &b, const acc_t &c)
     {
         return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
@@ -73,6 +78,13 @@ struct MmaI8 {  // int8 x int8 -> int32, exact: one v_mfma_i32_32x32x32_i8
 // block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 reaches the fp8 peak.  With both E8M0 scales = 127 (2^0) it is
 // the plain fp8 product sum; A and B fragments use the same (lane-half, byte) -> k assignment, so feeding two
 // consecutive 16-byte fragments as the 32-byte operand pairs every k-byte with its partner.
+template <int FMT> __device__ __forceinline__ v4f mma_fp8_16x16_k128(const v4i &a0, const v4i &a1, const v4i &b0, const v4i &b1, const v4f &c)
+{
+    const v8i A = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    const v8i B = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, c, FMT, FMT, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
 template <int FMT>  // 0 = e4m3fn, 1 = e5m2 (cbsz / blgp encoding)
 __device__ __forceinline__ v16f mma_fp8_k64(const v4i &a0, const v4i &a1, const v4i &b0, const v4i &b1, const v16f &c)
 {
@@ -89,6 +101,10 @@ struct MmaFp8 {  // OCP e4m3fn x e4m3fn -> fp32
     {
         return mma_fp8_k64<0>(a0, a1, b0, b1, c);
     }
+    static __device__ __forceinline__ acc4_t mma16(const v4i &a0, const v4i &a1, const v4i &b0, const v4i &b1, const acc4_t &c)
+    {
+        return mma_fp8_16x16_k128<0>(a0, a1, b0, b1, c);
+    }
     static __device__ __forceinline__ acc_t mma(const v4i &a, const v4i &b, const acc_t &c)
     {
         const v2l al = __builtin_bit_cast(v2l, a), bl = __builtin_bit_cast(v2l, b);
@@ -104,6 +120,10 @@ struct MmaBf8 {  // OCP e5m2 x e5m2 -> fp32
     static __device__ __forceinline__ acc_t mma2(const v4i &a0, const v4i &a1, const v4i &b0, const v4i &b1, const acc_t &c)
     {
         return mma_fp8_k64<1>(a0, a1, b0, b1, c);
+    }
+    static __device__ __forceinline__ acc4_t mma16(const v4i &a0, const v4i &a1, const v4i &b0, const v4i &b1, const acc4_t &c)
+    {
+        return mma_fp8_16x16_k128<1>(a0, a1, b0, b1, c);
     }
     static __device__ __forceinline__ acc_t mma(const v4i &a, const v4i &b, const acc_t &c)
     {
@@ -733,7 +753,6 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
     }
     constexpr bool kInt = Epi::Mma::kIsInt;
     GemmKernel kern = pick_kernel(x, w, M, N, K);
-    if (!kInt && kern == KERN_SKINNY) kern = KERN_P8;  // fp8: no weight-streaming variant yet
     if (kern == KERN_P8) {
         const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
         ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
@@ -786,10 +805,8 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
         }
         hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8H_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, epi);
     } else if (kern == KERN_SKINNY) {
-        if constexpr (kInt) {
-            const int rc = launch_skinny(x, w, M, N, K, epi, s);
-            if (rc) return rc;
-        }
+        const int rc = launch_skinny(x, w, M, N, K, epi, s);
+        if (rc) return rc;
     } else {
         const bool fast = (K % 16 == 0) && (((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0);
         dim3 grid((unsigned)((N + GEN_T - 1) / GEN_T), (unsigned)((M + GEN_T - 1) / GEN_T));

@@ -4,7 +4,8 @@
 //
 // Decomposition: one block of `wpb` waves per 16 output channels (grid-stride over channel tiles);
 // the waves split K in 128-byte units (wave v takes units v, v+wpb, ...).  Each unit is
-// 2 x v_mfma_i32_16x16x64_i8 per 16-token tile (W rows = matrix-core A operand, X rows = B operand).
+// 2 x v_mfma_i32_16x16x64_i8 per 16-token tile (W rows = matrix-core A operand, X rows = B operand);
+// fp8 operands run the same schedule with one v_mfma_scale_f32_16x16x128_f8f6f4 (unit scales) per unit.
 //
 // Both operands travel HBM/L2 -> LDS by LDS-DMA in FULL 128-byte lines (8 rows x 128 B per
 // wave-instruction) into a WAVE-PRIVATE 3-stage ring, and are read back as MFMA fragments with
@@ -64,7 +65,9 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
     const unsigned ring = lds0 + wave * SK_STAGES * UNIT;
-    v4i *const red = (v4i *)(lds + wpb * SK_STAGES * UNIT);  // [wpb][MT][64]
+    using MMA = typename Epi::Mma;
+    using acc4_t = typename MMA::acc4_t;  // v4i (int8: exact, order-free) or v4f (fp8: waves summed in a fixed order)
+    acc4_t *const red = (acc4_t *)(lds + wpb * SK_STAGES * UNIT);  // [wpb][MT][64]
 
     const int nunits = (int)(K / 128);
     const int upt = nunits > wave ? (nunits - wave + wpb - 1) / wpb : 0;  // this wave's units per tile
@@ -139,23 +142,23 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
         }
     };
 
-    v4i acc[MT];
+    acc4_t acc[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4i){0, 0, 0, 0};
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (acc4_t){0, 0, 0, 0};
 
     int done = 0, c_u = 0, c_tile = 0;
     auto tile_end = [&]() {  // block-wide: sum the wpb partials of this channel tile, fused epilogue
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             red[(wave * MT + mt) * 64 + lane] = acc[mt];
-            acc[mt] = (v4i){0, 0, 0, 0};
+            acc[mt] = (acc4_t){0, 0, 0, 0};
         }
         __syncthreads();
         int64_t n0;
         int mb;
         decode(c_tile, n0, mb);
         for (int mt = wave; mt < MT; mt += wpb) {
-            v4i s = red[mt * 64 + lane];
+            acc4_t s = red[mt * 64 + lane];
             for (int v = 1; v < wpb; ++v) s += red[(v * MT + mt) * 64 + lane];
             const int64_t m = (int64_t)mb * (MT * 16) + mt * 16 + fr, n = n0 + 4 * fg;
             if (m < M && n < N) {
@@ -183,10 +186,15 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) xf[mt][h] = *(const __attribute__((address_space(3))) v4i *)(uintptr_t)(faddr[S][h] + (1 + mt) * 2048);
         }
+        if constexpr (MMA::kIsInt) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[h], xf[mt][h], acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[h], xf[mt][h], acc[mt], 0, 0, 0);
+        } else {  // fp8: one K = 128 block-scaled instruction (unit scales) over both halves of the unit
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = MMA::mma16(wf[0], wf[1], xf[mt][0], xf[mt][1], acc[mt]);
+        }
         ++done;
         if (++c_u == upt) {
             c_u = 0;
