@@ -629,12 +629,12 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
     if (tiled_ok && (f == KERN_P8 || f == KERN_P8H)) return (GemmKernel)f;
     if (tiled_ok && M <= 1024 && f == KERN_SKINNY) return KERN_SKINNY;
     if (tiled_ok && f < 0) {
-        // measured crossover (tools/kbench.py grid, 16..512 rows x 9 LLaMA/OPT weight shapes): the
-        // weight-streaming kernel re-reads X from L2 once per 16 channels, so it wins while the
-        // (channel tile, 64-row block) items all fit on the chip at once and the total work is small
-        const int64_t items = ((N + 15) / 16) * ((M + 63) / 64);
+        // measured crossover (tools/cold_grid.sh: 48..256 rows x 8 LLaMA/OPT/Mixtral weight shapes, weights rotated
+        // through > 256 MiB so they come from HBM, not the Infinity Cache): the weight-streaming kernel re-reads X
+        // from L2 once per 16 (or 32) channels, so it wins while the total work N*K*M stays small; wide-N
+        // weights (11008x4096, 14336x4096, 20480x5120) stay ahead longer than square or long-K ones
         const double work = (double)N * (double)K * (double)M;
-        if ((M <= 64 || items <= 1024) && work <= 4.0e9) return KERN_SKINNY;
+        if (work <= (N > 2 * K ? 5.8e9 : 4.0e9)) return KERN_SKINNY;
         // 128-row tiles when the 256-row tiling cannot fill 256 CUs (or wastes half a tile row).  Measured
         // (tools/ksplit_sweep.sh): p8h is ~14 % slower per op on a full chip but wins up to 1.45x below ~144 tiles
         const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
@@ -694,12 +694,12 @@ static inline int pick_ksplit_p8h(int64_t tiles, int64_t K, int64_t M, int64_t N
     return s < 1 ? 1 : (int)s;
 }
 
-template <class Epi, int MT> int launch_skinny_mt(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, int mblocks, const Epi &epi, hipStream_t s)
+template <class Epi, int MT, int NT> int launch_skinny_mt(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, int mblocks, const Epi &epi, hipStream_t s)
 {
     constexpr int64_t LDS_CU = 160 * 1024;
-    const int64_t ntiles = (N + 15) / 16;
+    const int64_t ntiles = (N + 16 * NT - 1) / (16 * NT);
     const int64_t nitems = ((ntiles + 7) / 8) * 8 * mblocks;  // tiles padded to groups of 8 so m-blocks of a tile share an XCD
-    const int64_t perwave = SK_STAGES * (1 + MT) * 2048 + MT * 1024;  // DMA ring + reduction slot
+    const int64_t perwave = SK_STAGES * (NT + MT) * 2048 + NT * MT * 1024;  // DMA ring + reduction slot
     // the most waves per block (K parallelism inside a work item) that still gives EVERY item a resident block
     int wpb = 8;
     while (wpb > 1 && (wpb * perwave > LDS_CU || 256 * (LDS_CU / (wpb * perwave)) < nitems)) wpb >>= 1;
@@ -710,7 +710,7 @@ template <class Epi, int MT> int launch_skinny_mt(const int8_t *x, const int8_t 
     int64_t grid = 256 * per_cu;   // persistent beyond that: blocks walk the items grid-stride
     if (grid > nitems) grid = nitems;
     const size_t lds = (size_t)(wpb * perwave);
-    auto kfn = gemm_i8_skinny<Epi, MT>;
+    auto kfn = gemm_i8_skinny<Epi, MT, NT>;
     hipError_t e = ensure_dynamic_lds((const void *)kfn, (int)lds);
     if (e != hipSuccess) {
         asq_set_error("skinny: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -724,12 +724,21 @@ template <class Epi> int launch_skinny(const int8_t *x, const int8_t *w, int64_t
 {
     const int mblocks = (int)((M + 63) / 64);                       // m-blocks of <= 64 rows, balanced
     const int mt = (int)(((M + mblocks - 1) / mblocks + 15) / 16);  // 16-row tiles per m-block
+    // 32 channels per item halve the X re-reads from L2.  Measured (tools/ubench/skinny_probe, ASQ_SK_NT=1|2, M = 32):
+    // 14336x4096 16.8 -> 15.5 us, 20480x5120 29.5 -> 26.3, 5120x20480 40.9 -> 31.7; but 8192x8192 18.0 -> 20.6 and
+    // 4096x11008 13.1 -> 15.5 (too few items), 11008x4096 unchanged: only with plenty of items, or a long K
+    static int nt_forced = -1;
+    if (nt_forced < 0) { const char *e = getenv("ASQ_SK_NT"); nt_forced = e ? atoi(e) : 0; }
+    const int64_t items2 = ((N + 31) / 32) * mblocks;
+    const bool wide = nt_forced ? nt_forced == 2 : (items2 >= 448 || (K >= 16384 && items2 >= 128));
+#define ASQ_SK(MT_) (wide ? launch_skinny_mt<Epi, MT_, 2>(x, w, M, N, K, mblocks, epi, s) : launch_skinny_mt<Epi, MT_, 1>(x, w, M, N, K, mblocks, epi, s))
     switch (mt) {
-    case 1: return launch_skinny_mt<Epi, 1>(x, w, M, N, K, mblocks, epi, s);
-    case 2: return launch_skinny_mt<Epi, 2>(x, w, M, N, K, mblocks, epi, s);
-    case 3: return launch_skinny_mt<Epi, 3>(x, w, M, N, K, mblocks, epi, s);
-    default: return launch_skinny_mt<Epi, 4>(x, w, M, N, K, mblocks, epi, s);
+    case 1: return ASQ_SK(1);
+    case 2: return ASQ_SK(2);
+    case 3: return ASQ_SK(3);
+    default: return ASQ_SK(4);
     }
+#undef ASQ_SK
 }
 
 template <class Epi>

@@ -54,33 +54,36 @@ template <int N> __device__ __forceinline__ void sk_wait_vm()
 }
 #undef SK_VM_CASE
 
-template <class Epi, int MT>  // MT = 16-row token tiles per m-block (1..4)
+// MT = 16-row token tiles per m-block (1..4); NT = 16-channel tiles per work item (1 or 2).  NT = 2 halves the
+// number of items that each re-read the X rows from L2 (the kernel's bound once N is large): the launcher
+// picks it when there are still >= 256 items.
+template <class Epi, int MT, int NT>
 __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
                                                       int wpb, int mblocks, Epi epi)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int UNIT = (1 + MT) * 2048;  // one 128-byte K unit: 16 W rows + MT x 16 X rows
-    constexpr int D = 2 * (1 + MT);        // DMA instructions per unit per wave
+    constexpr int UNIT = (NT + MT) * 2048;  // one 128-byte K unit: NT x 16 W rows + MT x 16 X rows
+    constexpr int D = 2 * (NT + MT);        // DMA instructions per unit per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
     const unsigned ring = lds0 + wave * SK_STAGES * UNIT;
     using MMA = typename Epi::Mma;
     using acc4_t = typename MMA::acc4_t;  // v4i (int8: exact, order-free) or v4f (fp8: waves summed in a fixed order)
-    acc4_t *const red = (acc4_t *)(lds + wpb * SK_STAGES * UNIT);  // [wpb][MT][64]
+    acc4_t *const red = (acc4_t *)(lds + wpb * SK_STAGES * UNIT);  // [wpb][NT][MT][64]
 
     const int nunits = (int)(K / 128);
     const int upt = nunits > wave ? (nunits - wave + wpb - 1) / wpb : 0;  // this wave's units per tile
     // work item i of this block = global item (blockIdx.x + i * gridDim.x) -> (channel tile, m-block);
     // items g and g+8 (same XCD under round-robin dispatch) are the m-blocks of one tile
-    const int64_t nitems = (((N + 15) / 16 + 7) / 8) * 8 * mblocks;  // tiles padded to groups of 8 (padding items store nothing)
+    const int64_t nitems = (((N + 16 * NT - 1) / (16 * NT) + 7) / 8) * 8 * mblocks;  // tiles padded to groups of 8 (padding items store nothing)
     const int my_tiles = (int)((nitems - blockIdx.x + gridDim.x - 1) / gridDim.x);
     const int total = my_tiles * upt;  // (item, unit) pairs of this wave, item-major
     auto decode = [&](int i, int64_t &n0, int &mb) {
         const int64_t gidx = (int64_t)blockIdx.x + (int64_t)i * gridDim.x;
         const int64_t grp = gidx / (8 * mblocks), rem = gidx - grp * (8 * mblocks);
         mb = (int)(rem >> 3);
-        n0 = (grp * 8 + (rem & 7)) * 16;
+        n0 = (grp * 8 + (rem & 7)) * (16 * NT);
     };
 
     // ---- DMA lane mapping: instruction i of a 16-row tile covers rows 8i .. 8i+7, 128 B each;
@@ -100,7 +103,7 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
 
     // issue cursor (runs two items ahead of the consume cursor)
     int it_tile = 0, it_u = 0, issued = 0;
-    unsigned woff[2] = {0, 0};
+    unsigned woff[NT][2];
     int cur_item = -1;
     int64_t it_n0 = 0;
     auto issue = [&](int stage) {
@@ -108,13 +111,15 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
             cur_item = it_tile;
             int mb;
             decode(it_tile, it_n0, mb);
-            if (it_n0 >= N) it_n0 = ((N - 1) / 16) * 16;  // padding item of the last 8-tile group: harmless reload
+            if (it_n0 >= N) it_n0 = ((N - 1) / (16 * NT)) * (16 * NT);  // padding item of the last 8-tile group: harmless reload
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int64_t r = 8 * i + rr;
-                r = (it_n0 + r) < N ? r : (N - 1 - it_n0);
-                woff[i] = (unsigned)(r * K) + (unsigned)((cp ^ (((8 * i + rr) >> 1) & 7)) << 4);
-            }
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    int64_t r = nt * 16 + 8 * i + rr;
+                    r = (it_n0 + r) < N ? r : (N - 1 - it_n0);
+                    woff[nt][i] = (unsigned)(r * K) + (unsigned)((cp ^ (((8 * i + rr) >> 1) & 7)) << 4);
+                }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -130,11 +135,13 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
         const int8_t *xb = uniform_ptr(x + (int64_t)u * 128);
         const unsigned dst = ring + stage * UNIT;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) sk_dma16(wb, woff[i], dst + i * 1024);
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) sk_dma16(wb, woff[nt][i], dst + nt * 2048 + i * 1024);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) sk_dma16(xb, xoff[mt][i], dst + (1 + mt) * 2048 + i * 1024);
+            for (int i = 0; i < 2; ++i) sk_dma16(xb, xoff[mt][i], dst + (NT + mt) * 2048 + i * 1024);
         ++issued;
         if (++it_u == upt) {
             it_u = 0;
@@ -142,25 +149,30 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
         }
     };
 
-    acc4_t acc[MT];
+    acc4_t acc[NT][MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = (acc4_t){0, 0, 0, 0};
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (acc4_t){0, 0, 0, 0};
 
     int done = 0, c_u = 0, c_tile = 0;
     auto tile_end = [&]() {  // block-wide: sum the wpb partials of this channel tile, fused epilogue
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            red[(wave * MT + mt) * 64 + lane] = acc[mt];
-            acc[mt] = (acc4_t){0, 0, 0, 0};
-        }
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                red[((wave * NT + nt) * MT + mt) * 64 + lane] = acc[nt][mt];
+                acc[nt][mt] = (acc4_t){0, 0, 0, 0};
+            }
         __syncthreads();
         int64_t n0;
         int mb;
         decode(c_tile, n0, mb);
-        for (int mt = wave; mt < MT; mt += wpb) {
-            acc4_t s = red[mt * 64 + lane];
-            for (int v = 1; v < wpb; ++v) s += red[(v * MT + mt) * 64 + lane];
-            const int64_t m = (int64_t)mb * (MT * 16) + mt * 16 + fr, n = n0 + 4 * fg;
+        for (int p = wave; p < NT * MT; p += wpb) {
+            const int nt = p / MT, mt = p - nt * MT;
+            acc4_t s = red[p * 64 + lane];
+            for (int v = 1; v < wpb; ++v) s += red[(v * NT * MT + p) * 64 + lane];
+            const int64_t m = (int64_t)mb * (MT * 16) + mt * 16 + fr, n = n0 + nt * 16 + 4 * fg;
             if (m < M && n < N) {
                 const float sr = Epi::kHasRow ? epi.row(m) : 1.0f;
                 v4f sc = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
@@ -179,21 +191,26 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
         if (newer >= 2) sk_wait_vm<2 * D>();
         else if (newer == 1) sk_wait_vm<D>();
         else sk_wait_vm<0>();
-        v4i wf[2], xf[MT][2];
+        v4i wf[NT][2], xf[MT][2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            wf[h] = *(const __attribute__((address_space(3))) v4i *)(uintptr_t)(faddr[S][h]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xf[mt][h] = *(const __attribute__((address_space(3))) v4i *)(uintptr_t)(faddr[S][h] + (1 + mt) * 2048);
+            for (int nt = 0; nt < NT; ++nt) wf[nt][h] = *(const __attribute__((address_space(3))) v4i *)(uintptr_t)(faddr[S][h] + nt * 2048);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xf[mt][h] = *(const __attribute__((address_space(3))) v4i *)(uintptr_t)(faddr[S][h] + (NT + mt) * 2048);
         }
         if constexpr (MMA::kIsInt) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[h], xf[mt][h], acc[mt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[nt][h], xf[mt][h], acc[nt][mt], 0, 0, 0);
         } else {  // fp8: one K = 128 block-scaled instruction (unit scales) over both halves of the unit
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = MMA::mma16(wf[0], wf[1], xf[mt][0], xf[mt][1], acc[mt]);
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = MMA::mma16(wf[nt][0], wf[nt][1], xf[mt][0], xf[mt][1], acc[nt][mt]);
         }
         ++done;
         if (++c_u == upt) {

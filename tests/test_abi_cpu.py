@@ -45,7 +45,9 @@ def test_argument_errors_without_gpu():
     assert h.asq_gemm_kernel_name(64, 14336, 4096) == b"skinny"          # decode batch: weight stream
     assert h.asq_gemm_kernel_name(192, 4096, 4096) == b"skinny"          # 3 m-blocks x 256 channel tiles still fit the chip
     assert h.asq_gemm_kernel_name(320, 4096, 4096) == b"p8h"             # too few 256-row tiles for 256 CUs: 128-row tiles
-    assert h.asq_gemm_kernel_name(128, 11008, 4096) == b"p8h"            # measured crossover: work > 4e9
+    assert h.asq_gemm_kernel_name(128, 11008, 4096) == b"skinny"         # wide-N weight: streaming stays ahead up to work 5.8e9
+    assert h.asq_gemm_kernel_name(192, 11008, 4096) == b"p8h"
+    assert h.asq_gemm_kernel_name(96, 4096, 11008) == b"p8h"             # measured crossover: work > 4e9
     assert h.asq_gemm_kernel_name(64, 5120, 20480) == b"p8h"
     assert h.asq_gemm_kernel_name(2048, 4096, 4096) == b"p8h"            # 128 tiles of 256 rows
     assert h.asq_gemm_kernel_name(2048, 5120, 5120) == b"p8"             # 160 tiles: the 256-row kernel is the more efficient one

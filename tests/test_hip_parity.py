@@ -134,6 +134,8 @@ GEMM_SHAPES = [
     # skinny (M <= 64, K % 128 == 0): weight-streaming kernel, all token-tile counts, ragged N
     (1, 16, 128), (4, 4096, 4096), (16, 100, 256), (17, 33, 128), (32, 1000, 512), (33, 48, 1152), (48, 130, 384),
     (64, 64, 128), (63, 4099, 256), (32, 512, 11008),
+    # 32-channel items (N >= 14336, or K >= 16384): ragged N inside the second channel tile
+    (32, 14352, 256), (48, 14337, 128), (16, 4100, 16384),
     # 64 < M on a small weight: weight-streaming kernel with several 64-row m-blocks (balanced, ragged M and N,
     # channel-tile count not a multiple of 8 -> padding items)
     (65, 256, 128), (100, 200, 384), (129, 257, 1024), (200, 1000, 256), (256, 4096, 512), (300, 520, 384),

@@ -10,7 +10,7 @@
 int main(int argc, char** argv)
 {
     struct S { long M, N, K; };
-    std::vector<S> shapes = {{1, 4096, 4096}, {4, 4096, 4096}, {16, 4096, 4096}, {32, 4096, 4096}, {64, 4096, 4096}, {32, 11008, 4096}, {32, 4096, 11008}, {32, 5120, 20480}, {32, 14336, 4096}, {32, 1024, 4096}};
+    std::vector<S> shapes = {{1, 4096, 4096}, {4, 4096, 4096}, {16, 4096, 4096}, {32, 4096, 4096}, {64, 4096, 4096}, {32, 11008, 4096}, {32, 4096, 11008}, {32, 5120, 20480}, {32, 14336, 4096}, {32, 1024, 4096}, {64, 11008, 4096}, {64, 14336, 4096}, {16, 11008, 4096}, {32, 20480, 5120}, {32, 8192, 8192}, {64, 8192, 8192}};
     const size_t maxw = 5120L * 20480;
     const int NB = 6;  // 6 x 105 MB > 256 MiB
     int8_t* w[NB]; int8_t* x; void* out;
