@@ -178,8 +178,9 @@ int asq_linear_fp8(const uint8_t *xq, const uint8_t *w, int fp8_format, void *ou
  * restated from its intent: y = e5m2(x) . e5m2(W)^T + bias.) */
 int asq_cast_e5m2(const void *x, int x_dtype, uint8_t *xq, int64_t n, void *stream);
 
-/* ---- introspection for tests / bench: which GEMM kernel the dispatcher picks for a shape.
- * Returns a static string ("t256", "generic", ...). */
+/* ---- introspection for tests / bench: which GEMM kernel the dispatcher picks for a shape (aligned operands):
+ * "skinny" (weight streaming), "p8h" (128x256x128 tiles), "p8" (256x256x128 tiles) or "generic".
+ * Development overrides (read once per process): ASQ_GEMM_KERNEL=generic|skinny|p8h|p8, ASQ_KSPLIT=n, ASQ_SK_NT=1|2. */
 const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K);
 
 #ifdef __cplusplus
