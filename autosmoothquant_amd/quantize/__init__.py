@@ -1,2 +1,4 @@
-"""Weight-side conversion helpers: what runs once, before the hot path."""
+"""Weight-side conversion and calibration helpers: what runs once, before the hot path."""
 from .smooth import smooth_ln_fcs  # noqa: F401
+from .calibration import (decoder_layer_scales, get_act_scales, get_io_absmax, get_static_decoder_layer_scales,  # noqa: F401
+                          parse_quant_config)
