@@ -33,6 +33,7 @@ SIGNATURES = {
     "asq_gemm_kernel_name": (ctypes.c_char_p, [_i64, _i64, _i64]),
     "asq_quantize_act_fp8": (_int, [_vp, _int, _int, _f32, _vp, _vp, _i64, _i64, _vp]),
     "asq_linear_fp8": (_int, [_vp, _vp, _int, _vp, _int, _i64, _i64, _i64, _vp, _int, _f32, _f32, _vp, _vp]),
+    "asq_linear_fp8_grouped": (_int, [_vp, _vp, _vp, _int, _vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "asq_cast_e5m2": (_int, [_vp, _int, _vp, _i64, _vp]),
 }
 

@@ -205,6 +205,17 @@ int launch_fp8_linear(const int8_t *xq, const int8_t *w, void *out, int64_t M, i
     return launch_gemm(xq, w, M, N, K, EpiFp8<DT, false, MMA>{out, N, a_scale_dev, a_per_token, a_scale_host, w_scale, bias, vec_ok}, s, "asq_linear_fp8");
 }
 
+template <int DT>
+int launch_fp8_grouped(const int8_t *xq, const int8_t *w, void *out, int64_t M, int64_t N, int64_t K, const float *a_scale, const float *w_scale_group,
+                       const float *bias, bool vec_ok, const int *goffs, int ngroups, hipStream_t s)
+{
+    if (bias)
+        return launch_gemm(xq, w, M, N, K, EpiFp8<DT, true, MmaFp8>{out, N, a_scale, true, 1.0f, 1.0f, bias, vec_ok, w_scale_group}, s, "asq_linear_fp8_grouped",
+                           nullptr, 0, goffs, ngroups);
+    return launch_gemm(xq, w, M, N, K, EpiFp8<DT, false, MmaFp8>{out, N, a_scale, true, 1.0f, 1.0f, bias, vec_ok, w_scale_group}, s, "asq_linear_fp8_grouped",
+                       nullptr, 0, goffs, ngroups);
+}
+
 // unscaled elementwise cast to e5m2 (flat)
 template <int DT> __global__ void __launch_bounds__(256) cast_e5m2_kernel(const void *__restrict__ xv, uint8_t *__restrict__ xq, int64_t n, bool vec)
 {
@@ -305,4 +316,27 @@ extern "C" int asq_linear_fp8(const uint8_t *xq, const uint8_t *w, int fp8_forma
     default: return ASQ_F8L(ASQ_BF16, MmaBf8);
     }
 #undef ASQ_F8L
+}
+
+extern "C" int asq_linear_fp8_grouped(const uint8_t *xq, const uint8_t *w, void *out, int out_dtype, const int32_t *group_offsets, int ngroups, int64_t M,
+                                      int64_t N, int64_t K, const float *a_scale, const float *w_scale_group, const float *bias, void *stream)
+{
+    ASQ_REQUIRE(M >= 0 && N >= 0 && K >= 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), ASQ_ERR_DIM, "asq_linear_fp8_grouped: bad dims");
+    if (M == 0 || N == 0) return ASQ_OK;
+    ASQ_REQUIRE(out != nullptr && xq != nullptr && w != nullptr && group_offsets != nullptr && a_scale != nullptr && w_scale_group != nullptr &&
+                    ngroups > 0 && ngroups <= 4096,
+                ASQ_ERR_NULL, "asq_linear_fp8_grouped: need xq, w, out, group_offsets, a_scale, w_scale_group and 1 <= ngroups <= 4096");
+    ASQ_REQUIRE(out_dtype == ASQ_F32 || out_dtype == ASQ_F16 || out_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_linear_fp8_grouped: bad out_dtype %d", out_dtype);
+    ASQ_REQUIRE(((uintptr_t)out % asq_dtype_size(out_dtype)) == 0 &&
+                    ((((uintptr_t)a_scale | (uintptr_t)w_scale_group | (uintptr_t)bias | (uintptr_t)group_offsets) & 3) == 0),
+                ASQ_ERR_ALIGN, "asq_linear_fp8_grouped: misaligned pointer");
+    const size_t vbytes = out_dtype == ASQ_F32 ? 16 : 8;
+    const bool vec_ok = (N % 4 == 0) && (((uintptr_t)out & (vbytes - 1)) == 0) && ((((uintptr_t)bias) & 15) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int8_t *xa = (const int8_t *)xq, *wa = (const int8_t *)w;
+    switch (out_dtype) {
+    case ASQ_F32: return launch_fp8_grouped<ASQ_F32>(xa, wa, out, M, N, K, a_scale, w_scale_group, bias, vec_ok, group_offsets, ngroups, s);
+    case ASQ_F16: return launch_fp8_grouped<ASQ_F16>(xa, wa, out, M, N, K, a_scale, w_scale_group, bias, vec_ok, group_offsets, ngroups, s);
+    default: return launch_fp8_grouped<ASQ_BF16>(xa, wa, out, M, N, K, a_scale, w_scale_group, bias, vec_ok, group_offsets, ngroups, s);
+    }
 }

@@ -331,8 +331,15 @@ template <int DT, bool HAS_BIAS, class MMA_ = MmaFp8> struct EpiFp8 {
     float a_scale_host, w_scale;
     const float *bias;
     bool vec_ok;
+    const float *w_scale_group = nullptr;  // grouped launches: per-group weight scale [ngroups] (device)
     __device__ __forceinline__ const EpiFp8 &with_slab(int, int64_t, int64_t) const { return *this; }
-    __device__ __forceinline__ const EpiFp8 &with_group(int, int64_t) const { return *this; }
+    __device__ __forceinline__ EpiFp8 with_group(int e, int64_t Ncols) const
+    {
+        EpiFp8 r = *this;
+        if (w_scale_group) r.w_scale = w_scale_group[e];
+        if constexpr (HAS_BIAS) r.bias += (int64_t)e * Ncols;
+        return r;
+    }
     __device__ __forceinline__ float row(int64_t m) const { return a_scale_dev ? (a_per_token ? a_scale_dev[m] : a_scale_dev[0]) : a_scale_host; }
     __device__ __forceinline__ void cols(int64_t n, int64_t Ncols, v4f &sc, v4f &b) const
     {

@@ -286,3 +286,31 @@ def linear_fp8(xq, a_scale, w, w_scale, bias, out_dtype):
 
 def gemm_kernel_name(M, N, K):
     return L.lib().asq_gemm_kernel_name(M, N, K).decode()
+
+
+def linear_fp8_grouped(xq, a_scale, w, w_scale_group, group_offsets, out_dtype, bias=None):
+    """ngroups independent e4m3 linears in one launch (Mixtral experts, FP8LinearDynamic math).  xq float8_e4m3fn [M,K]
+    rows sorted by group, a_scale f32 [M] or [M,1] (per-token, device), w float8_e4m3fn [G,N,K], w_scale_group f32 [G]
+    (device), group_offsets int32 [G+1] (device), bias f32 [G,N] or None."""
+    _dev(xq, "xq"), _dev(w, "weight"), _dev(group_offsets, "group_offsets"), _dev(w_scale_group, "w_scale_group"), _dev(a_scale, "a_scale")
+    f8 = torch.float8_e4m3fn
+    if xq.dtype != f8 or w.dtype != f8 or xq.dim() != 2 or w.dim() != 3 or xq.shape[1] != w.shape[2]:
+        raise ValueError("xq [M,K] and weight [G,N,K] must be float8_e4m3fn with equal K")
+    M, K = xq.shape
+    G, N = w.shape[0], w.shape[1]
+    if group_offsets.dtype != torch.int32 or group_offsets.numel() != G + 1 or w_scale_group.dtype != torch.float32 or w_scale_group.numel() != G:
+        raise ValueError("group_offsets must be int32 [G+1] and w_scale_group float32 [G]")
+    if a_scale.dtype != torch.float32 or a_scale.numel() != M:
+        raise ValueError("a_scale must be float32 with M elements (per-token)")
+    if bias is not None:
+        _dev(bias, "bias")
+        if bias.dtype != torch.float32 or bias.numel() != G * N:
+            raise ValueError(f"bias must be float32 with {G * N} elements")
+    out = torch.empty((M, N), dtype=out_dtype, device=xq.device)
+    if M == 0 or N == 0:
+        return out
+    dev = _same_device(xq, w, group_offsets, w_scale_group, a_scale, bias)
+    with torch.cuda.device(dev):
+        L.check(L.lib().asq_linear_fp8_grouped(xq.data_ptr(), w.data_ptr(), out.data_ptr(), _DT[out_dtype], group_offsets.data_ptr(), G, M, N, K,
+                                               a_scale.data_ptr(), w_scale_group.data_ptr(), _ptr(bias), _stream(xq)), "asq_linear_fp8_grouped")
+    return out

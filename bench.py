@@ -154,6 +154,53 @@ def make_moe_workload(device, seed, dtype, skew=False):
     return st, grouped, sequential
 
 
+def make_moe_workload_fp8(device, seed, dtype):
+    """Same routing and shapes with the reference's FP8LinearDynamic math: e4m3 weights with one
+    scale per expert, per-token dynamic e4m3 activations, product on the fp8 matrix cores."""
+    from autosmoothquant_amd import ops
+    g = torch.Generator(device=device).manual_seed(seed)
+    E, H, F_, R = 8, 4096, 14336, 8192
+    counts = torch.bincount(torch.multinomial(torch.ones(E) / E, R, replacement=True, generator=torch.Generator().manual_seed(seed)), minlength=E)
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)]).to(torch.int32).to(device)
+
+    def qstack(n, k):
+        w = torch.empty(E, n, k, dtype=torch.float8_e4m3fn, device=device)
+        sc = torch.empty(E, dtype=torch.float32, device=device)
+        for e in range(E):
+            f = torch.randn(n, k, generator=g, device=device) * 0.02
+            s_ = f.abs().max() / 448
+            w[e] = (f / s_).clamp(-448, 448).to(torch.float8_e4m3fn)
+            sc[e] = s_
+        return w, sc
+    w1, s1 = qstack(F_, H)
+    w3, s3 = qstack(F_, H)
+    w2, s2 = qstack(H, F_)
+    st = dict(E=E, offs=offs, counts=counts.tolist(), w1=w1, w3=w3, w2=w2, s1=s1, s3=s3, s2=s2, x=torch.randn(R, H, generator=g, device=device).to(dtype))
+
+    def grouped():
+        xq, sx = ops.quantize_act_fp8(st["x"], "per-token")
+        h1 = ops.linear_fp8_grouped(xq, sx, st["w1"], st["s1"], st["offs"], dtype)
+        h3 = ops.linear_fp8_grouped(xq, sx, st["w3"], st["s3"], st["offs"], dtype)
+        aq, sa = ops.quantize_act_fp8(torch.nn.functional.silu(h1) * h3, "per-token")
+        return ops.linear_fp8_grouped(aq, sa, st["w2"], st["s2"], st["offs"], dtype)
+
+    s1h, s3h, s2h = st["s1"].tolist(), st["s3"].tolist(), st["s2"].tolist()
+
+    def sequential():   # one FP8LinearDynamic-style call per expert and projection
+        outs, o = [], 0
+        for e, c in enumerate(st["counts"]):
+            if c == 0:
+                continue
+            xq, sx = ops.quantize_act_fp8(st["x"][o:o + c], "per-token")
+            h1 = ops.linear_fp8(xq, sx, st["w1"][e], s1h[e], None, dtype)
+            h3 = ops.linear_fp8(xq, sx, st["w3"][e], s3h[e], None, dtype)
+            aq, sa = ops.quantize_act_fp8(torch.nn.functional.silu(h1) * h3, "per-token")
+            outs.append(ops.linear_fp8(aq, sa, st["w2"][e], s2h[e], None, dtype))
+            o += c
+        return torch.cat(outs)
+    return st, grouped, sequential
+
+
 LLAMA7B_SPEC = [("q", "linear", 4096, 4096, "per-tensor", False), ("k", "linear", 4096, 4096, "per-tensor", False),
                 ("v", "linear", 4096, 4096, "per-tensor", False), ("o", "quantscale", 4096, 4096, "per-token", False),
                 ("gate", "linear", 4096, 11008, "per-tensor", False), ("up", "linear", 4096, 11008, "per-tensor", False),
@@ -303,6 +350,7 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-norm", action="store_true", help="layer workloads: RMSNorm -> int8 fused (SURVEY 8f N1) instead of the reference's two-step composition")
+    ap.add_argument("--fp8", action="store_true", help="mixtral_experts only: FP8LinearDynamic math (e4m3 weights, per-token e4m3 activations) on the fp8 matrix cores")
     ap.add_argument("--graph", action="store_true", help="capture one step in a hipGraph and replay it in the timed loop (launch-bound decode shapes)")
     args = ap.parse_args()
 
@@ -329,8 +377,13 @@ def main():
     moe_mode = spec == "moe"
     moe_extra = None
     if moe_mode:
-        st, step, seq_step = make_moe_workload(device, 1234, tdt)
-        assert torch.equal(step(), seq_step()), "grouped launch != per-expert calls"
+        if args.fp8:
+            st, step, seq_step = make_moe_workload_fp8(device, 1234, tdt)
+            a_, b_ = step().float(), seq_step().float()   # fp32 accumulation order differs between the grouped and the per-expert kernels
+            assert float((a_ - b_).abs().max()) <= 2e-3 * float(b_.abs().max()), "grouped fp8 launch != per-expert calls"
+        else:
+            st, step, seq_step = make_moe_workload(device, 1234, tdt)
+            assert torch.equal(step(), seq_step()), "grouped launch != per-expert calls"
         mods, nlayers, spec = torch.nn.ModuleDict(), 1, MIXTRAL_SPEC
         for _ in range(3):
             seq_step()
@@ -400,14 +453,19 @@ def main():
         lbl, kind, K, N, aq, bias = max(spec, key=lambda s: s[2] * s[3])
         if moe_mode:
             from autosmoothquant_amd import ops as _ops
-            xq_, _ = _ops.quantize_act(st["x"], "per-tensor-round")
+            if args.fp8:
+                xq_, sx_ = _ops.quantize_act_fp8(st["x"], "per-token")
+                w1_launch = lambda: _ops.linear_fp8_grouped(xq_, sx_, st["w1"], st["s1"], st["offs"], tdt)
+            else:
+                xq_, _ = _ops.quantize_act(st["x"], "per-tensor-round")
+                w1_launch = lambda: _ops.linear_w8a8_grouped(xq_, st["w1"], st["offs"], st["s1"], tdt)
             for _ in range(3):
-                _ops.linear_w8a8_grouped(xq_, st["w1"], st["offs"], st["s1"], tdt)
+                w1_launch()
             torch.cuda.synchronize()
             ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ea.record()
             for _ in range(10):
-                _ops.linear_w8a8_grouped(xq_, st["w1"], st["offs"], st["s1"], tdt)
+                w1_launch()
             eb.record()
             eb.synchronize()
             avg_ms = min_ms = ea.elapsed_time(eb) / 10
@@ -426,12 +484,12 @@ def main():
         if kname == "skinny":   # M <= 64: one pass over the weights, HBM-bound
             achieved, peak, unit, bound = bytes_k / (avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
         else:
-            achieved, peak, unit, bound = ops_k / (avg_ms * 1e-3) / 1e12, PEAK_INT8_TOPS, "TOP/s", "mfma"
+            achieved, peak, unit, bound = ops_k / (avg_ms * 1e-3) / 1e12, PEAK_INT8_TOPS, "TFLOP/s" if (moe_mode and args.fp8) else "TOP/s", "mfma"  # fp8 dense peak = int8 dense peak
         out = {
             "metric": "INT8 GEMM TOPS + tokens/sec, LLaMA-7B W8A8 fwd, 1/2/4/8 MI355X vs CPU ref",
             "value": round(tops, 2), "unit": "TOPS", "tokens_per_s": round(tokens_per_s, 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8_e4m3" if (moe_mode and args.fp8) else "int8",
             "data": "synthetic (random-init N(0,0.02^2) weights quantised by from_float; N(0,1) activations with 1% outlier channels x20)",
             "config": {"workload": f"{args.workload}: {desc}", "M_per_gpu": M, "act_dtype": args.dtype,
                        "linears": [f"{l}:{k}:{K_}x{N_}:{a}" for (l, k, K_, N_, a, _) in spec],
@@ -440,7 +498,7 @@ def main():
             "roofline": {"bound": bound, "achieved": round(achieved, 1), "peak": peak, "unit": unit,
                          "frac": round(achieved / peak, 4),
                          "traffic": pmc_traffic(f"gemm_i8_{kname}<asq::EpiDequant<{ {'f32': 0, 'f16': 1, 'bf16': 2}[args.dtype] }, {'true' if aq == 'per-token' else 'false'}, false, {'true' if bias else 'false'}>", M_k, N, K),
-                         "kernel": f"gemm_i8_{kname}<EpiDequant {args.dtype}> [{lbl}] M={M_k} N={N} K={K}",
+                         "kernel": f"gemm_i8_{kname}<{'EpiFp8' if (moe_mode and args.fp8) else 'EpiDequant'} {args.dtype}> [{lbl}] M={M_k} N={N} K={K}",
                          "avg_us": round(avg_ms * 1e3, 2), "min_us": round(min_ms * 1e3, 2),
                          "algorithmic_ops": ops_k, "algorithmic_bytes": bytes_k,
                          "tops": round(ops_k / (avg_ms * 1e-3) / 1e12, 1),
@@ -452,7 +510,7 @@ def main():
             out["weight_broadcast"] = bcast
         if moe_extra:
             out["config"].update(moe_extra)
-            out["config"]["note"] = "step = quantise + grouped w1, w3 + SiLU*mul (torch) + per-token quantise + grouped w2; TOPS counts the int8 ops"
+            out["config"]["note"] = "step = quantise + grouped w1, w3 + SiLU*mul (torch) + per-token quantise + grouped w2; TOPS counts the " + ("fp8 flops (FP8LinearDynamic math, unit-scale block-scaled MFMA)" if args.fp8 else "int8 ops")
         if layer_mode:
             out["config"]["note"] = "TOPS counts the int8 linear ops only; tokens_per_s is the whole layer stack incl. the torch attention/norm glue"
             out["config"]["layers"] = nlayers

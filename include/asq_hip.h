@@ -172,6 +172,14 @@ int asq_linear_fp8(const uint8_t *xq, const uint8_t *w, int fp8_format, void *ou
                    const float *a_scale_dev, int a_per_token, float a_scale_host, float w_scale,
                    const float *bias, void *stream);
 
+/* Grouped fp8 launch (Mixtral experts with FP8LinearDynamic math): ngroups independent e4m3 linears in one
+ * kernel launch, the fp8 twin of asq_linear_w8a8_grouped.
+ *   xq e4m3 [M,K] rows sorted by group, group_offsets DEVICE int32 [ngroups+1], w e4m3 [ngroups][N][K],
+ *   a_scale f32 [M] (per-token, DEVICE), w_scale_group f32 [ngroups] (DEVICE), bias f32 [ngroups][N] | NULL
+ * out[m,n] = acc_f32 * (a_scale[m] * w_scale_group[g(m)]) (+ bias[g(m)][n]).  K % 128 == 0, 16-B aligned operands. */
+int asq_linear_fp8_grouped(const uint8_t *xq, const uint8_t *w, void *out, int out_dtype, const int32_t *group_offsets, int ngroups,
+                           int64_t M, int64_t N, int64_t K, const float *a_scale, const float *w_scale_group, const float *bias, void *stream);
+
 /* FP8E5M2Linear (linear.py:583-644): plain unscaled cast x -> e5m2 (round-to-nearest-even, IEEE-like
  * overflow to inf); the product then runs through asq_linear_fp8(..., ASQ_FP8_E5M2, ...) with unit scales.
  * (The reference's forward calls torch._scaled_mm with scale_a=None, which current PyTorch rejects;

@@ -143,3 +143,34 @@ def test_fp8_modules_vs_golden(dev):
     xe = torch.from_numpy(x).to(torch.float8_e5m2).float().numpy().astype(np.float64)
     we = lin.weight.data.to(torch.float8_e5m2).float().numpy().astype(np.float64)
     assert close(y, (xe @ we.T + lin.bias.data.numpy().astype(np.float64)).astype(np.float32))
+
+
+@pytest.mark.parametrize("counts", [[300, 0, 17, 256, 1, 130], [64, 64], [0, 0, 5]])
+def test_fp8_grouped_launch_vs_per_group_oracle(counts, dev):
+    """Grouped fp8 launch (Mixtral experts, FP8LinearDynamic math: per-token activation scales, one weight scale per
+    expert) against the oracle's easy_fp8_gemm on every group's slice; empty and ragged groups included."""
+    from autosmoothquant_amd import ops
+    G, N, K = len(counts), 320, 256
+    M = sum(counts)
+    x = O.round_to(detrng.act_like(210, M, (M, K), scale=3.0), "f16")
+    xt = t_in(x, "f16", dev)
+    q, s = ops.quantize_act_fp8(xt, "per-token")
+    aq, a_s = F8.per_token_quantize_fp8(x, "f16")
+    wqs, wss = [], []
+    for g in range(G):
+        wq, ws = F8.per_tensor_quantize_fp8((detrng.normal(211, g, (N, K)) * np.float32(0.02 * (g + 1))).astype(np.float32), "f32")
+        wqs.append(wq)
+        wss.append(np.float32(ws))
+    w = torch.from_numpy(np.stack(wqs)).to(dev).view(torch.float8_e4m3fn)
+    wsg = torch.tensor(wss, dtype=torch.float32, device=dev)
+    b = (detrng.normal(212, G, (G, N)) * np.float32(0.5)).astype(np.float32)
+    bt = torch.from_numpy(b).to(dev)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device=dev)
+    for use_bias in (False, True):
+        got = ops.linear_fp8_grouped(q, s, w, wsg, offs, torch.float32, bt if use_bias else None).cpu().numpy()
+        o = 0
+        for g, c in enumerate(counts):
+            if c:
+                ref = F8.easy_fp8_gemm(aq[o:o + c], a_s[o:o + c], wqs[g], wss[g], b[g] if use_bias else None, "f32")
+                assert close(got[o:o + c], ref, 1e-3), (g, c, use_bias)
+            o += c
