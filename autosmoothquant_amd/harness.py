@@ -62,9 +62,14 @@ class LlamaLayer(torch.nn.Module):
         x = self.input_layernorm(h)   # a float tensor, or a QuantizedActivation when the norm is fused (N1)
         if record is not None:
             record["attn_in"] = x
-        q = self.q_proj(x).view(B, S, self.heads, self.hd).transpose(1, 2)
-        k = self.k_proj(x).view(B, S, self.kv_heads, self.hd).transpose(1, 2)
-        v = self.v_proj(x).view(B, S, self.kv_heads, self.hd).transpose(1, 2)
+        if getattr(self, "qkv_proj", None) is not None:   # one GEMM over [q;k;v] (the reference's QKVLinear, as its Baichuan W_pack)
+            nq, nkv = self.heads * self.hd, self.kv_heads * self.hd
+            q, k, v = self.qkv_proj(x).split([nq, nkv, nkv], dim=-1)
+        else:
+            q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        q = q.view(B, S, self.heads, self.hd).transpose(1, 2)
+        k = k.view(B, S, self.kv_heads, self.hd).transpose(1, 2)
+        v = v.view(B, S, self.kv_heads, self.hd).transpose(1, 2)
         pos = torch.arange(S, device=h.device)
         q, k = _rope(q, pos), _rope(k, pos)
         if self.kv_heads != self.heads:
@@ -110,7 +115,7 @@ def calibrate(layer, h):
 
 
 @torch.no_grad()
-def to_w8a8(layer, scales, quant_config=None, fuse_norm=False):
+def to_w8a8(layer, scales, quant_config=None, fuse_norm=False, fuse_qkv=False):
     """Quantised copy of `layer`, composed exactly like the reference's
     QuantizedLlamaDecoderLayer.from_float_to_int8 (models/llama.py:289-339):
       q/k/v, gate/up : W8A8BFP32OFP32Linear(act_quant = cfg["qkv"] / cfg["fc1"]), norm weight folded iff per-tensor
@@ -127,9 +132,16 @@ def to_w8a8(layer, scales, quant_config=None, fuse_norm=False):
         src.weight = torch.nn.Parameter(lin.weight.detach().float().clone())  # from_float rounds an fp32 source in place
         return cls.from_float(src, scale, save_device=dev, act_quant=aq).to(dev)
 
-    q.q_proj = conv(layer.q_proj, W8A8BFP32OFP32Linear, scales["attn_in"], cfg["qkv"])
-    q.k_proj = conv(layer.k_proj, W8A8BFP32OFP32Linear, scales["attn_in"], cfg["qkv"])
-    q.v_proj = conv(layer.v_proj, W8A8BFP32OFP32Linear, scales["attn_in"], cfg["qkv"])
+    if fuse_qkv:   # q/k/v as ONE W8A8BFP32OFP32QKVLinear (per-segment weight scales, linear.py:210-245): one quantise + one GEMM
+        from .layers.nn.linear import W8A8BFP32OFP32QKVLinear
+        cat = torch.nn.Linear(layer.q_proj.in_features, layer.q_proj.out_features + 2 * layer.k_proj.out_features, bias=False)
+        cat.weight = torch.nn.Parameter(torch.cat([layer.q_proj.weight, layer.k_proj.weight, layer.v_proj.weight]).detach().float().clone())
+        sizes = [layer.q_proj.out_features, layer.k_proj.out_features, layer.v_proj.out_features]
+        q.qkv_proj = W8A8BFP32OFP32QKVLinear.from_float(cat, scales["attn_in"], sizes, save_device=dev, act_quant=cfg["qkv"]).to(dev)
+    else:
+        q.q_proj = conv(layer.q_proj, W8A8BFP32OFP32Linear, scales["attn_in"], cfg["qkv"])
+        q.k_proj = conv(layer.k_proj, W8A8BFP32OFP32Linear, scales["attn_in"], cfg["qkv"])
+        q.v_proj = conv(layer.v_proj, W8A8BFP32OFP32Linear, scales["attn_in"], cfg["qkv"])
     q.o_proj = conv(layer.o_proj, W8A8BFP32OFP32LinearWithQuantScale, scales["o_in"], cfg["out"])
     q.gate_proj = conv(layer.gate_proj, W8A8BFP32OFP32Linear, scales["mlp_in"], cfg["fc1"])
     q.up_proj = conv(layer.up_proj, W8A8BFP32OFP32Linear, scales["mlp_in"], cfg["fc1"])

@@ -207,7 +207,7 @@ LLAMA7B_SPEC = [("q", "linear", 4096, 4096, "per-tensor", False), ("k", "linear"
                 ("down", "quantscale", 11008, 4096, "per-token", False)]
 
 
-def make_layer_workload(spec, device, seed, dtype, fuse_norm=False):
+def make_layer_workload(spec, device, seed, dtype, fuse_norm=False, fuse_qkv=False):
     """spec = "layer:B:S:L": L quantised LLaMA-2-7B decoder layers (distinct random-init weights) and a
     [B,S,4096] hidden-state batch; calibration scales come from the float layer on that batch."""
     from autosmoothquant_amd import harness
@@ -223,7 +223,7 @@ def make_layer_workload(spec, device, seed, dtype, fuse_norm=False):
                 if p.dim() == 2:
                     p.copy_(torch.randn(p.shape, device=device) * 0.02)
         scales = harness.calibrate(fl, h)
-        layers.append(harness.to_w8a8(fl.to(dtype), scales, fuse_norm=fuse_norm))
+        layers.append(harness.to_w8a8(fl.to(dtype), scales, fuse_norm=fuse_norm, fuse_qkv=fuse_qkv))
         del fl
     x = torch.randn(B, S, 4096, device=device, dtype=torch.float32).to(dtype)
     return torch.nn.ModuleList(layers), x
@@ -350,6 +350,7 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-norm", action="store_true", help="layer workloads: RMSNorm -> int8 fused (SURVEY 8f N1) instead of the reference's two-step composition")
+    ap.add_argument("--fuse-qkv", action="store_true", help="layer workloads: q/k/v as one W8A8BFP32OFP32QKVLinear (the reference's own fused class, used by its Baichuan model)")
     ap.add_argument("--fp8", action="store_true", help="mixtral_experts only: FP8LinearDynamic math (e4m3 weights, per-token e4m3 activations) on the fp8 matrix cores")
     ap.add_argument("--graph", action="store_true", help="capture one step in a hipGraph and replay it in the timed loop (launch-bound decode shapes)")
     args = ap.parse_args()
@@ -394,7 +395,7 @@ def main():
         torch.cuda.synchronize()
         moe_extra = {"sequential_per_expert_ms": round((time.perf_counter() - t0) / 10 * 1e3, 4), "rows_per_expert": st["counts"]}
     elif layer_mode:
-        mods, xs = make_layer_workload(spec, device, seed=1234 if rank == 0 else 99 + rank, dtype=tdt, fuse_norm=args.fuse_norm)
+        mods, xs = make_layer_workload(spec, device, seed=1234 if rank == 0 else 99 + rank, dtype=tdt, fuse_norm=args.fuse_norm, fuse_qkv=args.fuse_qkv)
         nlayers = len(mods)
         spec = LLAMA7B_SPEC
         step = lambda: run_layers(mods, xs)

@@ -173,3 +173,21 @@ def test_baichuan_block_matches_oracle_on_fresh_inputs():
         with torch.no_grad():
             y = harness.to_w8a8_baichuan(layer, scales, qc)(x.to(dev)).cpu().numpy()
         assert np.abs(y - ref).max() <= 2e-3 * np.abs(ref).max(), qc
+
+
+def test_fused_qkv_layer_equals_separate_projections():
+    """q/k/v as one W8A8BFP32OFP32QKVLinear (per-segment weight scales) == three W8A8BFP32OFP32Linear, bit for bit:
+    same int8 activations, same per-block weight quantisation, same epilogue arithmetic per element."""
+    from autosmoothquant_amd import harness
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    layer = harness.init_llama_layer(harness.LlamaLayer(hidden=256, inter=512, heads=4, kv_heads=2), std=0.05).to(dev)
+    h = torch.randn(2, 40, 256, device=dev)
+    scales = harness.calibrate(layer, h)
+    for cfg in (None, {"qkv": "per-token"}):
+        for fuse_norm in (False, True):
+            a = harness.to_w8a8(layer, scales, cfg, fuse_norm=fuse_norm)
+            b = harness.to_w8a8(layer, scales, cfg, fuse_norm=fuse_norm, fuse_qkv=True)
+            assert not hasattr(b, "q_proj") and b.qkv_proj.weight.shape == (256 + 2 * 128, 256)
+            with torch.no_grad():
+                assert torch.equal(a(h), b(h)), (cfg, fuse_norm)
