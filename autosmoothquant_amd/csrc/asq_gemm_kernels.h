@@ -641,7 +641,7 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
         // from L2 once per 16 (or 32) channels, so it wins while the total work N*K*M stays small; wide-N
         // weights (11008x4096, 14336x4096, 20480x5120) stay ahead longer than square or long-K ones
         const double work = (double)N * (double)K * (double)M;
-        if (work <= (N > 2 * K ? 5.8e9 : 4.0e9)) return KERN_SKINNY;
+        if (M <= 256 && work <= (N > 2 * K ? 5.8e9 : 4.0e9)) return KERN_SKINNY;  // (measured up to 256 rows; beyond that the tiled kernels)
         // 128-row tiles when the 256-row tiling cannot fill 256 CUs (or wastes half a tile row).  Measured
         // (tools/ksplit_sweep.sh): p8h is ~14 % slower per op on a full chip but wins up to 1.45x below ~144 tiles
         const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);

@@ -482,7 +482,7 @@ def main():
         esz = {"f16": 2, "bf16": 2, "f32": 4}[args.dtype]
         # algorithmic bytes of the fused GEMM launch: int8 activations in, int8 weights in, fp out (+ per-token scales, bias)
         bytes_k = M_k * K + N * K + M_k * N * esz + (4 * M_k if aq == "per-token" else 0) + (4 * N if bias else 0)
-        if kname == "skinny":   # M <= 64: one pass over the weights, HBM-bound
+        if kname == "skinny":   # weight-streaming kernel: one pass over the weights, HBM-bound
             achieved, peak, unit, bound = bytes_k / (avg_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
         else:
             achieved, peak, unit, bound = ops_k / (avg_ms * 1e-3) / 1e12, PEAK_INT8_TOPS, "TFLOP/s" if (moe_mode and args.fp8) else "TOP/s", "mfma"  # fp8 dense peak = int8 dense peak

@@ -127,11 +127,11 @@ def test_golden_config_shapes(c, dev):
 
 # ---- oracle comparisons on seeded inputs -------------------------------------------------
 GEMM_SHAPES = [
-    # (M, N, K)  -- chosen to hit: generic (odd K / small), t256 (K%128==0, M,N>=128) with ragged edges
+    # (M, N, K)  -- chosen to hit: generic (odd K / small) and the tiled kernels (K % 128 == 0) with ragged edges
     (1, 1, 1), (3, 5, 7), (17, 33, 95), (64, 64, 64), (65, 130, 200), (33, 48, 320),
     (128, 128, 128), (256, 256, 256), (300, 520, 384), (129, 257, 1024), (512, 768, 1024),
     (1000, 300, 512), (255, 4096, 256), (2048, 128, 2048),
-    # skinny (M <= 64, K % 128 == 0): weight-streaming kernel, all token-tile counts, ragged N
+    # few rows, K % 128 == 0: weight-streaming kernel, all token-tile counts, ragged N
     (1, 16, 128), (4, 4096, 4096), (16, 100, 256), (17, 33, 128), (32, 1000, 512), (33, 48, 1152), (48, 130, 384),
     (64, 64, 128), (63, 4099, 256), (32, 512, 11008),
     # 32-channel items (N >= 14336, or K >= 16384): ragged N inside the second channel tile
