@@ -157,6 +157,38 @@ def test_gemm_i8_i32_vs_oracle(shape, dev):
     assert np.array_equal(out.cpu().numpy(), O.igemm(x, w))
 
 
+def _fuzz_shapes():
+    rng = np.random.default_rng(20240607)
+    shapes = []
+    for i in range(36):
+        M = int(rng.choice([rng.integers(1, 65), rng.integers(65, 300), rng.integers(300, 900)]))
+        N = int(rng.choice([rng.integers(1, 64), rng.integers(64, 600), rng.integers(600, 2200)]))
+        K = int(128 * rng.integers(1, 20)) if i % 6 else int(rng.integers(1, 700))
+        shapes.append((M, N, K))
+    return shapes
+
+
+@pytest.mark.parametrize("shape", _fuzz_shapes(), ids=lambda s: "x".join(map(str, s)))
+def test_gemm_fuzz_vs_oracle(shape, dev):
+    """Seeded random shapes across every dispatcher boundary (rows 1..900, ragged N, K % 128 == 0 and odd K), int32 and
+    fp16 epilogues, each launched twice (a race in the LDS-DMA / barrier protocol shows up as run-to-run differences)."""
+    from autosmoothquant_amd import ops
+    M, N, K = shape
+    x = detrng.int8_uniform(301, M * 3 + K, (M, K))
+    w = detrng.int8_uniform(302, N * 7 + K, (N, K))
+    xt, wt = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    acc = O.igemm(x, w)
+    for _ in range(2):
+        out = torch.full((M, N), 5, dtype=torch.int32, device=dev)
+        ops.gemm_i8_i32(xt, wt, out)
+        assert np.array_equal(out.cpu().numpy(), acc)
+    srow = (np.abs(detrng.normal(303, M, (M,))) * 1e-3 + 1e-4).astype(np.float32)
+    bias = detrng.normal(304, N, (N,)).astype(np.float32)
+    ref = O.dequant_epilogue(acc, np.float32(0.125), srow, bias, "f16")
+    got = ops.linear_w8a8(xt, wt, torch.float16, 0.125, torch.from_numpy(srow).to(dev), None, torch.from_numpy(bias).to(dev))
+    assert np.array_equal(got.float().cpu().numpy(), ref)
+
+
 def test_gemm_transpose_detecting(dev):
     """x = one-hot rows selects rows of W: an m<->n swap or wrong fragment map cannot pass."""
     from autosmoothquant_amd import ops
