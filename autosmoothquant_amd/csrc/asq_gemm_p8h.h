@@ -12,12 +12,18 @@
 //   K-tile image = 3 units {X: tile rows 0..127, W-even: rows 64*wn + [0,32), W-odd: + 32} = 48 KiB;
 //   ring of THREE K-tiles (144 KiB): tile t+2 is fetched while tile t is consumed, so a unit has two
 //   K-tiles (4 phases, ~2000 cycles) to arrive -- the same depth as p8's 4-phase lead.
-//   DMA issue order (3 per wave per phase, 6 per K-tile):
-//       P1(t): X[0] X[1] We[0]  of tile t+2        P2(t): We[1] Wo[0] Wo[1]  of tile t+2
+//   DMA issue order (6 per wave per K-tile, split 2 + 4 to even out the two load segments):
+//       P1(t): X[0] X[1]  of tile t+2              P2(t): We[0] We[1] Wo[0] Wo[1]  of tile t+2
 //   Counted waits (after the phase's own issue; a wave retires its DMAs in order):
-//       P1(t): W-odd(t) must have landed for P2(t): 9 younger DMAs may stay in flight -> vmcnt(9)
+//       P1(t): W-odd(t) must have landed for P2(t): 8 younger DMAs may stay in flight -> vmcnt(8)
 //       P2(t): X(t+1), W-even(t+1) for P1(t+1): 8 younger                            -> vmcnt(8)
 //   A slot is re-filled >= 2 phases (4 barriers) after its last ds_read; the stagger is 1 barrier.
+//
+//   Measured (tools/ubench/p8_probe, s_memtime per block, 4096-deep K): prologue 4.3k + K-loop 37.6k (MFMA-issue
+//   floor 32.8k = 87 %) + epilogue 4.2k cycles per 128x256 tile, i.e. 92.6k per 256x256 of output against the
+//   81.4k of p8.  The loop is bound by LDS bandwidth, not by issue order (3+3 and 2+4 DMA splits measure the same):
+//   a 64x64 wave tile reads one 1-KiB fragment per MFMA -- 128 KiB per K-tile per CU in ~1024 cycles = 125 B/clk of
+//   the 128 B/clk LDS port (p8's 128x64 wave tile: 0.75 fragments per MFMA, 94 B/clk).
 #pragma once
 #include <type_traits>
 
@@ -26,7 +32,9 @@ namespace asq {
 constexpr int P8H_STAGE = 3 * P8_UNIT;      // 48 KiB
 constexpr int P8H_LDS_BYTES = 3 * P8H_STAGE;  // 144 KiB
 
-template <class Epi>
+#define P8H_BLK(i) do { if constexpr (PROBE) { if (wave == 0 && lane == 0 && blockIdx.x < 4096) p8_blk[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } } while (0)
+
+template <class Epi, bool PROBE = false>  // PROBE: per-block s_memtime stamps for tools/ubench/p8_probe (production: false)
 __global__ void __launch_bounds__(512, 2) gemm_i8_p8h(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
                                                       int tiles_m, int tiles_n, int ksplit, Epi epi_in)
 {
@@ -34,6 +42,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8h(const int8_t *__restrict__
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+    P8H_BLK(0);
 
     // logical id = split * ntiles + tile (see p8); groups of GM tile rows share their X panels in L2
     constexpr int GM = 8;
@@ -97,8 +106,8 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8h(const int8_t *__restrict__
         const int8_t *b = (kind == 0 ? xbase : wbase) + k0;  // SALU
         p8_dma16(b, voff[kind][i], dma_dst + stage * P8H_STAGE + kind * P8_UNIT + i * 1024);
     };
-    auto issue_a = [&](int stage, int k0) { dma(0, 0, stage, k0); dma(0, 1, stage, k0); dma(1, 0, stage, k0); };
-    auto issue_b = [&](int stage, int k0) { dma(1, 1, stage, k0); dma(2, 0, stage, k0); dma(2, 1, stage, k0); };
+    auto issue_a = [&](int stage, int k0) { dma(0, 0, stage, k0); dma(0, 1, stage, k0); };
+    auto issue_b = [&](int stage, int k0) { dma(1, 0, stage, k0); dma(1, 1, stage, k0); dma(2, 0, stage, k0); dma(2, 1, stage, k0); };
 
     // ---- prologue: K-tiles 0 and 1 (clamped), wait for X(0), W-even(0)
     {
@@ -111,6 +120,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8h(const int8_t *__restrict__
     P8_WAIT_VM(8);
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger: the wm=1 group runs one barrier behind
+    P8H_BLK(1);
 
     v4i xf[2][4], wf[4];
     auto ktile = [&](auto stage_tag, int t) {
@@ -126,7 +136,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8h(const int8_t *__restrict__
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) xf[j][ks] = *(p8_lds_v4i)(uintptr_t)(xb[S][ks] + j * 4096);
-        P8_WAIT_VM(9);
+        P8_WAIT_VM(8);
         __builtin_amdgcn_s_barrier();
         P8_WAIT_LGKM0();
         __builtin_amdgcn_sched_barrier(0);
@@ -180,6 +190,7 @@ if constexpr (MMA::kIsInt) {
     if (t < nt) ktile(std::integral_constant<int, 0>{}, t);
     if (t + 1 < nt) ktile(std::integral_constant<int, 1>{}, t + 1);
 
+    P8H_BLK(2);
     P8_WAIT_VM(0);                                // drain the dead prefetches before LDS is released
     if (wm == 0) __builtin_amdgcn_s_barrier();    // balance the stagger barrier
 
@@ -194,6 +205,16 @@ if constexpr (MMA::kIsInt) {
         }
     } else {
         epilogue_wave<2, 2>(epi, get, [](int im) { return im * 32; }, m0 + wm * 64, n0 + wn * 64, lane, M, N);
+    }
+    if constexpr (PROBE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        P8H_BLK(3);
+        if (wave == 0 && lane == 0 && blockIdx.x < 4096) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            p8_blk[blockIdx.x][4] = xcc;
+            p8_blk[blockIdx.x][5] = (unsigned)(tile_m * 65536 + tile_n);
+        }
     }
 }
 

@@ -57,6 +57,25 @@ template <class Epi> void blk_timeline(const int8_t* x, const int8_t* w, Epi epi
     printf("\n    blockIdx%%8 == xcc for %d of %d blocks\n", c, nb);
 }
 
+template <class Epi> void blk_timeline_p8h(const int8_t* x, const int8_t* w, Epi epi, int64_t M, int64_t N, int64_t K, const char* tag)
+{
+    auto kfn = gemm_i8_p8h<Epi, true>;
+    CK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8H_LDS_BYTES));
+    int tm = (M + 127) / 128, tn = (N + 255) / 256;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8H_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, epi);
+    CK(hipDeviceSynchronize());
+    static unsigned long long h[4096][6];
+    CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(p8_blk), sizeof(h)));
+    int nb = tm * tn; if (nb > 4096) nb = 4096;
+    double s[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    for (int b = 0; b < nb; ++b) {
+        double d[3] = {(double)(h[b][1] - h[b][0]), (double)(h[b][2] - h[b][1]), (double)(h[b][3] - h[b][2])};
+        for (int i = 0; i < 3; ++i) { s[i] += d[i]; if (d[i] > mx[i]) mx[i] = d[i]; }
+    }
+    printf("  [p8h %s] %d blocks; avg/max cycles: prologue %.0f/%.0f  kloop %.0f/%.0f  epilogue %.0f/%.0f   (K-loop floor %lld)\n", tag, nb, s[0] / nb, mx[0], s[1] / nb, mx[1],
+           s[2] / nb, mx[2], (long long)(K / 128) * 1024);
+}
+
 int main()
 {
     const int64_t N = 4096, K = 4096, MMAX = 4096;
@@ -74,6 +93,9 @@ int main()
         blk_timeline(x, w, e16, 256, N, K, "M=256 f16 epilogue");
         EpiI32 e32{out, N, true};
         blk_timeline(x, w, e32, 4096, N, K, "4096^3 i32 epilogue");
+        blk_timeline_p8h(x, w, e16, 4096, N, K, "4096^3 f16 epilogue (512 blocks, 2 per CU in turn)");
+        blk_timeline_p8h(x, w, e16, 2048, N, K, "M=2048 f16 epilogue (256 blocks)");
+        blk_timeline_p8h(x, w, e16, 256, N, K, "M=256 f16 epilogue (32 blocks)");
     }
     for (int64_t M : {256, 4096}) {
         run<32>(x, w, out, M, N, K, 3);
