@@ -21,9 +21,9 @@
 //
 //   Measured (tools/ubench/p8_probe, s_memtime per block, 4096-deep K): prologue 4.3k + K-loop 37.6k (MFMA-issue
 //   floor 32.8k = 87 %) + epilogue 4.2k cycles per 128x256 tile, i.e. 92.6k per 256x256 of output against the
-//   81.4k of p8.  The loop is bound by LDS bandwidth, not by issue order (3+3 and 2+4 DMA splits measure the same):
-//   a 64x64 wave tile reads one 1-KiB fragment per MFMA -- 128 KiB per K-tile per CU in ~1024 cycles = 125 B/clk of
-//   the 128 B/clk LDS port (p8's 128x64 wave tile: 0.75 fragments per MFMA, 94 B/clk).
+//   81.4k of p8.  3+3 and 2+4 DMA splits measure the same.  Per K-tile the half tile moves 48 KiB through the
+//   64 B/clk/CU vector-memory path in ~1024 cycles (73 % of that peak; p8: 64 KiB in 2048 = 50 %) and its 64x64
+//   wave tiles read one 1-KiB fragment per MFMA (125 B/clk of LDS reads, peak 256; p8's 128x64 wave tile: 94).
 #pragma once
 #include <type_traits>
 
