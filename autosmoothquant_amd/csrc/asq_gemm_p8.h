@@ -51,7 +51,7 @@ constexpr int P8_LDS_BYTES = 2 * P8_STAGE;
 #define P8_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // ---- probe support (tools/ubench/p8_probe.hip): ablation + per-phase s_memtime stamps -------
-//   ABL 1 = no LDS-DMA, 2 = no fragment ds_reads, 4 = no MFMA, 8 = no barriers,
+//   ABL 1 = no LDS-DMA, 2 = no fragment ds_reads, 4 = no MFMA, 8 = no barriers, 16 = every fragment read issued twice,
 //       32 = timing stamps of block 0 waves 0/4, 64 = no s_setprio.   Production uses ABL = 0.
 static __device__ unsigned long long p8_dbg[2][4][8];
 static __device__ unsigned long long p8_blk[4096][6];  // ABL & 128: per-block {start, prologue done, loop done, end, xcc_id, tile id}
@@ -84,7 +84,14 @@ typedef const __attribute__((address_space(3))) v4i *p8_lds_v4i;
 template <int ABL> __device__ __forceinline__ v4i p8_ldfrag(unsigned lds_addr, int lane)
 {
     if constexpr (ABL & 2) return (v4i){lane, 1, 2, 3};
-    else return *(p8_lds_v4i)(uintptr_t)lds_addr;
+    else {
+        if constexpr (ABL & 16) {  // probe: every fragment read issued twice (sensitivity of the kernel to LDS read traffic)
+            v4i dup;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dup) : "v"(lds_addr) : "memory");
+            asm volatile("" ::"v"(dup));
+        }
+        return *(p8_lds_v4i)(uintptr_t)lds_addr;
+    }
 }
 
 // LDS-DMA, 16 B per lane: global address = SGPR-pair base + 32-bit VGPR offset (no VALU address

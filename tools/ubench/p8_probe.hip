@@ -26,7 +26,7 @@ template <int ABL> float run(const int8_t* x, const int8_t* w, int32_t* out, int
         float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best; sum += ms;
     }
     printf("  ABL=%2d (%s%s%s%s) M=%5lld: min %.1f us avg %.1f us  -> %.0f TOPS-equivalent\n", ABL, (ABL & 1) ? "noDMA " : "", (ABL & 2) ? "noDSREAD " : "",
-           (ABL & 4) ? "noMFMA " : "", (ABL & 8) ? "noBAR " : "", (long long)M, best * 1e3, sum / iters * 1e3, 2.0 * M * N * K / (sum / iters) / 1e9);
+           (ABL & 4) ? "noMFMA " : "", (ABL & 16) ? "2xDSREAD " : (ABL & 8) ? "noBAR " : "", (long long)M, best * 1e3, sum / iters * 1e3, 2.0 * M * N * K / (sum / iters) / 1e9);
     return best;
 }
 
@@ -125,6 +125,7 @@ int main()
         run<5>(x, w, out, M, N, K, 20);
         run<7>(x, w, out, M, N, K, 20);
         run<11>(x, w, out, M, N, K, 20);
+        run<16>(x, w, out, M, N, K, 20);   // fragment reads doubled
     }
     return 0;
 }
