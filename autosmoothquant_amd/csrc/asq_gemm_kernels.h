@@ -634,7 +634,7 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
     const int f = forced_kernel();
     if (f == KERN_GENERIC) return KERN_GENERIC;
     if (tiled_ok && (f == KERN_P8 || f == KERN_P8H)) return (GemmKernel)f;
-    if (tiled_ok && M <= 1024 && f == KERN_SKINNY) return KERN_SKINNY;
+    if (tiled_ok && M <= 1024 && M * K < (1ll << 32) && f == KERN_SKINNY) return KERN_SKINNY;  // (32-bit row offsets in the DMA address)
     if (tiled_ok && f < 0) {
         // measured crossover (tools/cold_grid.sh: 48..256 rows x 8 LLaMA/OPT/Mixtral weight shapes, weights rotated
         // through > 256 MiB so they come from HBM, not the Infinity Cache): the weight-streaming kernel re-reads X
