@@ -48,6 +48,8 @@ WORKLOADS = {
     # whole-layer harness workloads (linears on the HIP path; RMSNorm / RoPE / causal SDPA / SiLU in stock torch-ROCm)
     "llama7b_layer_b32_s128": ("LLaMA-2-7B decoder layer (W8A8 linears + torch RMSNorm/RoPE/SDPA/SiLU), batch 32 x 128 tok", 4096, "layer:32:128:1"),
     "llama7b_attn_block_b1_s2048": ("LLaMA-2-7B decoder layer, batch 1 x 2048 tok (BASELINE configs[1] shape)", 2048, "layer:1:2048:1"),
+    "llama7b_attn_block_b1_s128": ("LLaMA-2-7B decoder layer, batch 1 x 128 tok (BASELINE configs[1], short prompt)", 128, "layer:1:128:1"),
+    "llama7b_attn_block_b1_s1": ("LLaMA-2-7B decoder layer, batch 1 x 1 tok (BASELINE configs[1], single-token step without a KV cache)", 1, "layer:1:1:1"),
     "llama7b_decoder_b32_s2048": ("LLaMA-2-7B full decoder stack, 32 layers, batch 32 x 2048 tok (BASELINE configs[2])", 65536, "layer:32:2048:32"),
     "mixtral_experts": ("Mixtral-8x7B expert MLPs (w1,w3 per-tensor 4096->14336; w2 per-token 14336->4096), 4096 tokens x top-2 "
                         "routed to 8 experts, ONE grouped launch per projection (BASELINE configs[4])", 8192, "moe"),
