@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): the default bench.py line, the same command under
-# rocprofv3 --kernel-trace --stats, and two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; never
+# rocprofv3 --kernel-trace --stats, and separate --pmc passes (FETCH_SIZE, WRITE_SIZE, MfmaUtil, MFMA / LDS counts; never
 # combined with other trace domains).  Everything lands in gpurun_out/prof_$TAG/ ;
 # tools/summarise_profiles.py then writes the tracked summaries under profiles/.
 #   usage: gpurun --timeout 900 -- 'tools/collect_profiles.sh r1'
@@ -12,7 +12,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
-for C in FETCH_SIZE WRITE_SIZE; do
+for C in FETCH_SIZE WRITE_SIZE MfmaUtil SQ_INSTS_VALU_MFMA_I8 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- python "$ROOT/bench.py" --no-cpu-baseline --steps 5 --warmup 2 > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err"
 done
 ls -R "$OUT" | head -40

@@ -65,5 +65,22 @@ for key in sorted(fetch, key=lambda k: -fetch[k][0]):
                      "~3x the 33.5 MB of operands; they are served by the 256 MiB Infinity Cache (FETCH_SIZE counts those hits)")
     out["kernels"][f"{short} grid={grid}"] = e
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+
+# MFMA / LDS counters (each from its own pass), per kernel: mean over the sampled dispatches
+extra = {}
+for counter in ("MfmaUtil", "SQ_INSTS_VALU_MFMA_I8", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
+    try:
+        for (name, grid), (val, n) in pmc_means(counter).items():
+            if "asq::gemm" in name:
+                short = name.split("(")[0].replace("void ", "")
+                extra.setdefault(f"{short} grid={grid}", {"dispatches_sampled": n})[counter] = round(val, 2)
+    except (IndexError, KeyError):
+        pass
+if extra:
+    json.dump({"command": "rocprofv3 --kernel-trace --pmc <C> -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 (one pass per counter)",
+               "notes": "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * SIMD_NUM) in percent (rocprofv3 derived metric); "
+                        "SQ_INSTS_VALU_MFMA_I8: 4096^3 with 32x32x32 tiles needs 2*4096^3 / (2*32*32*32) = 2097152 wave-level MFMAs",
+               "kernels": extra}, open(os.path.join(dst, f"{tag}_pmc_mfma_lds.json"), "w"), indent=1)
+    print(json.dumps(extra, indent=1)[:2500])
 print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read())
 print(json.dumps(out["kernels"], indent=1)[:3000])
