@@ -430,8 +430,9 @@ __device__ __forceinline__ void epilogue_wave(const Epi &epi, Get get, MOff moff
 // cycles for the fp16 tile and 26k for an int32 split-K slab.  Here the finished (scaled, biased,
 // converted) values go through a WAVE-PRIVATE 16 KiB LDS image first and leave as whole rows: 8
 // lanes x 16 B = one 128-B line (2-byte outputs; 16 lanes x 16 B = 256 B for 4-byte outputs), 8 (4)
-// full rows per store instruction.  16-B chunks are XOR-swizzled by the row so the transposing
-// ds_write and the lane-linear ds_read_b128 stay (nearly) conflict-free.  No block barrier: each
+// full rows per store instruction.  16-B chunks are XOR-swizzled by the row (and, for 2-byte outputs, the
+// 8-byte halves flipped on odd rows) so the transposing ds_write and the lane-linear
+// ds_read_b128 are conflict-free.  No block barrier: each
 // wave only re-reads what it wrote; LDS operations of one wave execute in order.
 // Needs: out 16-B aligned and N * sizeof(out element) % 16 == 0 (then a 16-B chunk is never ragged).
 template <int NTM, class Epi, class Get>  // NTM = 32-row token tiles of the wave tile: 4 (256-row block tile) or 2 (128-row)
@@ -474,7 +475,9 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const v2u v = epi.pack((acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g]);
-                    *(lds_u2)(uintptr_t)(stage + row * 128 + (((in * 4 + g) ^ ((row >> 1) & 7)) << 4) + 8 * hi) = v;
+                    // ds_write_b64 is served in groups of 16 consecutive lanes over 32 banks: rows 2j and 2j+1 share a chunk
+                    // position, so odd rows take the other 8-byte half (without it: 2-way conflict, SQ_LDS_BANK_CONFLICT)
+                    *(lds_u2)(uintptr_t)(stage + row * 128 + (((in * 4 + g) ^ ((row >> 1) & 7)) << 4) + 8 * (hi ^ (row & 1))) = v;
                 }
             }
         }
@@ -483,7 +486,8 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
 #pragma unroll
         for (int i = 0; i < 4 * NTM; ++i) {
             const int row = 8 * i + (lane >> 3);
-            const v4i v = *(lds_v4i)(uintptr_t)(stage + i * 1024 + lane * 16);
+            v4i v = *(lds_v4i)(uintptr_t)(stage + i * 1024 + lane * 16);
+            if ((lane >> 3) & 1) v = (v4i){v[2], v[3], v[0], v[1]};  // odd rows were staged with their 8-byte halves flipped
             const int64_t m = mw0 + row, n = nw0 + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
             if (m < M && n < N) *(v4i *)(outb + (m * N + n) * 2) = v;
         }
