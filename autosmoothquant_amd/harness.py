@@ -34,14 +34,29 @@ class RMSNorm(torch.nn.Module):
         return n.to(self.weight.device, self.weight.dtype)
 
 
-def _rope(x, pos, theta=10000.0):
-    # x [B, H, S, D]
+_ROPE_CACHE = {}
+
+
+def _rope_tables(S, d, device, dtype, theta=10000.0):
+    key = (S, d, str(device), dtype, theta)
+    if key not in _ROPE_CACHE:
+        inv = 1.0 / (theta ** (torch.arange(0, d, 2, device=device, dtype=torch.float32) / d))
+        ang = torch.arange(S, device=device, dtype=torch.float32)[:, None] * inv[None, :]
+        _ROPE_CACHE.clear()   # one entry: the harness runs one (S, d) at a time
+        _ROPE_CACHE[key] = (torch.cos(ang)[None, None].to(dtype), torch.sin(ang)[None, None].to(dtype))
+    return _ROPE_CACHE[key]
+
+
+def _rope(x, theta=10000.0):
+    """Rotary embedding, HF "rotate_half" convention, positions 0..S-1; x [B, H, S, D].  Two fused multiply-adds per
+    half written straight into the output (no concatenation pass), tables cached per (S, D)."""
     d = x.shape[-1]
-    inv = 1.0 / (theta ** (torch.arange(0, d, 2, device=x.device, dtype=torch.float32) / d))
-    ang = pos.float()[:, None] * inv[None, :]
-    cos, sin = torch.cos(ang)[None, None].to(x.dtype), torch.sin(ang)[None, None].to(x.dtype)
+    cos, sin = _rope_tables(x.shape[-2], d, x.device, x.dtype, theta)
     x1, x2 = x[..., : d // 2], x[..., d // 2:]
-    return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], dim=-1)
+    out = torch.empty_like(x)
+    torch.addcmul(x1 * cos, x2, sin, value=-1, out=out[..., : d // 2])
+    torch.addcmul(x2 * cos, x1, sin, out=out[..., d // 2:])
+    return out
 
 
 class LlamaLayer(torch.nn.Module):
@@ -70,8 +85,7 @@ class LlamaLayer(torch.nn.Module):
         q = q.view(B, S, self.heads, self.hd).transpose(1, 2)
         k = k.view(B, S, self.kv_heads, self.hd).transpose(1, 2)
         v = v.view(B, S, self.kv_heads, self.hd).transpose(1, 2)
-        pos = torch.arange(S, device=h.device)
-        q, k = _rope(q, pos), _rope(k, pos)
+        q, k = _rope(q), _rope(k)
         if self.kv_heads != self.heads:
             r = self.heads // self.kv_heads
             k, v = k.repeat_interleave(r, dim=1), v.repeat_interleave(r, dim=1)
