@@ -144,8 +144,9 @@ struct EpiI32 {
     int32_t *out;
     int64_t N;
     bool vec_ok;
-    __device__ __forceinline__ EpiI32 with_slab(int s, int64_t M, int64_t Ncols) const { return EpiI32{out + (int64_t)s * M * Ncols, N, vec_ok}; }
-    __device__ __forceinline__ const EpiI32 &with_group(int, int64_t) const { return *this; }
+    // the functor a block works with: split-K slab `split` of [M, Ncols] int32, group `grp` of a grouped launch.
+    // One by-value expression (no conditionally modified copy: that ended up in scratch memory).
+    __device__ __forceinline__ EpiI32 rebased(int, int split, int64_t M, int64_t Ncols) const { return EpiI32{out + (int64_t)split * M * Ncols, N, vec_ok}; }
     __device__ __forceinline__ float row(int64_t) const { return 1.0f; }
     __device__ __forceinline__ void cols(int64_t, int64_t, v4f &, v4f &) const {}
     __device__ __forceinline__ void store4(int64_t m, int64_t n, const v4i &a, float, const v4f &, const v4f &, int64_t Ncols) const
@@ -178,14 +179,10 @@ template <int DT, bool HAS_ROW, bool HAS_COL, bool HAS_BIAS> struct EpiDequant {
     bool vec_ok;
     const float *s_group;  // grouped launches: per-group scalar dequant scale [ngroups] (device) or null
 
-    __device__ __forceinline__ const EpiDequant &with_slab(int, int64_t, int64_t) const { return *this; }
-    __device__ __forceinline__ EpiDequant with_group(int e, int64_t Ncols) const
+    __device__ __forceinline__ EpiDequant rebased(int grp, int, int64_t, int64_t Ncols) const
     {
-        EpiDequant r = *this;
-        if (s_group) r.s_scalar = s_group[e];
-        if constexpr (HAS_COL) r.s_col += (int64_t)e * Ncols;
-        if constexpr (HAS_BIAS) r.bias += (int64_t)e * Ncols;
-        return r;
+        return EpiDequant{out, N, s_group ? s_group[grp] : s_scalar, s_row, HAS_COL ? s_col + (int64_t)grp * Ncols : s_col,
+                          HAS_BIAS ? bias + (int64_t)grp * Ncols : bias, order, vec_ok, s_group};
     }
     __device__ __forceinline__ float row(int64_t m) const { return HAS_ROW ? s_row[m] : 1.0f; }
 
@@ -271,8 +268,7 @@ struct EpiI8 {  // out = sat_i8(rne(alpha*acc + beta*c)), c = previous out
     int64_t N;
     float alpha, beta;
     bool vec_ok;
-    __device__ __forceinline__ const EpiI8 &with_slab(int, int64_t, int64_t) const { return *this; }
-    __device__ __forceinline__ const EpiI8 &with_group(int, int64_t) const { return *this; }
+    __device__ __forceinline__ EpiI8 rebased(int, int, int64_t, int64_t) const { return *this; }
     __device__ __forceinline__ float row(int64_t) const { return 1.0f; }
     __device__ __forceinline__ void cols(int64_t, int64_t, v4f &, v4f &) const {}
     __device__ __forceinline__ int one(int acc, int c) const
@@ -332,13 +328,10 @@ template <int DT, bool HAS_BIAS, class MMA_ = MmaFp8> struct EpiFp8 {
     const float *bias;
     bool vec_ok;
     const float *w_scale_group = nullptr;  // grouped launches: per-group weight scale [ngroups] (device)
-    __device__ __forceinline__ const EpiFp8 &with_slab(int, int64_t, int64_t) const { return *this; }
-    __device__ __forceinline__ EpiFp8 with_group(int e, int64_t Ncols) const
+    __device__ __forceinline__ EpiFp8 rebased(int grp, int, int64_t, int64_t Ncols) const
     {
-        EpiFp8 r = *this;
-        if (w_scale_group) r.w_scale = w_scale_group[e];
-        if constexpr (HAS_BIAS) r.bias += (int64_t)e * Ncols;
-        return r;
+        return EpiFp8{out, N, a_scale_dev, a_per_token, a_scale_host, w_scale_group ? w_scale_group[grp] : w_scale,
+                      HAS_BIAS ? bias + (int64_t)grp * Ncols : bias, vec_ok, w_scale_group};
     }
     __device__ __forceinline__ float row(int64_t m) const { return a_scale_dev ? (a_per_token ? a_scale_dev[m] : a_scale_dev[0]) : a_scale_host; }
     __device__ __forceinline__ void cols(int64_t n, int64_t Ncols, v4f &sc, v4f &b) const

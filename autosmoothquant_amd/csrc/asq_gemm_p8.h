@@ -123,9 +123,9 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
     // are the row offsets (device int32), w is [ngroups][N][K].  The grid is the host-side upper bound
     // floor(M/256) + ngroups tile rows; each block finds its (group, tile) by a scalar scan, surplus blocks exit.
     constexpr int GM = 4;
-    int split = 0, id;
+    int split = 0, id, grp = 0;
     int64_t m_base = 0;
-    Epi epi = epi_in;
+    const int64_t M_all = M;
     if (goffs != nullptr) {
         int gid = xcd_remap(blockIdx.x, gridDim.x), e = 0, r0 = 0, r1 = 0, tm_e = 0;
         for (; e < ngroups; ++e) {
@@ -142,14 +142,14 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
         m_base = r0;
         M = r1;  // rows >= r1 belong to the next group: clamp loads, mask stores
         w += (int64_t)e * N * K;
-        epi = epi_in.with_group(e, N);
+        grp = e;
     } else {
         const int nwg = tiles_m * tiles_n;
         const int lid = xcd_remap(blockIdx.x, nwg * ksplit);
         split = lid / nwg;
         id = lid - split * nwg;
-        epi = epi_in.with_slab(split, M, N);
     }
+    const Epi epi = epi_in.rebased(grp, split, M_all, N);
     const int per_group = GM * tiles_n;
     const int group = id / per_group, in_group = id - group * per_group;
     const int first_m = group * GM;

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8h(const int8_t *__restrict__
     const int nwg = tiles_m * tiles_n;
     const int lid = xcd_remap(blockIdx.x, nwg * ksplit);
     const int split = lid / nwg, id = lid - split * nwg;
-    const Epi epi = epi_in.with_slab(split, M, N);
+    const Epi epi = epi_in.rebased(0, split, M, N);
     const int per_group = GM * tiles_n;
     const int group = id / per_group, in_group = id - group * per_group;
     const int first_m = group * GM;

@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
     const int64_t nitems = (((N + 16 * NT - 1) / (16 * NT) + 7) / 8) * 8 * mblocks;  // tiles padded to groups of 8 (padding items store nothing)
     const int my_tiles = (int)((nitems - blockIdx.x + gridDim.x - 1) / gridDim.x);
     const int total = my_tiles * upt;  // (item, unit) pairs of this wave, item-major
-    auto decode = [&](int i, int64_t &n0, int &mb) {
+    auto decode = [&](int i, int64_t &n0, int &mb) __attribute__((always_inline)) {
         const int64_t gidx = (int64_t)blockIdx.x + (int64_t)i * gridDim.x;
         const int64_t grp = gidx / (8 * mblocks), rem = gidx - grp * (8 * mblocks);
         mb = (int)(rem >> 3);
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
     unsigned woff[NT][2];
     int cur_item = -1;
     int64_t it_n0 = 0;
-    auto issue = [&](int stage) {
+    auto issue = [&](int stage) __attribute__((always_inline)) {
         if (it_tile != cur_item) {  // new work item: per-lane W / X offsets (clamped at the ragged edges)
             cur_item = it_tile;
             int mb;
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
         for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = (acc4_t){0, 0, 0, 0};
 
     int done = 0, c_u = 0, c_tile = 0;
-    auto tile_end = [&]() {  // block-wide: sum the wpb partials of this channel tile, fused epilogue
+    auto tile_end = [&]() __attribute__((always_inline)) {  // block-wide: sum the wpb partials of this channel tile, fused epilogue
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
         ++c_tile;
     };
 
-    auto step = [&](auto stage_tag) {
+    auto step = [&](auto stage_tag) __attribute__((always_inline)) {
         constexpr int S = decltype(stage_tag)::value;
         if (issued < total) issue((S + 2) % SK_STAGES);
         const int newer = issued - done - 1;  // units issued after the one consumed now (0..2)
