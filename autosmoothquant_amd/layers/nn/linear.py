@@ -49,6 +49,9 @@ class Int8GEMM(object):
         return self.i8cugemm
 
 
+# The reference decorates every forward with @torch.no_grad().  The int8 forwards below never record an autograd
+# graph in the first place (their outputs are fresh buffers filled through the C-ABI), so the decorator's ~2 us of
+# context management per call is dropped on this hot path; the result is the same: outputs never require grad.
 class _W8A8Base(torch.nn.Module):
     """Shared plumbing: buffers, host-pinned scalar scales, shape handling."""
     _host_scalars = ("dequant_scale",)
@@ -125,7 +128,6 @@ class W8A8BFP32OFP32Linear(_W8A8Base):
     norm, reference models/llama.py:326-339) -> round+clamp only.  per-token: dynamic
     absmax/127 per row (reference :83-106)."""
 
-    @torch.no_grad()
     def forward(self, x):
         if isinstance(x, QuantizedActivation):
             return _prequantized_forward(self, x, self._scalar("dequant_scale"), None)
@@ -171,7 +173,6 @@ class W8A8BFP32OFP32QKVLinear(_W8A8Base):
             self._scol_cache = (key, torch.cat(parts).to(device))
         return self._scol_cache[1]
 
-    @torch.no_grad()
     def forward(self, x):
         if isinstance(x, QuantizedActivation):
             return _prequantized_forward(self, x, 1.0, self._scale_vector(x.xq.device))
@@ -211,7 +212,6 @@ class W8A8BFP32OFP32LinearWithQuantScale(_W8A8Base):
             self._host_scalars = ("dequant_scale", "quant_scale")
             self.register_buffer("quant_scale", torch.tensor(1.0, dtype=torch.float32, requires_grad=False))
 
-    @torch.no_grad()
     def forward(self, x):
         if isinstance(x, QuantizedActivation):  # already quantised for this module (fused.silu_mul_q)
             return _prequantized_forward(self, x, self._scalar("dequant_scale"), None)

@@ -367,3 +367,15 @@ def test_grouped_launch_equals_per_group_calls(counts, per_token, dev):
                                       None, bias[g] if use_bias else None)
                 assert torch.equal(got[o:o + c], ref), (g, c, use_bias)
             o += c
+
+
+def test_forward_outputs_never_require_grad(dev):
+    """The reference decorates forward with @torch.no_grad(); here no autograd graph is recorded at all, so even an input
+    that requires grad (under grad mode) yields an output that does not."""
+    from autosmoothquant_amd.layers.nn.linear import W8A8BFP32OFP32Linear, W8A8BFP32OFP32LinearWithQuantScale, W8A8BFP32OFP32QKVLinear
+    x = torch.randn(5, 256, device=dev, requires_grad=True)
+    with torch.enable_grad():
+        for m in (W8A8BFP32OFP32Linear(256, 128), W8A8BFP32OFP32LinearWithQuantScale(256, 128, False, "per-token"),
+                  W8A8BFP32OFP32QKVLinear([64, 32, 32], 256, 128)):
+            y = m.to(dev)(x)
+            assert not y.requires_grad and y.grad_fn is None

@@ -20,3 +20,27 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(2000): m(x)
 pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats('cumulative').print_stats(14)
+
+# ---- where the per-call time goes: the bare C-ABI call (two kernel launches) vs the Python around it
+from autosmoothquant_amd import _lib as L
+lib = L.lib()
+M, K, N = 32, 4096, 4096
+nbytes = lib.asq_linear_w8a8_workspace_bytes(M, N, K)
+ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+out = torch.empty(M, N, dtype=torch.float16, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+args = (x.data_ptr(), L.ASQ_F16, m.weight.data_ptr(), out.data_ptr(), M, N, K, L.ASQ_ACT_ROUND, 1.0, 1.0, None, None, ws.data_ptr(), nbytes, st)
+for _ in range(20): lib.asq_linear_w8a8_forward(*args)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(2000): lib.asq_linear_w8a8_forward(*args)
+t1 = time.perf_counter(); torch.cuda.synchronize()
+print('bare ctypes call (quantise + GEMM launches) us', (t1 - t0) / 2000 * 1e6)
+t0 = time.perf_counter()
+for _ in range(2000): torch.empty((M, N), dtype=torch.float16, device=dev); torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+t1 = time.perf_counter()
+print('two torch.empty us', (t1 - t0) / 2000 * 1e6)
+t0 = time.perf_counter()
+for _ in range(2000): ops.linear_w8a8_forward(x, m.weight, "per-tensor-round", 1.0, 1.0)
+t1 = time.perf_counter(); torch.cuda.synchronize()
+print('ops.linear_w8a8_forward us', (t1 - t0) / 2000 * 1e6)
