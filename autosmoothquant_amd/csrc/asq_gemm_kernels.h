@@ -428,7 +428,18 @@ __device__ __forceinline__ void epilogue_wave(const Epi &epi, Get get, MOff moff
 // ds_read_b128 are conflict-free.  No block barrier: each
 // wave only re-reads what it wrote; LDS operations of one wave execute in order.
 // Needs: out 16-B aligned and N * sizeof(out element) % 16 == 0 (then a 16-B chunk is never ragged).
-template <int NTM, class Epi, class Get>  // NTM = 32-row token tiles of the wave tile: 4 (256-row block tile) or 2 (128-row)
+// 16-byte global store with an explicit cache policy: 0 = default (write-back in the XCD's L2), 1 = nt (streaming),
+// 2 = sc1, 3 = sc0 sc1 (write-through: the line leaves the L2 with the store, nothing stays dirty for the
+// end-of-kernel release to write back).  tools/ubench/clock_probe measures them; see DESIGN.md section 4.
+template <int POL> __device__ __forceinline__ void store16_policy(void *p, const v4i &v)
+{
+    if constexpr (POL == 0) *(v4i *)p = v;
+    else if constexpr (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    else if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int NTM, int POL = 0, class Epi, class Get>  // NTM = 32-row token tiles of the wave tile: 4 (256-row block tile) or 2 (128-row)
 __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, int64_t M, int64_t N, unsigned stage)
 {
     constexpr int EB = Epi::kOutBytes;
@@ -482,7 +493,7 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
             v4i v = *(lds_v4i)(uintptr_t)(stage + i * 1024 + lane * 16);
             if ((lane >> 3) & 1) v = (v4i){v[2], v[3], v[0], v[1]};  // odd rows were staged with their 8-byte halves flipped
             const int64_t m = mw0 + row, n = nw0 + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
-            if (m < M && n < N) *(v4i *)(outb + (m * N + n) * 2) = v;
+            if (m < M && n < N) store16_policy<POL>(outb + (m * N + n) * 2, v);
         }
     } else {
 #pragma unroll
@@ -507,7 +518,7 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
                 const int row = 4 * i + (lane >> 4);
                 const v4i v = *(lds_v4i)(uintptr_t)(stage + i * 1024 + lane * 16);
                 const int64_t m = mw0 + 64 * h + row, n = nw0 + (((lane & 15) ^ (row & 15)) << 2);
-                if (m < M && n < N) *(v4i *)(outb + (m * N + n) * 4) = v;
+                if (m < M && n < N) store16_policy<POL>(outb + (m * N + n) * 4, v);
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");

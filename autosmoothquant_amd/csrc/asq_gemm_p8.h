@@ -50,16 +50,34 @@ constexpr int P8_LDS_BYTES = 2 * P8_STAGE;
 #define P8_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define P8_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-// ---- probe support (tools/ubench/p8_probe.hip): ablation + per-phase s_memtime stamps -------
+// ---- probe support.  Production TUs never define ASQ_P8_PROBE: the ABL template parameter is then pinned to 0 and every
+// probe macro below is empty (no device globals, no s_memtime).  tools/ubench/{p8_probe,clock_probe}.hip define it
+// before including the sources and own the stamp arrays.
 //   ABL 1 = no LDS-DMA, 2 = no fragment ds_reads, 4 = no MFMA, 8 = no barriers, 16 = every fragment read issued twice,
-//       32 = timing stamps of block 0 waves 0/4, 64 = no s_setprio.   Production uses ABL = 0.
+//       32 = timing stamps of block 0 waves 0/4, 64 = no s_setprio, 128 = per-block stamps,
+//       256 / 512 / 768 = epilogue stores nt / sc1 / sc0 sc1 instead of P8_STORE_DEFAULT.
+#ifdef ASQ_P8_PROBE
 static __device__ unsigned long long p8_dbg[2][4][8];
-static __device__ unsigned long long p8_blk[4096][6];  // ABL & 128: per-block {start, prologue done, loop done, end, xcc_id, tile id}
+// ABL & 128: per-block {start, prologue done, loop done, end} in s_memtime ticks, xcc_id, tile id, {start, end} in s_memrealtime (100 MHz) ticks
+static __device__ unsigned long long p8_blk[4096][8];
+#define P8_ABL_OK(ABL) true
 #define P8_BLK(i) do { if constexpr (ABL & 128) { if (wave == 0 && lane == 0 && blockIdx.x < 4096) p8_blk[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } } while (0)
-#define P8_BAR() do { if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier(); } while (0)
-#define P8_PRIO(v) do { if constexpr (!(ABL & 64)) __builtin_amdgcn_s_setprio(v); } while (0)
+#define P8_BLK_RT(i) do { if constexpr (ABL & 128) { if (wave == 0 && lane == 0 && blockIdx.x < 4096) p8_blk[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #define P8_STAMP(i) do { if constexpr (ABL & 32) st[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define P8_ACCUM(ph) do { if constexpr (ABL & 32) { _Pragma("unroll") for (int q_ = 0; q_ < 7; ++q_) tacc[ph][q_] += st[q_ + 1] - st[q_]; } } while (0)
+#else
+#define P8_ABL_OK(ABL) ((ABL) == 0)
+#define P8_BLK(i) do { } while (0)
+#define P8_BLK_RT(i) do { } while (0)
+#define P8_STAMP(i) do { } while (0)
+#define P8_ACCUM(ph) do { } while (0)
+#endif
+#ifndef P8_STORE_DEFAULT
+#define P8_STORE_DEFAULT 0   // cache policy of the staged epilogue's global stores (store16_policy)
+#endif
+#define P8_STORE_POLICY(ABL) ((((ABL) >> 8) & 3) ? (((ABL) >> 8) & 3) : P8_STORE_DEFAULT)
+#define P8_BAR() do { if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier(); } while (0)
+#define P8_PRIO(v) do { if constexpr (!(ABL & 64)) __builtin_amdgcn_s_setprio(v); } while (0)
 
 template <int ABL, class MMA> __device__ __forceinline__ typename MMA::acc_t p8_mfma(const v4i &a, const v4i &b, const typename MMA::acc_t &c)
 {
@@ -115,7 +133,9 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+    static_assert(P8_ABL_OK(ABL), "probe variants need -DASQ_P8_PROBE (tools/ubench)");
 
+    P8_BLK_RT(6);
     P8_BLK(0);
     // split-K (ksplit > 1, int32 slabs only): logical id = split * ntiles + tile, so the blocks an XCD
     // receives share one K range and neighbouring tiles (operand panels stay L2-local)
@@ -227,9 +247,11 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
     P8_BLK(1);
 
     v4i xf[2][4], wa[4], wb[4];
+#ifdef ASQ_P8_PROBE
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tacc[4][7] = {};
     (void)st;
     (void)tacc;
+#endif
 
     // one K-tile at LDS stage S (compile-time), prefetching K-tile (t+1) into stage S^1
     auto ktile = [&](auto stage_tag, int t) {
@@ -379,11 +401,13 @@ if constexpr (MMA::kIsInt) {
     }
     if (t < nt) ktile(std::integral_constant<int, 0>{}, t);
 
+#ifdef ASQ_P8_PROBE
     if constexpr (ABL & 32) {
         if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))
             for (int a = 0; a < 4; ++a)
                 for (int b = 0; b < 7; ++b) p8_dbg[wave >> 2][a][b] = tacc[a][b];
     }
+#endif
     P8_BLK(2);
     P8_WAIT_VM(0);          // drain the dead prefetches before LDS is released
     if (wm == 0) P8_BAR();  // balance the stagger barrier
@@ -395,14 +419,16 @@ if constexpr (MMA::kIsInt) {
     if (staged) {
         if constexpr (Epi::kOutBytes >= 2) {
             P8_BAR();  // every wave's ring reads are done and every wave's (dead) DMAs have landed: the ring becomes staging space
-            epilogue_wave_staged<4>(epi, get, m0 + wm * 128, n0 + wn * 64, lane, M, N, lds0 + wave * 16384);
+            epilogue_wave_staged<4, P8_STORE_POLICY(ABL)>(epi, get, m0 + wm * 128, n0 + wn * 64, lane, M, N, lds0 + wave * 16384);
         }
     } else {
         epilogue_wave<2, 4>(epi, get, [](int im) { return im * 32; }, m0 + wm * 128, n0 + wn * 64, lane, M, N);
     }
+#ifdef ASQ_P8_PROBE
     if constexpr (ABL & 128) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         P8_BLK(3);
+        P8_BLK_RT(7);
         if (wave == 0 && lane == 0 && blockIdx.x < 4096) {
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -410,6 +436,7 @@ if constexpr (MMA::kIsInt) {
             p8_blk[blockIdx.x][5] = (unsigned)(tile_m * 65536 + tile_n);
         }
     }
+#endif
 }
 
 }  // namespace asq

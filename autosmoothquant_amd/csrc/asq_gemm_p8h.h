@@ -32,7 +32,11 @@ namespace asq {
 constexpr int P8H_STAGE = 3 * P8_UNIT;      // 48 KiB
 constexpr int P8H_LDS_BYTES = 3 * P8H_STAGE;  // 144 KiB
 
+#ifdef ASQ_P8_PROBE
 #define P8H_BLK(i) do { if constexpr (PROBE) { if (wave == 0 && lane == 0 && blockIdx.x < 4096) p8_blk[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define P8H_BLK(i) do { } while (0)
+#endif
 
 template <class Epi, bool PROBE = false>  // PROBE: per-block s_memtime stamps for tools/ubench/p8_probe (production: false)
 __global__ void __launch_bounds__(512, 2) gemm_i8_p8h(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
@@ -206,6 +210,7 @@ if constexpr (MMA::kIsInt) {
     } else {
         epilogue_wave<2, 2>(epi, get, [](int im) { return im * 32; }, m0 + wm * 64, n0 + wn * 64, lane, M, N);
     }
+#ifdef ASQ_P8_PROBE
     if constexpr (PROBE) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         P8H_BLK(3);
@@ -216,6 +221,7 @@ if constexpr (MMA::kIsInt) {
             p8_blk[blockIdx.x][5] = (unsigned)(tile_m * 65536 + tile_n);
         }
     }
+#endif
 }
 
 }  // namespace asq

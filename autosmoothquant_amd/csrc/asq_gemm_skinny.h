@@ -63,11 +63,7 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int UNIT = (NT + MT) * 2048;  // one 128-byte K unit: NT x 16 W rows + MT x 16 X rows
-#ifdef SK_PROBE_NOX
-    constexpr int D = 2 * NT;
-#else
     constexpr int D = 2 * (NT + MT);        // DMA instructions per unit per wave
-#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
@@ -142,12 +138,10 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 2; ++i) sk_dma16(wb, woff[nt][i], dst + nt * 2048 + i * 1024);
-#ifndef SK_PROBE_NOX  // dev probe (tools/ubench): -DSK_PROBE_NOX streams W only (results invalid)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 2; ++i) sk_dma16(xb, xoff[mt][i], dst + (NT + mt) * 2048 + i * 1024);
-#endif
         ++issued;
         if (++it_u == upt) {
             it_u = 0;

@@ -206,6 +206,36 @@ template <int DT> int quantize_dt(const void *x, int mode, float quant_scale, in
 // result equals the two-kernel path except at rounding boundaries (tests: <= 1e-3 of entries, +-1).
 // LAYERNORM additionally subtracts the mean and adds a bias (OPT, reference models/opt.py:20-29).
 // ---------------------------------------------------------------------------------
+// 1 / sqrt(v) from one correctly rounded square root and one correctly rounded division (hipcc keeps fp32 sqrt and
+// division IEEE by default): what torch.rsqrt computes on the host, and reproducible operation by operation in
+// oracle/n1.py -- v_rsq_f32 (1 ulp, implementation-defined) is not.
+__device__ __forceinline__ float rsqrt_exact(float v) { return __fdiv_rn(1.0f, __fsqrt_rn(v)); }
+
+// exp(x) as a fixed sequence of IEEE fp32 operations (no FMA, no library call): Cody-Waite reduction by ln 2,
+// degree-7 Taylor polynomial in Horner form, scaling by two exact powers of two.  <= ~2 ulp from the true value
+// on [-87, 88]; +inf above 88.8, 0 below -104; NaN propagates.  oracle/n1.py::exp_det repeats it step by step, so
+// every kernel that uses it is compared with the oracle bit for bit (libm / ocml exp differ in the last ulp between
+// implementations, which is what made the r1 silu test a +-1 comparison).
+__device__ __forceinline__ float pow2i(int k) { return __int_as_float((k + 127) << 23); }  // 2^k, -126 <= k <= 127
+__device__ __forceinline__ float exp_det(float x)
+{
+    if (!(x == x)) return x;
+    x = fminf(fmaxf(x, -104.0f), 89.0f);
+    const float n = rintf(__fmul_rn(x, 1.44269502162933349609375f));          // round-half-even(x * log2 e)
+    float r = __fadd_rn(x, -__fmul_rn(n, 0.693138122558593750f));             // ln2_hi (17 significant bits)
+    r = __fadd_rn(r, -__fmul_rn(n, 9.05800061445916071534156799316e-06f));    // ln2_lo
+    float p = 1.0f / 5040.0f;
+    p = __fadd_rn(__fmul_rn(p, r), 1.0f / 720.0f);
+    p = __fadd_rn(__fmul_rn(p, r), 1.0f / 120.0f);
+    p = __fadd_rn(__fmul_rn(p, r), 1.0f / 24.0f);
+    p = __fadd_rn(__fmul_rn(p, r), 1.0f / 6.0f);
+    p = __fadd_rn(__fmul_rn(p, r), 0.5f);
+    p = __fadd_rn(__fmul_rn(p, r), 1.0f);
+    p = __fadd_rn(__fmul_rn(p, r), 1.0f);
+    const int ni = (int)n, n1 = ni >> 1, n2 = ni - n1;                          // |n1|, |n2| <= 75
+    return __fmul_rn(__fmul_rn(p, pow2i(n1)), pow2i(n2));
+}
+
 __device__ __forceinline__ float block_sum_256(float v, float *red)
 {
 #pragma unroll
@@ -231,14 +261,31 @@ template <int DT> __device__ __forceinline__ void vec_unpack(const v4i &v, float
     }
 }
 
-template <int DT, int NV, bool LAYERNORM, bool PER_TOKEN>
-__global__ void __launch_bounds__(256) norm_quant_cached(const void *__restrict__ xv, const void *__restrict__ wv, const void *__restrict__ bv, float eps,
+template <int DT> __device__ __forceinline__ v4i vec_pack(const float (&f)[ElemT<DT>::VEC])
+{
+    if constexpr (DT == ASQ_F32) {
+        return (v4i){__float_as_int(f[0]), __float_as_int(f[1]), __float_as_int(f[2]), __float_as_int(f[3])};
+    } else {
+        v4i v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (int)((uint32_t)ElemT<DT>::store(f[2 * i]) | ((uint32_t)ElemT<DT>::store(f[2 * i + 1]) << 16));
+        return v;
+    }
+}
+
+// ADD: the residual-add form (the reference's dq_add_layernorm_q, csrc/kernels/fused.cu:5-25, with a floating `x`
+// -- here the previous GEMM's epilogue has already dequantised): h = dt(x + residual) is written to `hout` (the
+// new residual stream) and normalised + quantised in the same pass.
+template <int DT, int NV, bool LAYERNORM, bool PER_TOKEN, bool ADD>
+__global__ void __launch_bounds__(256) norm_quant_cached(const void *__restrict__ xv, const void *__restrict__ resv, void *__restrict__ hout,
+                                                         const void *__restrict__ wv, const void *__restrict__ bv, float eps,
                                                          int8_t *__restrict__ xq, float *__restrict__ s_row, int K)
 {
     constexpr int VEC = ElemT<DT>::VEC;
     __shared__ float red[4];
     const int64_t row = blockIdx.x;
-    const char *xrow = (const char *)xv + row * (int64_t)K * (16 / VEC);
+    const int64_t rowoff = row * (int64_t)K * (16 / VEC);
+    const char *xrow = (const char *)xv + rowoff;
     const int nvec = K / VEC;
     float f[NV][VEC];
     float sum = 0.f, sq = 0.f;
@@ -247,25 +294,35 @@ __global__ void __launch_bounds__(256) norm_quant_cached(const void *__restrict_
         const int idx = i * 256 + threadIdx.x;
         if (idx < nvec) {
             vec_unpack<DT>(*(const v4i *)(xrow + (int64_t)idx * 16), f[i]);
+            if constexpr (ADD) {
+                float r[VEC];
+                vec_unpack<DT>(*(const v4i *)((const char *)resv + rowoff + (int64_t)idx * 16), r);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) f[i][j] = ElemT<DT>::round(__fadd_rn(r[j], f[i][j]));  // torch.add(residual, x) in dt
+                *(v4i *)((char *)hout + rowoff + (int64_t)idx * 16) = vec_pack<DT>(f[i]);
+            }
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                sum += f[i][j];
-                sq += f[i][j] * f[i][j];
+                sum = __fadd_rn(sum, f[i][j]);
+                sq = __fadd_rn(sq, __fmul_rn(f[i][j], f[i][j]));
             }
         }
     }
     float mean = 0.f;
     if constexpr (LAYERNORM) {
-        mean = block_sum_256(sum, red) / (float)K;
+        mean = __fdiv_rn(block_sum_256(sum, red), (float)K);
         sq = 0.f;  // two-pass variance, as ATen's layer_norm
 #pragma unroll
         for (int i = 0; i < NV; ++i)
             if (i * 256 + threadIdx.x < nvec)
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) sq += (f[i][j] - mean) * (f[i][j] - mean);
+                for (int j = 0; j < VEC; ++j) {
+                    const float d = __fadd_rn(f[i][j], -mean);
+                    sq = __fadd_rn(sq, __fmul_rn(d, d));
+                }
     }
-    const float var = block_sum_256(sq, red) / (float)K;
-    const float rs = rsqrtf(var + eps);
+    const float var = __fdiv_rn(block_sum_256(sq, red), (float)K);
+    const float rs = rsqrt_exact(__fadd_rn(var, eps));
     uint32_t amax = 0;  // |y| maximum as an fp32 bit pattern (see AbsMax)
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -278,7 +335,7 @@ __global__ void __launch_bounds__(256) norm_quant_cached(const void *__restrict_
             for (int j = 0; j < VEC; ++j) {
                 float y;
                 if constexpr (LAYERNORM) {
-                    y = ElemT<DT>::round(__fadd_rn(__fmul_rn(__fmul_rn(f[i][j] - mean, rs), wf[j]), bf[j]));
+                    y = ElemT<DT>::round(__fadd_rn(__fmul_rn(__fmul_rn(__fadd_rn(f[i][j], -mean), rs), wf[j]), bf[j]));
                 } else {
                     const float n = ElemT<DT>::round(__fmul_rn(f[i][j], rs));  // hidden_states.to(input_dtype)
                     y = ElemT<DT>::round(__fmul_rn(wf[j], n));                 // self.weight * ...
@@ -314,13 +371,14 @@ __global__ void __launch_bounds__(256) norm_quant_cached(const void *__restrict_
     }
 }
 
-template <int DT, bool LN, bool PT>
-int launch_norm_quant(const void *x, const void *w, const void *b, float eps, int8_t *xq, float *s_row, int64_t M, int64_t K, hipStream_t s)
+template <int DT, bool LN, bool PT, bool ADD = false>
+int launch_norm_quant(const void *x, const void *w, const void *b, float eps, int8_t *xq, float *s_row, int64_t M, int64_t K, hipStream_t s,
+                      const void *res = nullptr, void *hout = nullptr)
 {
     constexpr int VEC = ElemT<DT>::VEC;
     const int64_t nvec = K / VEC;
     dim3 grid((unsigned)M), block(256);
-#define ASQ_NQ(NV) hipLaunchKernelGGL((norm_quant_cached<DT, NV, LN, PT>), grid, block, 0, s, x, w, b, eps, xq, s_row, (int)K)
+#define ASQ_NQ(NV) hipLaunchKernelGGL((norm_quant_cached<DT, NV, LN, PT, ADD>), grid, block, 0, s, x, res, hout, w, b, eps, xq, s_row, (int)K)
     if (nvec <= 256 * 1) ASQ_NQ(1);
     else if (nvec <= 256 * 2) ASQ_NQ(2);
     else if (nvec <= 256 * 4) ASQ_NQ(4);
@@ -334,8 +392,8 @@ int launch_norm_quant(const void *x, const void *w, const void *b, float eps, in
 // down_proj's quantiser (W8A8BFP32OFP32LinearWithQuantScale: per-token, or per-tensor x / quant_scale,
 // reference linear.py:283-292).  a = dt(dt(g / (1 + exp(-g))) * u) as the two ATen ops compute it; the
 // [M, K] fp16 product never reaches HBM (reads 2 x s_in, writes 1 B per element instead of
-// reading 3 x and writing s_in + 1).  exp() differs in the last ulp between libraries, so -- like the
-// norm fusion -- the int8 result can differ by +-1 at rounding boundaries.
+// reading 3 x and writing s_in + 1).  exp() is exp_det above: bit-identical to oracle/n1.py; against
+// torch's silu (a different exp) the int8 result can differ by +-1 at rounding boundaries.
 // ---------------------------------------------------------------------------------
 template <int DT, int NV, bool PER_TOKEN>
 __global__ void __launch_bounds__(256) silu_mul_quant_cached(const void *__restrict__ gv, const void *__restrict__ uv, float quant_scale,
@@ -358,7 +416,7 @@ __global__ void __launch_bounds__(256) silu_mul_quant_cached(const void *__restr
             vec_unpack<DT>(*(const v4i *)(urow + (int64_t)idx * 16), u);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                const float sl = ElemT<DT>::round(g[j] / (1.0f + expf(-g[j])));
+                const float sl = ElemT<DT>::round(__fdiv_rn(g[j], __fadd_rn(1.0f, exp_det(-g[j]))));
                 a[i][j] = ElemT<DT>::round(__fmul_rn(sl, u[j]));
                 if constexpr (PER_TOKEN) amax = umax32(amax, absbits(a[i][j]));
             }
@@ -448,6 +506,31 @@ extern "C" int asq_norm_quantize(const void *x, int x_dtype, const void *weight,
     default: return ASQ_NQD(ASQ_BF16);
     }
 #undef ASQ_NQD
+}
+
+extern "C" int asq_add_norm_quantize(const void *x, const void *residual, void *h_out, int x_dtype, const void *weight, const void *bias, float eps,
+                                     int per_token, int8_t *xq, float *s_row, int64_t M, int64_t K, void *stream)
+{
+    ASQ_REQUIRE(M >= 0 && K > 0 && M < (1ll << 31), ASQ_ERR_DIM, "asq_add_norm_quantize: bad dims");
+    ASQ_REQUIRE(x_dtype == ASQ_F32 || x_dtype == ASQ_F16 || x_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_add_norm_quantize: bad x_dtype %d", x_dtype);
+    if (M == 0) return ASQ_OK;
+    ASQ_REQUIRE(x && residual && h_out && weight && xq && (!per_token || s_row), ASQ_ERR_NULL, "asq_add_norm_quantize: NULL pointer");
+    const int vec = x_dtype == ASQ_F32 ? 4 : 8;
+    ASQ_REQUIRE(K % vec == 0 && K / vec <= 256 * 8, ASQ_ERR_DIM, "asq_add_norm_quantize: K must be a multiple of %d and <= %d", vec, 256 * 8 * vec);
+    ASQ_REQUIRE(((((uintptr_t)x | (uintptr_t)residual | (uintptr_t)h_out | (uintptr_t)weight | (uintptr_t)bias) & 15) == 0) && (((uintptr_t)xq & (vec - 1)) == 0),
+                ASQ_ERR_ALIGN, "asq_add_norm_quantize: x / residual / h_out / weight / bias must be 16-B aligned");
+    hipStream_t s = (hipStream_t)stream;
+#define ASQ_ANQ(DT_)                                                                                                                       \
+    (bias ? (per_token ? launch_norm_quant<DT_, true, true, true>(x, weight, bias, eps, xq, s_row, M, K, s, residual, h_out)               \
+                       : launch_norm_quant<DT_, true, false, true>(x, weight, bias, eps, xq, s_row, M, K, s, residual, h_out))             \
+          : (per_token ? launch_norm_quant<DT_, false, true, true>(x, weight, bias, eps, xq, s_row, M, K, s, residual, h_out)              \
+                       : launch_norm_quant<DT_, false, false, true>(x, weight, bias, eps, xq, s_row, M, K, s, residual, h_out)))
+    switch (x_dtype) {
+    case ASQ_F32: return ASQ_ANQ(ASQ_F32);
+    case ASQ_F16: return ASQ_ANQ(ASQ_F16);
+    default: return ASQ_ANQ(ASQ_BF16);
+    }
+#undef ASQ_ANQ
 }
 
 extern "C" int asq_silu_mul_quantize(const void *gate, const void *up, int x_dtype, int per_token, float quant_scale, int8_t *xq, float *s_row,

@@ -74,10 +74,11 @@ class LlamaLayer(torch.nn.Module):
 
     def attention(self, h, record=None):
         B, S, _ = h.shape
-        x = self.input_layernorm(h)   # a float tensor, or a QuantizedActivation when the norm is fused (N1)
+        alt = getattr(self, "use_fused", False)   # to_w8a8(both=True): the fused (N1) modules sit beside the reference composition
+        x = (self.input_layernorm_q if alt else self.input_layernorm)(h)   # a float tensor, or a QuantizedActivation when the norm is fused (N1)
         if record is not None:
             record["attn_in"] = x
-        if getattr(self, "qkv_proj", None) is not None:   # one GEMM over [q;k;v] (the reference's QKVLinear, as its Baichuan W_pack)
+        if getattr(self, "qkv_proj", None) is not None and (alt or getattr(self, "q_proj", None) is None):   # one GEMM over [q;k;v] (the reference's QKVLinear, as its Baichuan W_pack)
             nq, nkv = self.heads * self.hd, self.kv_heads * self.hd
             q, k, v = self.qkv_proj(x).split([nq, nkv, nkv], dim=-1)
         else:
@@ -95,10 +96,11 @@ class LlamaLayer(torch.nn.Module):
         return h + self.o_proj(a)
 
     def mlp(self, h, record=None):
-        x = self.post_attention_layernorm(h)
+        alt = getattr(self, "use_fused", False)
+        x = (self.post_attention_layernorm_q if alt else self.post_attention_layernorm)(h)
         if record is not None:
             record["mlp_in"] = x
-        if getattr(self, "fuse_act", False):  # SiLU * up quantised in one pass; the fp product never reaches HBM
+        if getattr(self, "fuse_act", False) or alt:  # SiLU * up quantised in one pass; the fp product never reaches HBM
             from .layers.nn.fused import silu_mul_q
             return h + self.down_proj(silu_mul_q(self.gate_proj(x), self.up_proj(x), self.down_proj))
         g = F.silu(self.gate_proj(x)) * self.up_proj(x)
@@ -129,11 +131,28 @@ def calibrate(layer, h):
 
 
 @torch.no_grad()
-def to_w8a8(layer, scales, quant_config=None, fuse_norm=False, fuse_qkv=False):
+def qkv_from_parts(q_proj, k_proj, v_proj):
+    """One W8A8BFP32OFP32QKVLinear over three already-quantised projections: the int8 rows are concatenated as they are
+    and each segment keeps its own dequant scale -- exactly what QKVLinear.from_float produces from the concatenated
+    float weight (per-segment absmax scales, reference linear.py:226-232)."""
+    from .layers.nn.linear import W8A8BFP32OFP32QKVLinear
+    sizes = [q_proj.out_features, k_proj.out_features, v_proj.out_features]
+    m = W8A8BFP32OFP32QKVLinear(sizes, q_proj.in_features, sum(sizes), False, q_proj.act_quant)
+    m.weight = torch.cat([q_proj.weight, k_proj.weight, v_proj.weight], dim=0)
+    for name, part in zip(m._host_scalars, (q_proj, k_proj, v_proj)):
+        setattr(m, name, part._buffers["dequant_scale"].detach().clone())
+    return m.to(q_proj.weight.device)
+
+
+@torch.no_grad()
+def to_w8a8(layer, scales, quant_config=None, fuse_norm=False, fuse_qkv=False, both=False):
     """Quantised copy of `layer`, composed exactly like the reference's
     QuantizedLlamaDecoderLayer.from_float_to_int8 (models/llama.py:289-339):
       q/k/v, gate/up : W8A8BFP32OFP32Linear(act_quant = cfg["qkv"] / cfg["fc1"]), norm weight folded iff per-tensor
-      o, down        : W8A8BFP32OFP32LinearWithQuantScale(act_quant = cfg["out"] / cfg["fc2"])."""
+      o, down        : W8A8BFP32OFP32LinearWithQuantScale(act_quant = cfg["out"] / cfg["fc2"]).
+    both=True keeps that composition AND attaches the fused (N1) modules beside it -- RMSNormQ twins of the two norms and a
+    QKVLinear over the same int8 rows; `layer.use_fused = True/False` selects the path per forward (bench.py times both
+    on one set of weights)."""
     cfg = {"qkv": "per-tensor", "out": "per-token", "fc1": "per-tensor", "fc2": "per-token"}
     cfg.update(quant_config or {})
     dev = layer.q_proj.weight.device
@@ -168,6 +187,13 @@ def to_w8a8(layer, scales, quant_config=None, fuse_norm=False, fuse_qkv=False):
         return q
     q.input_layernorm = layer.input_layernorm.folded(scales["attn_in"]) if cfg["qkv"] == "per-tensor" else layer.input_layernorm
     q.post_attention_layernorm = layer.post_attention_layernorm.folded(scales["mlp_in"]) if cfg["fc1"] == "per-tensor" else layer.post_attention_layernorm
+    if both:
+        from .layers.nn.fused import RMSNormQ
+        q.input_layernorm_q = RMSNormQ.from_float(layer.input_layernorm, scales["attn_in"], per_token=cfg["qkv"] == "per-token")
+        q.post_attention_layernorm_q = RMSNormQ.from_float(layer.post_attention_layernorm, scales["mlp_in"], per_token=cfg["fc1"] == "per-token")
+        if not fuse_qkv:
+            q.qkv_proj = qkv_from_parts(q.q_proj, q.k_proj, q.v_proj)
+        q.use_fused = False
     return q
 
 

@@ -4,16 +4,21 @@ semantics (reference autosmoothquant/layers/functional/quantization.py:9-120).
 These are offline / conversion-time helpers (plain torch ops on whatever device the
 tensor lives on); the per-forward activation quantisers of the nn modules are the HIP
 prologue kernels in csrc/asq_quant.hip, reached through ``autosmoothquant_amd.ops``.
-Arithmetic follows the reference's CPU branch: scales are computed in the tensor's own
-dtype, the division itself in fp32.
+Arithmetic follows the reference branch for branch: scales are computed in the tensor's own
+dtype; the division runs in fp32 for host tensors and IN THE TENSOR'S OWN DTYPE for device
+tensors (reference :11-16 -- its real conversion flow loads fp16 weights onto the GPU, where the
+fp16 quotient is rounded to half before ``round_()``; a device-side conversion therefore gives
+the reference's device results, a host-side one its host results; they can differ by +-1 on a
+few percent of large-magnitude entries of an fp16 weight, and are identical for fp32 weights).
 """
 import torch
 
 
 def _fp32_view(t):
     # the reference converts only non-CUDA tensors ("half rounding is not supported on CPU",
-    # reference :11-13); doing it everywhere keeps results identical to its CPU path.
-    return t if t.dtype == torch.float32 else t.float()
+    # reference :11-13, :28-30, :45-47); device tensors are divided and rounded in place in
+    # their own dtype, exactly like the reference's GPU conversion flow.
+    return t if t.is_cuda else t.float()
 
 
 @torch.no_grad()

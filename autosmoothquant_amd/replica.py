@@ -1,13 +1,33 @@
 """Replica-parallel forwards: one process per GPU, every rank holds a full copy of the
-quantised buffers and processes its own rows.  The ONLY collective is a one-time
-broadcast of {int8 weight, fp32 bias, fp32 scalar scales} from rank 0 at load time
+quantised buffers and processes its own rows.  The ONLY collective traffic is a one-time
+broadcast of {int8 / fp8 weights, fp32 biases, fp32 scalar scales} from rank 0 at load time
 (``torch.distributed`` backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
 The reference has no distributed code at all; the correctness criterion is
 "every replica's rows equal the 1-GPU rows bit for bit" -- rows of an Int8Linear are
 independent (per-token scales are per row, per-tensor has no cross-row state).
+
+How the broadcast is shaped for xGMI.  An MI355X node is a full mesh of
+point-to-point links (7 x ~153 GB/s per GPU), not a switch: one ``broadcast`` per buffer
+(~450 collectives for LLaMA-7B) runs as a ring bound by ONE link.  Instead
+
+  1. every quantised buffer of every module (W8A8 and FP8 classes alike) is re-homed into ONE
+     flat, 256-B aligned device arena (`QuantArena`; the module buffers become views of it, so
+     packing is a one-time copy on the source and zero-copy on the receivers);
+  2. the arena is cut into `world` equal chunks; the source SCATTERS chunk r to rank r -- G-1
+     different links of the source carry 1/G of the payload each, concurrently;
+  3. one in-place ALL-GATHER completes every rank's arena -- every link of the mesh busy,
+     (G-1)/G of the payload in and out per GPU.
+
+Two collectives in total, time ~ payload / G / link + payload (G-1)/G / (links x link) instead
+of payload / link.  The host-pinned scalar scales travel in the arena's tail.
 """
+import hashlib
+
 import torch
 import torch.distributed as dist
+
+_ALIGN = 256
+XGMI_LINK_GBPS = 153.0  # per direction, per link; 7 links per GPU
 
 
 def shard_rows(M, world_size, rank):
@@ -17,49 +37,120 @@ def shard_rows(M, world_size, rank):
     return (M * rank) // world_size, (M * (rank + 1)) // world_size
 
 
-def _w8a8_modules(root):
-    from .layers.nn.linear import _W8A8Base
-    return [m for m in root.modules() if isinstance(m, _W8A8Base)]
+def _quant_modules(root):
+    from .layers.nn.linear import _W8A8Base, _FP8Base
+    return [m for m in root.modules() if isinstance(m, (_W8A8Base, _FP8Base))]
+
+
+_w8a8_modules = _quant_modules  # (old name)
+
+
+def _pad(n, a=_ALIGN):
+    return (n + a - 1) // a * a
+
+
+class QuantArena:
+    """Flat layout of every quantised buffer under `root`: (module index, buffer name, dtype, shape,
+    byte offset) for the device buffers, then one fp32 slot per host-pinned scalar scale."""
+
+    def __init__(self, root, world=1):
+        self.mods = _quant_modules(root)
+        self.entries, off, sig = [], 0, hashlib.sha256()
+        for i, m in enumerate(self.mods):
+            for n in ("weight", "bias"):
+                t = m._buffers.get(n)
+                if t is None:
+                    continue
+                nb = t.numel() * t.element_size()
+                self.entries.append((i, n, t.dtype, tuple(t.shape), off, nb))
+                sig.update(f"{type(m).__name__}.{n}:{t.dtype}:{tuple(t.shape)}@{off};".encode())
+                off += _pad(nb)
+        self.scalars = [(i, n) for i, m in enumerate(self.mods) for n in m._host_scalars]
+        sig.update(";".join(f"{type(self.mods[i]).__name__}.{n}" for i, n in self.scalars).encode())
+        self.scalar_off = off
+        off += _pad(4 * len(self.scalars))
+        self.payload_bytes = sum(e[5] for e in self.entries) + 4 * len(self.scalars)
+        self.total = _pad(max(off, _ALIGN), _ALIGN * max(world, 1))  # equal, aligned chunks
+        self.signature = int.from_bytes(sig.digest()[:7], "big")
+        self.buf = None
+
+    def _view(self, e):
+        _, _, dt, shape, off, nb = e
+        return self.buf[off:off + nb].view(dt).view(shape)
+
+    def pack(self, device):
+        """Allocate the arena on `device`, copy every buffer in (source rank: the real data; receivers: whatever
+        they hold, about to be overwritten) and re-home the module buffers as views of it."""
+        self.buf = torch.zeros(self.total, dtype=torch.uint8, device=device)
+        for e in self.entries:
+            m, n = self.mods[e[0]], e[1]
+            v = self._view(e)
+            v.copy_(m._buffers[n].detach().to(device))
+            m._buffers[n] = v
+        if self.scalars:
+            vals = torch.tensor([float(self.mods[i]._buffers[n]) for i, n in self.scalars], dtype=torch.float32)
+            self.buf[self.scalar_off:self.scalar_off + 4 * len(self.scalars)].view(torch.float32).copy_(vals.to(device))
+        return self
+
+    def unpack_scalars(self):
+        """Arena tail -> the modules' host-pinned fp32 scalar buffers (one device-to-host copy)."""
+        if self.scalars:
+            host = self.buf[self.scalar_off:self.scalar_off + 4 * len(self.scalars)].view(torch.float32).cpu()
+            for k, (i, n) in enumerate(self.scalars):
+                self.mods[i]._buffers[n] = host[k].clone()
+        for m in self.mods:
+            if hasattr(m, "_scol_cache"):
+                m._scol_cache = None
+
+
+def all_ranks_equal(value, group=None, device=None):
+    """True iff `value` (python int, < 2^62) is identical on every rank."""
+    t = torch.tensor([value, -value], dtype=torch.int64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t[0]) == value and int(t[1]) == -value
+
+
+def broadcast_arena(arena, src=0, group=None):
+    """Scatter + all-gather of a packed arena (see the module docstring).  In place on every rank."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return
+    chunk = arena.total // world
+    views = [arena.buf[r * chunk:(r + 1) * chunk] for r in range(world)]
+    mine = views[rank]
+    # 1. scatter: chunk r -> rank r (the source keeps its own); G-1 links of the source in parallel
+    dist.scatter(mine, scatter_list=views if rank == src else None, src=src, group=group)
+    # 2. all-gather of the chunks into every arena (input staged: in-place aliasing is backend-specific)
+    dist.all_gather_into_tensor(arena.buf, mine.clone(), group=group)
 
 
 def broadcast_quantized(root, src=0, group=None, device=None):
-    """Broadcast every W8A8 module's buffers from `src`.  Device buffers (weight, bias) go as
-    they are; the host-pinned scalar scales of all modules travel packed in ONE fp32 tensor.
-    Returns the number of payload bytes moved (for GB/s reporting)."""
-    mods = _w8a8_modules(root)
-    nbytes = 0
-    names = []
-    for m in mods:
-        for n in m._host_scalars:
-            names.append((m, n))
-    dev = device if device is not None else (mods[0].weight.device if mods else torch.device("cpu"))
-    packed = torch.tensor([float(m._buffers[n]) for m, n in names], dtype=torch.float32, device=dev)
-    if len(names):
-        dist.broadcast(packed, src=src, group=group)
-        nbytes += packed.numel() * 4
-        host = packed.cpu()
-        for i, (m, n) in enumerate(names):
-            m._buffers[n] = host[i].clone()
-    for m in mods:
-        for n in ("weight", "bias"):
-            t = m._buffers.get(n)
-            if t is None:
-                continue
-            if not t.is_contiguous():
-                t = t.contiguous()
-                m._buffers[n] = t
-            dist.broadcast(t, src=src, group=group)
-            nbytes += t.numel() * t.element_size()
-        if hasattr(m, "_scol_cache"):
-            m._scol_cache = None
-    return nbytes
+    """Make every rank's quantised buffers (W8A8 *and* FP8 modules) equal to rank `src`'s: flat-pack, scatter,
+    all-gather.  Module buffers are views of the arena afterwards (kept alive by `root._asq_arena`).
+    Returns the number of payload bytes (for GB/s reporting)."""
+    world = dist.get_world_size(group)
+    arena = QuantArena(root, world)
+    if not arena.mods:
+        return 0
+    dev = device if device is not None else arena.mods[0].weight.device
+    if not all_ranks_equal(arena.signature, group=group, device=dev):
+        raise RuntimeError("broadcast_quantized: ranks hold different module structures (class / buffer names / shapes); "
+                           "every rank must build the same quantised model skeleton before the broadcast")
+    arena.pack(dev)
+    broadcast_arena(arena, src=src, group=group)
+    arena.unpack_scalars()
+    try:
+        root._asq_arena = arena
+    except Exception:
+        pass
+    return arena.payload_bytes
 
 
 def buffers_fingerprint(root):
-    """Order-dependent 64-bit fingerprint of all quantised buffers (equal on every rank after
+    """Order-dependent 61-bit fingerprint of all quantised buffers (equal on every rank after
     the broadcast).  Computed with integer tensor ops on the buffers' own device."""
     acc = 0
-    for m in _w8a8_modules(root):
+    for m in _quant_modules(root):
         for n in ("weight", "bias") + tuple(m._host_scalars):
             t = m._buffers.get(n)
             if t is None:
@@ -70,8 +161,10 @@ def buffers_fingerprint(root):
     return acc
 
 
-def all_ranks_equal(value, group=None, device=None):
-    """True iff `value` (python int) is identical on every rank."""
-    t = torch.tensor([value, -value], dtype=torch.int64, device=device or "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    return int(t[0]) == value and int(t[1]) == -value
+def broadcast_report(nbytes, seconds, world):
+    """The `weight_broadcast` block of the bench line: achieved GB/s next to one xGMI link and the scatter +
+    all-gather model (payload/G over one link, then (G-1)/G of the payload over G-1 links)."""
+    model_s = (nbytes / world / (XGMI_LINK_GBPS * 1e9) + nbytes * (world - 1) / world / ((world - 1) * XGMI_LINK_GBPS * 1e9)) if world > 1 else 0.0
+    return {"bytes": nbytes, "ms": seconds * 1e3, "GBps": nbytes / seconds / 1e9 if seconds > 0 else None, "xgmi_link_GBps": XGMI_LINK_GBPS,
+            "x_one_link": (nbytes / seconds / 1e9 / XGMI_LINK_GBPS) if seconds > 0 else None, "model_ms_scatter_allgather": model_s * 1e3,
+            "collectives": "1 scatter + 1 all-gather over one flat arena" if world > 1 else "none"}

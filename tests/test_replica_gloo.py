@@ -24,7 +24,7 @@ def _free_port():
 
 def _make_model(seed):
     from autosmoothquant_amd.layers.nn.linear import (W8A8BFP32OFP32Linear, W8A8BFP32OFP32LinearWithQuantScale,
-                                                      W8A8BFP32OFP32QKVLinear)
+                                                      W8A8BFP32OFP32QKVLinear, FP8LinearStatic, FP8LinearDynamic, FP8E5M2Linear)
     g = torch.Generator().manual_seed(seed)
     mods = torch.nn.ModuleDict()
     a = W8A8BFP32OFP32Linear(64, 48, True, "per-tensor")
@@ -39,6 +39,16 @@ def _make_model(seed):
     b.quant_scale = torch.tensor(0.5 + seed)
     c.q_dequant_scale, c.k_dequant_scale, c.v_dequant_scale = (torch.tensor(0.003 * (seed + 1) * (i + 1)) for i in range(3))
     mods["a"], mods["b"], mods["c"] = a, b, c
+    # fp8 classes travel in the same arena (weights as raw fp8 bytes, their host scalars in the tail)
+    d = FP8LinearStatic(32, 24, use_bias=True)
+    e = FP8LinearDynamic(24, 40, "per-token")
+    f = FP8E5M2Linear(40, 8, use_bias=False)
+    for m in (d, e, f):
+        m.weight = torch.randint(0, 120, m.weight.shape, generator=g, dtype=torch.uint8).view(m._weight_dtype)
+    d.bias = torch.randn(24, generator=g)
+    d.weight_scale, d.input_scale, d.output_scale = torch.tensor(0.01 * (seed + 1)), torch.tensor(0.02 * (seed + 2)), torch.tensor(0.0)
+    e.weight_scale = torch.tensor(0.04 * (seed + 3))
+    mods["d"], mods["e"], mods["f"] = d, e, f
     return mods
 
 
@@ -63,6 +73,12 @@ def _worker(rank, world, port, q):
         # scalar scales stay host-side fp32 after the broadcast
         host_ok = all(m._buffers[n].device.type == "cpu" and m._buffers[n].dtype == torch.float32
                       for m in mods.values() for n in m._host_scalars)
+        # module buffers are views of ONE flat arena afterwards, dtypes / shapes untouched
+        arena = mods._asq_arena
+        base = arena.buf.untyped_storage().data_ptr()
+        host_ok = host_ok and all(m.weight.untyped_storage().data_ptr() == base for m in mods.values())
+        host_ok = host_ok and mods["d"].weight.dtype == torch.float8_e4m3fn and mods["f"].weight.dtype == torch.float8_e5m2
+        host_ok = host_ok and arena.total % (256 * world) == 0
         # each rank computes its shard of a global batch; rank 0 gathers and compares with the 1-process result
         M = 37
         xg = detrng.act_like(5, 0, (M, 64), scale=40.0)
@@ -104,7 +120,8 @@ def test_broadcast_and_row_sharding_world2():
     for rank, differs_before, same_after, host_ok, nbytes, fp, parts in res:
         assert differs_before, "test is vacuous if ranks start identical"
         assert same_after and host_ok
-        assert nbytes == (48 * 64 + 64 * 48 + 64 * 64) + 4 * (48 + 64) + 4 * 6  # int8 weights + fp32 biases + 6 scalars
+        # int8 weights + fp8 weights + fp32 biases + (6 int8-module + 4 fp8-module) host scalars
+        assert nbytes == (48 * 64 + 64 * 48 + 64 * 64) + (24 * 32 + 40 * 24 + 8 * 40) + 4 * (48 + 64 + 24) + 4 * (6 + 4)
         fps.add(fp)
     assert len(fps) == 1
     # replica rows == single-process rows, bit for bit

@@ -1,0 +1,393 @@
+// Clock / power evidence for the dominant kernel (dev tool, MI355X).
+//
+// Question: is gemm_i8_p8 at 4096^3 stall-bound or power(clock)-bound?
+// Every block of the stamped build (ABL = 128: stamps only, schedule unchanged) records
+//     s_memtime      (shader-clock ticks)           at block start / prologue end / K-loop end / block end
+//     s_memrealtime  (constant 100 MHz ticks)       at block start / block end
+// so   effective shader clock = d(memtime) / d(memrealtime) * 100 MHz   inside the kernel itself, no SMI needed.
+// The same stamps go into an MFMA-only kernel (operands in registers, nothing but v_mfma_i32_32x32x32_i8):
+// its rate on the SAME operand statistics is the matrix-core ceiling for that data.
+//
+// Operand statistics:
+//   bench   what bench.py feeds the kernel: weights N(0, 0.02^2) absmax-quantised (int8 std ~23), activations
+//           N(0,1) with 1 % outlier channels x20, scaled by absmax/127 (most entries |x| <= 3)
+//   uniform full-range uniform int8 (the r1 ceiling of 3500 TOPS was measured on this)
+//   zeros
+//
+//   usage: clock_probe [seconds per arm = 1.5] [what = all | gemm | mfma | abl | pmc]
+//   build: see Makefile (-DASQ_P8_PROBE is set by this file)
+#define ASQ_P8_PROBE 1
+#include "../../autosmoothquant_amd/csrc/asq_api.hip"
+#include "../../autosmoothquant_amd/csrc/asq_quant.hip"
+#include "../../autosmoothquant_amd/csrc/asq_gemm_inst_f32.hip"
+#include "../../autosmoothquant_amd/csrc/asq_gemm_inst_f16.hip"
+#include "../../autosmoothquant_amd/csrc/asq_gemm_inst_bf16.hip"
+#include "../../autosmoothquant_amd/csrc/asq_gemm.hip"
+#include <vector>
+#include <string>
+#include <thread>
+#include <atomic>
+#include <chrono>
+#include <math.h>
+#include <glob.h>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+// ---------------------------------------------------------------- operand generators
+struct Rng {
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 1) {}
+    uint32_t u32() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(s >> 32); }
+    double uni() { return (u32() + 0.5) / 4294967296.0; }
+    double gauss() { const double a = uni(), b = uni(); return sqrt(-2.0 * log(a)) * cos(6.283185307179586 * b); }
+};
+static int8_t q8(double v) { double r = nearbyint(v); r = r > 127 ? 127 : (r < -128 ? -128 : r); return (int8_t)r; }
+
+static void gen_weights_bench(std::vector<int8_t> &w, int64_t N, int64_t K, Rng &r)
+{
+    std::vector<float> f(N * K);
+    float amax = 0;
+    for (auto &v : f) { v = (float)(0.02 * r.gauss()); amax = fmaxf(amax, fabsf(v)); }
+    const float sc = amax / 127.0f;
+    for (int64_t i = 0; i < N * K; ++i) w[i] = q8(f[i] / sc);
+}
+static void gen_acts_bench(std::vector<int8_t> &x, int64_t M, int64_t K, Rng &r)
+{
+    std::vector<float> mul(K);
+    for (auto &m : mul) m = r.uni() < 0.01 ? 20.0f : 1.0f;
+    std::vector<float> f(M * K);
+    float amax = 0;
+    for (int64_t m = 0; m < M; ++m)
+        for (int64_t k = 0; k < K; ++k) { float v = (float)r.gauss() * mul[k]; f[m * K + k] = v; amax = fmaxf(amax, fabsf(v)); }
+    const float sc = amax / 127.0f;
+    for (int64_t i = 0; i < M * K; ++i) x[i] = q8(f[i] / sc);
+}
+static void gen_uniform(std::vector<int8_t> &v, Rng &r) { for (auto &e : v) e = (int8_t)(r.u32() >> 24); }
+static void stats(const char *name, const std::vector<int8_t> &v)
+{
+    double s2 = 0; int64_t small = 0;
+    for (auto e : v) { s2 += (double)e * e; small += (e >= -3 && e <= 3); }
+    printf("    %-10s int8 rms %.1f, %.1f %% of entries in [-3,3]\n", name, sqrt(s2 / v.size()), 100.0 * small / v.size());
+}
+
+// ---------------------------------------------------------------- sysfs power / clock sampler (best effort)
+struct Sampler {
+    std::vector<std::string> power_files, freq_files;
+    std::atomic<bool> run{false};
+    std::thread th;
+    std::vector<double> pw, fq;
+    static std::vector<std::string> globv(const char *pat)
+    {
+        std::vector<std::string> r; glob_t g;
+        if (glob(pat, 0, nullptr, &g) == 0) { for (size_t i = 0; i < g.gl_pathc; ++i) r.push_back(g.gl_pathv[i]); globfree(&g); }
+        return r;
+    }
+    static double readnum(const std::string &p) { FILE *f = fopen(p.c_str(), "r"); if (!f) return -1; double v = -1; if (fscanf(f, "%lf", &v) != 1) v = -1; fclose(f); return v; }
+    Sampler()
+    {
+        for (const char *pat : {"/sys/class/drm/card*/device/hwmon/hwmon*/power1_average", "/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"})
+            for (auto &p : globv(pat)) power_files.push_back(p);
+        for (auto &p : globv("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")) freq_files.push_back(p);
+        printf("  sysfs sampler: %zu power file(s), %zu sclk file(s)%s\n", power_files.size(), freq_files.size(), power_files.empty() ? " (none: rely on the in-kernel clock and the SMI log)" : "");
+        for (auto &p : power_files) printf("      %s = %.0f\n", p.c_str(), readnum(p));
+        for (auto &p : freq_files) printf("      %s = %.0f\n", p.c_str(), readnum(p));
+    }
+    void start()
+    {
+        pw.clear(); fq.clear(); run = true;
+        th = std::thread([this] {
+            while (run) {
+                double p = 0, f = 0; int np = 0, nf = 0;
+                for (auto &s : power_files) { double v = readnum(s); if (v > 0) { p = fmax(p, v); ++np; } }   // busiest device
+                for (auto &s : freq_files) { double v = readnum(s); if (v > 0) { f = fmax(f, v); ++nf; } }
+                if (np) pw.push_back(p / 1e6);
+                if (nf) fq.push_back(f / 1e6);
+                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            }
+        });
+    }
+    void stop(const char *tag)
+    {
+        run = false; th.join();
+        auto mean_tail = [](const std::vector<double> &v) { if (v.empty()) return -1.0; size_t a = v.size() / 2; double s = 0; for (size_t i = a; i < v.size(); ++i) s += v[i]; return s / (v.size() - a); };
+        if (!pw.empty() || !fq.empty())
+            printf("    [sysfs %s: %zu samples, 2nd-half mean power %.0f W]\n", tag, pw.size() > fq.size() ? pw.size() : fq.size(), mean_tail(pw));
+        else printf("\n");
+    }
+};
+
+// ---------------------------------------------------------------- MFMA-only kernels with clock stamps
+// PAT: order / operand sharing of consecutive MFMAs (64 per loop trip, operands static in registers)
+//   0 distinct   every MFMA gets an A and a B fragment different from its predecessor's
+//   1 r1         tools/ubench/mfma_power.hip's pattern: 4 A x 4 B fragments, neighbours share one operand
+//   2 p8         gemm_i8_p8's K-loop order: per phase 4 k-steps x 2 token tiles, pairs share the W fragment
+//   3 snake      2 x 2 (W x X) fragments per k-step walked (w0,x0)(w0,x1)(w1,x1)(w1,x0): 3 of 4 steps share an operand
+// GAP: s_nop 15 (16 idle issue cycles) inserted after every 8 MFMAs -> matrix-pipe duty below 100 % (run with 4 waves
+//      per block = one wave per SIMD so the idle is real)
+__device__ unsigned long long mf_stamp[256][4];
+#define MF(acc_, a_, b_) acc_ = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_, b_, acc_, 0, 0, 0)
+template <int GAP> __device__ __forceinline__ void mf_gap()
+{
+#pragma unroll
+    for (int g = 0; g < GAP; ++g) asm volatile("s_nop 15");
+}
+template <int PAT, int GAP> __global__ void __launch_bounds__(512) mfma_var(const v4i *__restrict__ ab, int iters, int *out)
+{
+    v4i a[8], b[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = 0; i < 8; ++i) a[i] = ab[((blockIdx.x * 8 + wave) * 24 + i) * 64 + lane];
+    for (int i = 0; i < 16; ++i) b[i] = ab[((blockIdx.x * 8 + wave) * 24 + 8 + i) * 64 + lane];
+    v16i acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (v16i){0};
+    unsigned long long t0 = 0, r0 = 0;
+    if (threadIdx.x == 0) { r0 = __builtin_amdgcn_s_memrealtime(); t0 = __builtin_amdgcn_s_memtime(); }
+    for (int it = 0; it < iters; it += 8) {
+        if constexpr (PAT == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) MF(acc[i], a[(i + j) & 7], b[(i * 3 + j) & 15]);
+                mf_gap<GAP>();
+            }
+        } else if constexpr (PAT == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) MF(acc[i], a[i & 3], b[(i >> 1) & 3]);
+                mf_gap<GAP>();
+            }
+        } else if constexpr (PAT == 2) {
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) {  // P1 (wa, xf), P2 (wb, xf), P3 (wb, xf'), P4 (wa, xf')
+                    const int wsel = (ph == 1 || ph == 2) ? 4 : 0, xsel = (ph >= 2) ? 8 : 0;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) MF(acc[2 * ph + j], a[wsel + ks], b[xsel + j * 4 + ks]);
+                    mf_gap<GAP>();
+                }
+            }
+        } else {
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        MF(acc[4 * h + 0], a[ks], b[8 * h + ks]);
+                        MF(acc[4 * h + 1], a[ks], b[8 * h + 4 + ks]);
+                        MF(acc[4 * h + 3], a[4 + ks], b[8 * h + 4 + ks]);
+                        MF(acc[4 * h + 2], a[4 + ks], b[8 * h + ks]);
+                        if (ks & 1) mf_gap<GAP>();
+                    }
+                }
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        mf_stamp[blockIdx.x][0] = t0; mf_stamp[blockIdx.x][1] = __builtin_amdgcn_s_memtime();
+        mf_stamp[blockIdx.x][2] = r0; mf_stamp[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
+    }
+    int r = 0;
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) r += acc[i][j];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+static v4i *mf_operands(const std::vector<int8_t> &wsrc, const std::vector<int8_t> &xsrc)
+{
+    // fragments: lane l of a wave gets 16 consecutive k-bytes of row (l & 31), k-half (l >> 5) -- the GEMM's own layout;
+    // per wave 8 W fragments then 16 X fragments
+    const int nfr = 256 * 8 * 24;
+    std::vector<int8_t> h((size_t)nfr * 64 * 16);
+    Rng r(99);
+    for (int f = 0; f < nfr; ++f) {
+        const std::vector<int8_t> &src = ((f % 24) < 8) ? wsrc : xsrc;
+        const size_t rows = src.size() / 4096, row0 = r.u32() % (rows - 32), k0 = (r.u32() % (4096 / 32)) * 32;
+        for (int l = 0; l < 64; ++l) memcpy(&h[((size_t)f * 64 + l) * 16], &src[(row0 + (l & 31)) * 4096 + k0 + 16 * (l >> 5)], 16);
+    }
+    v4i *ab;
+    CK(hipMalloc(&ab, h.size()));
+    CK(hipMemcpy(ab, h.data(), h.size(), hipMemcpyHostToDevice));
+    return ab;
+}
+
+template <int PAT, int GAP> static void run_mfma_var(const char *pat, const char *name, const v4i *ab, int waves, double seconds, Sampler &smp)
+{
+    static int *out = nullptr;
+    if (!out) CK(hipMalloc(&out, 256 * 512 * 4));
+    const int iters = waves == 8 ? 20000 : 40000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto kfn = mfma_var<PAT, GAP>;
+    hipLaunchKernelGGL(kfn, dim3(256), dim3(waves * 64), 0, 0, ab, iters, out);
+    CK(hipDeviceSynchronize());
+    const auto tstart = std::chrono::steady_clock::now();
+    smp.start();
+    std::vector<double> series, mss;
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count() < seconds) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kfn, dim3(256), dim3(waves * 64), 0, 0, ab, iters, out);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned long long st[256][4];
+        CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(mf_stamp), sizeof(st)));
+        double clk = 0;
+        for (int b = 0; b < 256; ++b) clk += (double)(st[b][1] - st[b][0]) / (double)(st[b][3] - st[b][2]) * 0.1;  // GHz
+        series.push_back(clk / 256); mss.push_back(ms);
+    }
+    auto tail = [](const std::vector<double> &v) { double s = 0; size_t a = v.size() / 2; for (size_t i = a; i < v.size(); ++i) s += v[i]; return s / (v.size() - a); };
+    const double ops = 2.0 * 32 * 32 * 32 * 8.0 * iters * waves * 256, ms = tail(mss), clk = tail(series), tops = ops / ms / 1e9;
+    printf("  MFMA-only %-8s %-7s gap %d, %d waves/CU: %.2f ms -> %5.0f TOPS @ %.3f GHz in-kernel; matrix-pipe duty %.1f %% (op/clk/CU %.0f of 8192)", pat, name, GAP, waves, ms, tops, clk,
+           100.0 * tops * 1e12 / (clk * 1e9) / 256 / 8192, tops * 1e12 / (clk * 1e9) / 256);
+    smp.stop("");
+    fflush(stdout);
+}
+#define RUN_MF(PAT, GAP, patname, dname, ab, waves) run_mfma_var<PAT, GAP>(patname, dname, ab, waves, seconds, smp)
+
+// ---------------------------------------------------------------- the production schedule with stamps
+template <class Epi, int XABL = 0> static void run_gemm(const char *name, const int8_t *x, const int8_t *w, Epi epi, int64_t M, int64_t N, int64_t K, double seconds, Sampler &smp)
+{
+    auto kfn = gemm_i8_p8<Epi, 128 | XABL>;   // stamps only (+ the store policy under test)
+    auto kprod = gemm_i8_p8<Epi, XABL>;       // without stamps, for the wall-clock comparison
+    CK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void *)kprod, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES));
+    const int tm = (int)((M + 255) / 256), tn = (int)((N + 255) / 256), nb = tm * tn < 4096 ? tm * tn : 4096;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int BATCH = 50;
+    auto launch = [&](bool prod) {
+        if (prod) hipLaunchKernelGGL(kprod, dim3(tm * tn), dim3(512), P8_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, (const int *)nullptr, 0, epi);
+        else hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, (const int *)nullptr, 0, epi);
+    };
+    for (int i = 0; i < 5; ++i) launch(false);
+    CK(hipDeviceSynchronize());
+    smp.start();
+    const auto tstart = std::chrono::steady_clock::now();
+    std::vector<double> s_clk, s_us, s_cyc[4];
+    static unsigned long long h[4096][8];
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count() < seconds) {
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < BATCH; ++i) launch(false);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(p8_blk), sizeof(h)));
+        double clk = 0, c[4] = {0, 0, 0, 0};
+        for (int b = 0; b < nb; ++b) {
+            clk += (double)(h[b][3] - h[b][0]) / (double)(h[b][7] - h[b][6]) * 0.1;
+            c[0] += (double)(h[b][1] - h[b][0]); c[1] += (double)(h[b][2] - h[b][1]); c[2] += (double)(h[b][3] - h[b][2]); c[3] += (double)(h[b][3] - h[b][0]);
+        }
+        s_clk.push_back(clk / nb); s_us.push_back(ms * 1e3 / BATCH);
+        for (int i = 0; i < 4; ++i) s_cyc[i].push_back(c[i] / nb);
+    }
+    smp.stop(name);
+    // the production instantiation right behind it (same DVFS state)
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < BATCH; ++i) launch(true);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float msp; CK(hipEventElapsedTime(&msp, e0, e1));
+    auto tail = [](const std::vector<double> &v) { double s = 0; size_t a = v.size() / 2; for (size_t i = a; i < v.size(); ++i) s += v[i]; return s / (v.size() - a); };
+    const double us = tail(s_us), clk = tail(s_clk), cyc = tail(s_cyc[3]);
+    const double tops = 2.0 * M * N * K / us / 1e6;
+    const double floor_cyc = (double)(K / 128) * 2048.0;  // 64 MFMAs per SIMD per K-tile x 32 cycles
+    printf("  gemm_i8_p8 %-8s M=%lld N=%lld K=%lld: %zu batches of %d; steady state %.2f us/launch (stamped) / %.2f (production) -> %.0f TOPS = %.1f %% of 5033\n", name, (long long)M,
+           (long long)N, (long long)K, s_us.size(), BATCH, us, msp * 1e3 / BATCH, tops, tops / 50.33);
+    printf("      in-kernel shader clock %.3f GHz; block = %.0f cycles (prologue %.0f + K-loop %.0f + epilogue %.0f); MFMA floor %.0f cycles = %.1f %% of the block;\n", clk, cyc, tail(s_cyc[0]),
+           tail(s_cyc[1]), tail(s_cyc[2]), floor_cyc, 100.0 * floor_cyc / cyc);
+    printf("      block time %.2f us (cycles / clock) vs launch-to-launch %.2f us; clock-normalised: %.0f TOPS at 2.4 GHz; first batch %.2f us @ %.3f GHz\n", cyc / clk / 1e3, us,
+           tops * 2.4 / clk, s_us[0], s_clk[0]);
+    printf("      clock series (GHz):");
+    for (size_t i = 0; i < s_clk.size(); i += s_clk.size() / 10 + 1) printf(" %.2f", s_clk[i]);
+    printf("\n");
+}
+
+__global__ void empty_kernel(int *p) { if (p && threadIdx.x == 9999) *p = 1; }
+
+int main(int argc, char **argv)
+{
+    const double seconds = argc > 1 ? atof(argv[1]) : 1.5;
+    const std::string what = argc > 2 ? argv[2] : "all";
+    const int64_t N = 4096, K = 4096, M = 4096, KL = 16384;
+    Rng r(1234);
+    std::vector<int8_t> xb(M * KL), wb(N * KL), xu(M * K), wu(N * K), z(M * K, 0);
+    gen_weights_bench(wb, N, KL, r);
+    gen_acts_bench(xb, M, KL, r);
+    gen_uniform(xu, r); gen_uniform(wu, r);
+    printf("operand statistics:\n");
+    stats("bench W", wb); stats("bench X", xb); stats("uniform", xu);
+    int8_t *dxb, *dwb, *dxu, *dwu, *dz; void *o16;
+    CK(hipMalloc(&dxb, xb.size())); CK(hipMalloc(&dwb, wb.size())); CK(hipMalloc(&dxu, xu.size())); CK(hipMalloc(&dwu, wu.size())); CK(hipMalloc(&dz, z.size()));
+    CK(hipMalloc(&o16, M * N * 2));
+    CK(hipMemcpy(dxb, xb.data(), xb.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(dwb, wb.data(), wb.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dxu, xu.data(), xu.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(dwu, wu.data(), wu.size(), hipMemcpyHostToDevice));
+    CK(hipMemset(dz, 0, z.size()));
+    EpiDequant<ASQ_F16, false, false, false> e16{o16, N, 1e-4f, nullptr, nullptr, nullptr, 0, true, nullptr};
+
+    if (what == "pmc") {
+        // for rocprofv3 --pmc: the PRODUCTION kernel on bench data at two K depths (a fixed per-dispatch overhead in
+        // GRBM_GUI_ACTIVE shows as a different MfmaUtil at K = 16384) and an empty kernel (the overhead itself)
+        auto kprod = gemm_i8_p8<decltype(e16), 0>;
+        CK(hipFuncSetAttribute((const void *)kprod, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES));
+        for (int i = 0; i < 30; ++i) {
+            hipLaunchKernelGGL(kprod, dim3(256), dim3(512), P8_LDS_BYTES, 0, dxb, dwb, M, N, K, 16, 16, 1, (const int *)nullptr, 0, e16);
+            hipLaunchKernelGGL(kprod, dim3(256), dim3(512), P8_LDS_BYTES, 0, dxb, dwb, M, N, KL, 16, 16, 1, (const int *)nullptr, 0, e16);
+            hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(512), 0, 0, (int *)nullptr);
+        }
+        CK(hipDeviceSynchronize());
+        return 0;
+    }
+    Sampler smp;
+    if (what == "all" || what == "mfma") {
+        printf("== MFMA-only (v_mfma_i32_32x32x32_i8, 256 blocks, operands static in registers) ==\n");
+        v4i *ab_b = mf_operands(wb, xb), *ab_u = mf_operands(wu, xu), *ab_z = mf_operands(z, z);
+        RUN_MF(1, 0, "r1", "zeros", ab_z, 8);
+        RUN_MF(0, 0, "distinct", "zeros", ab_z, 8);
+        RUN_MF(0, 0, "distinct", "bench", ab_b, 8);
+        RUN_MF(1, 0, "r1", "bench", ab_b, 8);
+        RUN_MF(2, 0, "p8", "bench", ab_b, 8);
+        RUN_MF(3, 0, "snake", "bench", ab_b, 8);
+        {   // roles swapped: activations as the matrix-core A operand, weights as B (the GEMM uses W = A, X = B)
+            v4i *ab_s = mf_operands(xb, wb);
+            RUN_MF(2, 0, "p8", "bench-sw", ab_s, 8);
+            RUN_MF(0, 0, "distinct", "bench-sw", ab_s, 8);
+        }
+        RUN_MF(0, 0, "distinct", "uniform", ab_u, 8);
+        RUN_MF(1, 0, "r1", "uniform", ab_u, 8);
+        RUN_MF(2, 0, "p8", "uniform", ab_u, 8);
+        RUN_MF(3, 0, "snake", "uniform", ab_u, 8);
+        printf("  -- duty sweep, one wave per SIMD, snake order --\n");
+        RUN_MF(3, 0, "snake", "bench", ab_b, 4);
+        RUN_MF(3, 1, "snake", "bench", ab_b, 4);
+        RUN_MF(3, 2, "snake", "bench", ab_b, 4);
+        RUN_MF(3, 4, "snake", "bench", ab_b, 4);
+        RUN_MF(3, 8, "snake", "bench", ab_b, 4);
+        RUN_MF(1, 0, "r1", "bench", ab_b, 4);
+        RUN_MF(0, 0, "distinct", "bench", ab_b, 4);
+        RUN_MF(3, 0, "snake", "uniform", ab_u, 4);
+        RUN_MF(3, 2, "snake", "uniform", ab_u, 4);
+        RUN_MF(3, 4, "snake", "uniform", ab_u, 4);
+    }
+    if (what == "all" || what == "gemm") {
+        printf("== gemm_i8_p8 (production schedule + stamps), f16 epilogue ==\n");
+        run_gemm("bench", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm<decltype(e16), 256>("bench nt", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm<decltype(e16), 512>("bench sc1", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm<decltype(e16), 768>("bench wt", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm("bench", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm("uniform", dxu, dwu, e16, M, N, K, seconds, smp);
+        run_gemm("zeros", dz, dz, e16, M, N, K, seconds, smp);
+        run_gemm("benchK16k", dxb, dwb, e16, M, N, KL, seconds, smp);
+    }
+    if (what == "all" || what == "abl") {
+        printf("== gemm_i8_p8 ablations on bench data: what each part of the schedule costs in time, clock and power (results invalid) ==\n");
+        run_gemm("full", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm<decltype(e16), 4>("noMFMA", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm<decltype(e16), 6>("DMAonly", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm<decltype(e16), 5>("dsRDonly", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm<decltype(e16), 7>("skeleton", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm<decltype(e16), 2>("no dsRD", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm<decltype(e16), 1>("no DMA", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm<decltype(e16), 3>("MFMAonly", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm<decltype(e16), 16>("2x dsRD", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm("full", dxb, dwb, e16, M, N, K, seconds, smp);
+    }
+    return 0;
+}

@@ -1,5 +1,6 @@
 // Ablation probe for the p8 GEMM schedule (dev tool; timing only, ablated results are invalid).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off p8_probe.hip -o p8_probe
+#define ASQ_P8_PROBE 1
 #include "../../autosmoothquant_amd/csrc/asq_api.hip"
 #include "../../autosmoothquant_amd/csrc/asq_quant.hip"
 #include "../../autosmoothquant_amd/csrc/asq_gemm_inst_f32.hip"
@@ -37,7 +38,7 @@ template <class Epi> void blk_timeline(const int8_t* x, const int8_t* w, Epi epi
     int tm = (M + 255) / 256, tn = (N + 255) / 256;
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, (const int*)nullptr, 0, epi);
     CK(hipDeviceSynchronize());
-    static unsigned long long h[4096][6];
+    static unsigned long long h[4096][8];
     CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(p8_blk), sizeof(h)));
     int nb = tm * tn; if (nb > 4096) nb = 4096;
     unsigned long long t0 = ~0ull, t3 = 0;
@@ -64,7 +65,7 @@ template <class Epi> void blk_timeline_p8h(const int8_t* x, const int8_t* w, Epi
     int tm = (M + 127) / 128, tn = (N + 255) / 256;
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8H_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, epi);
     CK(hipDeviceSynchronize());
-    static unsigned long long h[4096][6];
+    static unsigned long long h[4096][8];
     CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(p8_blk), sizeof(h)));
     int nb = tm * tn; if (nb > 4096) nb = 4096;
     double s[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
