@@ -25,8 +25,10 @@ SIGNATURES = {
     "asq_gemm_i8_i8": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _f32, _vp, _sz, _vp]),
     "asq_quantize_act": (_int, [_vp, _int, _int, _f32, _vp, _vp, _i64, _i64, _vp]),
     "asq_norm_quantize": (_int, [_vp, _int, _vp, _vp, _f32, _int, _vp, _vp, _i64, _i64, _vp]),
+    "asq_add_norm_quantize": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _f32, _int, _vp, _vp, _i64, _i64, _vp]),
     "asq_silu_mul_quantize": (_int, [_vp, _vp, _int, _int, _f32, _vp, _vp, _i64, _i64, _vp]),
     "asq_linear_w8a8": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _int, _vp, _sz, _vp]),
+    "asq_linear_w8a8_q8": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _int, _int, _int, _f32, _vp, _sz, _vp]),
     "asq_linear_w8a8_grouped": (_int, [_vp, _vp, _vp, _int, _vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "asq_linear_w8a8_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "asq_linear_w8a8_forward": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _int, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),

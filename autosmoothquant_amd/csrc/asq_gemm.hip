@@ -94,6 +94,26 @@ extern "C" int asq_linear_w8a8(const int8_t *xq, const int8_t *w, void *out, int
     }
 }
 
+extern "C" int asq_linear_w8a8_q8(const int8_t *xq, const int8_t *w, int8_t *out_q, int mid_dtype, int64_t M, int64_t N, int64_t K, float s_scalar,
+                                  const float *s_row, const float *s_col, const float *bias, int epi_order, int act, int qmode, float quant_scale,
+                                  void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_gemm_args("asq_linear_w8a8_q8", xq, w, out_q, M, N, K);
+    if (rc) return rc;
+    ASQ_REQUIRE(mid_dtype == ASQ_F32 || mid_dtype == ASQ_F16 || mid_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_linear_w8a8_q8: bad mid_dtype %d", mid_dtype);
+    ASQ_REQUIRE(epi_order == ASQ_EPI_SCALE_FIRST || epi_order == ASQ_EPI_ACC_FIRST, ASQ_ERR_DTYPE, "asq_linear_w8a8_q8: bad epi_order %d", epi_order);
+    ASQ_REQUIRE((act == 0 || act == 1) && (qmode == ASQ_ACT_ROUND || qmode == ASQ_ACT_DIV), ASQ_ERR_DTYPE, "asq_linear_w8a8_q8: bad act %d / qmode %d", act, qmode);
+    ASQ_REQUIRE((((uintptr_t)s_row | (uintptr_t)s_col | (uintptr_t)bias) & 3) == 0, ASQ_ERR_ALIGN, "asq_linear_w8a8_q8: scale/bias misaligned");
+    const bool vec_ok = (N % 4 == 0) && (((uintptr_t)out_q & 3) == 0);
+    DequantQArgs a{{xq, w, out_q, M, N, K, s_scalar, s_row, s_col, bias, epi_order, vec_ok, workspace, workspace_bytes}, act, qmode, quant_scale};
+    hipStream_t s = (hipStream_t)stream;
+    switch (mid_dtype) {
+    case ASQ_F32: return launch_dequant_q<ASQ_F32>(a, s);
+    case ASQ_F16: return launch_dequant_q<ASQ_F16>(a, s);
+    default: return launch_dequant_q<ASQ_BF16>(a, s);
+    }
+}
+
 extern "C" int asq_linear_w8a8_grouped(const int8_t *xq, const int8_t *w, void *out, int out_dtype, const int32_t *group_offsets, int ngroups,
                                        int64_t M, int64_t N, int64_t K, const float *s_group, const float *s_row, const float *bias, void *stream)
 {

@@ -260,6 +260,67 @@ template <int DT, bool HAS_ROW, bool HAS_COL, bool HAS_BIAS> struct EpiDequant {
     }
 };
 
+// int8-OUT epilogue that hands the activation straight to the NEXT W8A8 linear (the K3-K5 idea of the
+// reference's csrc/int8gemm/bindings.cpp:86-142, with the consumer's real quantiser instead of one alpha):
+//     y  = DT(dequant(acc) (+ bias))            -- exactly what EpiDequant<DT> would have stored
+//     a  = relu(y)                               (act = 1; OPT's fc1 -> ReLU -> fc2, reference models/opt.py:127-128)
+//     xq = int8(clamp(rne(a)))                   (ASQ_ACT_ROUND: consumer is a per-tensor W8A8BFP32OFP32Linear, linear.py:95-96)
+//        | int8(clamp(rne(DT(a / quant_scale)))) (ASQ_ACT_DIV:   consumer is a per-tensor ...WithQuantScale, linear.py:289-292)
+// Every step is elementwise, so the result is bit-identical to "linear, activation, then the consumer's prologue".
+// Row / column scales and bias are runtime-optional (one instantiation per DT keeps the build small).
+template <int DT> struct EpiDequantQ {
+    using Mma = MmaI8;
+    static constexpr bool kHasRow = true, kHasCol = true, kHasBias = true;
+    static constexpr int kOutBytes = 1;
+    int8_t *out;
+    int64_t N;
+    float s_scalar;
+    const float *s_row, *s_col, *bias;
+    int order, act, qmode;
+    float quant_scale;
+    bool vec_ok;
+    __device__ __forceinline__ EpiDequantQ rebased(int, int, int64_t, int64_t) const { return *this; }
+    __device__ __forceinline__ float row(int64_t m) const { return s_row ? s_row[m] : 1.0f; }
+    __device__ __forceinline__ void cols(int64_t n, int64_t Ncols, v4f &sc, v4f &b) const
+    {
+        sc = (v4f){s_scalar, s_scalar, s_scalar, s_scalar};
+        b = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (n + i < Ncols) {
+                if (s_col) sc[i] = s_col[n + i];
+                if (bias) b[i] = bias[n + i];
+            }
+    }
+    __device__ __forceinline__ int one(int acc, float sc, float sr, float b) const
+    {
+        const float a = (float)acc;
+        float v;
+        if (order == ASQ_EPI_SCALE_FIRST) {
+            v = __fmul_rn(s_row ? __fmul_rn(sc, sr) : sc, a);
+        } else {
+            v = __fmul_rn(a, sc);
+            if (s_row) v = __fmul_rn(v, sr);
+        }
+        if (bias) v = __fadd_rn(v, b);
+        float y = ElemT<DT>::round(v);
+        if (act == 1) y = (y < 0.0f) ? 0.0f : y;  // relu; NaN stays NaN
+        return quant_i8(qmode == ASQ_ACT_DIV ? ElemT<DT>::round(y / quant_scale) : y);
+    }
+    __device__ __forceinline__ void store4(int64_t m, int64_t n, const v4i &a, float sr, const v4f &sc, const v4f &b, int64_t Ncols) const
+    {
+        int8_t *p = out + m * N + n;
+        if (vec_ok && n + 3 < Ncols) {
+            *(uint32_t *)p = (uint32_t)(one(a[0], sc[0], sr, b[0]) & 0xFF) | ((uint32_t)(one(a[1], sc[1], sr, b[1]) & 0xFF) << 8) |
+                             ((uint32_t)(one(a[2], sc[2], sr, b[2]) & 0xFF) << 16) | ((uint32_t)(one(a[3], sc[3], sr, b[3]) & 0xFF) << 24);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n + i < Ncols) p[i] = (int8_t)one(a[i], sc[i], sr, b[i]);
+        }
+    }
+};
+
 struct EpiI8 {  // out = sat_i8(rne(alpha*acc + beta*c)), c = previous out
     using Mma = MmaI8;
     static constexpr bool kHasRow = false, kHasCol = false, kHasBias = false;
@@ -856,6 +917,19 @@ struct DequantArgs {
     int ngroups = 0;
 };
 template <int DT> int launch_dequant(const DequantArgs &a, hipStream_t s);
+struct DequantQArgs {
+    DequantArgs d;  // d.out = int8 [M,N]
+    int act, qmode;
+    float quant_scale;
+};
+template <int DT> int launch_dequant_q(const DequantQArgs &a, hipStream_t s);
+template <int DT> static inline int launch_dequant_q_impl(const DequantQArgs &q, hipStream_t s)
+{
+    const DequantArgs &a = q.d;
+    return launch_gemm(a.xq, a.w, a.M, a.N, a.K,
+                       EpiDequantQ<DT>{(int8_t *)a.out, a.N, a.s_scalar, a.s_row, a.s_col, a.bias, a.order, q.act, q.qmode, q.quant_scale, a.vec_ok}, s,
+                       "asq_linear_w8a8_q8", a.ws, a.ws_bytes);
+}
 
 template <int DT, bool R, bool C, bool B> static inline int launch_dequant_one(const DequantArgs &a, hipStream_t s)
 {

@@ -209,7 +209,8 @@ template <int DT> int quantize_dt(const void *x, int mode, float quant_scale, in
 // 1 / sqrt(v) from one correctly rounded square root and one correctly rounded division (hipcc keeps fp32 sqrt and
 // division IEEE by default): what torch.rsqrt computes on the host, and reproducible operation by operation in
 // oracle/n1.py -- v_rsq_f32 (1 ulp, implementation-defined) is not.
-__device__ __forceinline__ float rsqrt_exact(float v) { return __fdiv_rn(1.0f, __fsqrt_rn(v)); }
+// (sqrtf, not __fsqrt_rn: the HIP header maps the latter to the NATIVE square root unless OCML_BASIC_ROUNDED_OPERATIONS is set)
+__device__ __forceinline__ float rsqrt_exact(float v) { return __fdiv_rn(1.0f, sqrtf(v)); }
 
 // exp(x) as a fixed sequence of IEEE fp32 operations (no FMA, no library call): Cody-Waite reduction by ln 2,
 // degree-7 Taylor polynomial in Horner form, scaling by two exact powers of two.  <= ~2 ulp from the true value

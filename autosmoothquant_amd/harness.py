@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from .layers.nn.linear import W8A8BFP32OFP32Linear, W8A8BFP32OFP32LinearWithQuantScale
+from .layers.nn.fused import DeferredResidual
 
 
 class RMSNorm(torch.nn.Module):
@@ -73,9 +74,17 @@ class LlamaLayer(torch.nn.Module):
         self.gate_proj, self.up_proj, self.down_proj = L(hidden, inter, bias=False), L(hidden, inter, bias=False), L(inter, hidden, bias=False)
 
     def attention(self, h, record=None):
-        B, S, _ = h.shape
+        B, S, _ = (h.base if isinstance(h, DeferredResidual) else h).shape
         alt = getattr(self, "use_fused", False)   # to_w8a8(both=True): the fused (N1) modules sit beside the reference composition
-        x = (self.input_layernorm_q if alt else self.input_layernorm)(h)   # a float tensor, or a QuantizedActivation when the norm is fused (N1)
+        norm = self.input_layernorm_q if alt else self.input_layernorm
+        if isinstance(h, DeferredResidual):       # the previous layer left its residual add to this layer's input norm
+            if hasattr(norm, "add_forward"):
+                h, x = norm.add_forward(h.delta, h.base)
+            else:
+                h = h.materialize()
+                x = norm(h)
+        else:
+            x = norm(h)   # a float tensor, or a QuantizedActivation when the norm is fused (N1)
         if record is not None:
             record["attn_in"] = x
         if getattr(self, "qkv_proj", None) is not None and (alt or getattr(self, "q_proj", None) is None):   # one GEMM over [q;k;v] (the reference's QKVLinear, as its Baichuan W_pack)
@@ -93,16 +102,28 @@ class LlamaLayer(torch.nn.Module):
         a = F.scaled_dot_product_attention(q, k, v, is_causal=True).transpose(1, 2).reshape(B, S, self.heads * self.hd)
         if record is not None:
             record["o_in"] = a
-        return h + self.o_proj(a)
+        o = self.o_proj(a)
+        if getattr(self, "defer_residual", False):   # h + o is added inside the post-attention norm (asq_add_norm_quantize)
+            return DeferredResidual(h, o)
+        return h + o
 
     def mlp(self, h, record=None):
         alt = getattr(self, "use_fused", False)
-        x = (self.post_attention_layernorm_q if alt else self.post_attention_layernorm)(h)
+        norm = self.post_attention_layernorm_q if alt else self.post_attention_layernorm
+        if isinstance(h, DeferredResidual):
+            if hasattr(norm, "add_forward"):
+                h, x = norm.add_forward(h.delta, h.base)
+            else:
+                h = h.materialize()
+                x = norm(h)
+        else:
+            x = norm(h)
         if record is not None:
             record["mlp_in"] = x
         if getattr(self, "fuse_act", False) or alt:  # SiLU * up quantised in one pass; the fp product never reaches HBM
             from .layers.nn.fused import silu_mul_q
-            return h + self.down_proj(silu_mul_q(self.gate_proj(x), self.up_proj(x), self.down_proj))
+            d = self.down_proj(silu_mul_q(self.gate_proj(x), self.up_proj(x), self.down_proj))
+            return DeferredResidual(h, d) if getattr(self, "defer_residual", False) else h + d
         g = F.silu(self.gate_proj(x)) * self.up_proj(x)
         if record is not None:
             record["down_in"] = g

@@ -45,6 +45,32 @@ class _NormQ(torch.nn.Module):
         return QuantizedActivation(xq, s_row, x.dtype, lead)
 
 
+    @torch.no_grad()
+    def add_forward(self, x, residual):
+        """The residual-add form (reference dq_add_layernorm_q, csrc/kernels/fused.cu:5-25): h = residual + x is written once
+        and normalised + quantised in the same pass.  Returns (h, QuantizedActivation of norm(h))."""
+        lead = residual.shape[:-1]
+        x2, r2 = x.reshape(-1, x.shape[-1]), residual.reshape(-1, residual.shape[-1])
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        r2 = r2 if r2.is_contiguous() else r2.contiguous()
+        w = self.weight if self.weight.dtype == x.dtype else self.weight.to(x.dtype)
+        b = None if self.bias is None else (self.bias if self.bias.dtype == x.dtype else self.bias.to(x.dtype))
+        h, xq, s_row = ops.add_norm_quantize(x2, r2, w, b, self.eps, self.per_token)
+        return h.view(residual.shape), QuantizedActivation(xq, s_row, x.dtype, lead)
+
+
+class DeferredResidual:
+    """`base + delta` not yet added: a decoder layer in fused mode hands its MLP output to the NEXT layer's input norm, which
+    performs the add inside asq_add_norm_quantize (one pass instead of add + norm + quantise)."""
+    __slots__ = ("base", "delta")
+
+    def __init__(self, base, delta):
+        self.base, self.delta = base, delta
+
+    def materialize(self):
+        return self.base + self.delta
+
+
 class RMSNormQ(_NormQ):
     """RMSNorm with weight / input_scale, emitting int8 (per-tensor) or int8 + row scales (per-token)."""
 

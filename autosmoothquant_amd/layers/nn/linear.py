@@ -110,6 +110,35 @@ class _W8A8Base(torch.nn.Module):
             self.bias = self.bias.to(device=device, dtype=torch.float32)
         return self.bias
 
+    # (mode, quant_scale) of this module's own activation quantiser, and (s_scalar, s_col) of its dequant epilogue
+    def _input_mode(self):
+        return ("per-token", 1.0) if self.act_quant == "per-token" else ("per-tensor-round", 1.0)
+
+    def _epilogue_scales(self, device):
+        return self._scalar("dequant_scale"), None
+
+    def forward_q(self, x, consumer, act=None):
+        """This linear, an optional activation (act = "relu": OPT's fc1 -> ReLU -> fc2, reference models/opt.py:127-128) and the
+        per-tensor prologue of `consumer` (the next W8A8 linear) in ONE GEMM launch with an int8-out epilogue
+        (asq_linear_w8a8_q8).  Returns the QuantizedActivation `consumer` accepts; bit-identical to
+        consumer's own quantisation of act(self(x))."""
+        if getattr(consumer, "act_quant", None) != "per-tensor":
+            raise ValueError("forward_q needs a per-tensor consumer (a per-token scale depends on the whole output row)")
+        if isinstance(x, QuantizedActivation):
+            per_token = self.act_quant == "per-token"
+            if per_token != (x.s_row is not None):
+                raise ValueError("QuantizedActivation does not match this module's act_quant")
+            xq, s_row, lead, dt = x.xq, x.s_row, x.lead, x.out_dtype
+        else:
+            lead, dt = x.shape[:-1], x.dtype
+            mode, qs = self._input_mode()
+            xq, s_row = ops.quantize_act(self._flatten(x), mode, qs)
+        s_scalar, s_col = self._epilogue_scales(xq.device)
+        div = "quant_scale" in consumer._buffers
+        out = ops.linear_w8a8_q8(xq, self.weight, dt, s_scalar, s_row, s_col, self._bias_on(xq.device), act,
+                                 "per-tensor-div" if div else "per-tensor-round", consumer._scalar("quant_scale") if div else 1.0)
+        return QuantizedActivation(out, None, dt, lead)
+
 
 def _prequantized_forward(mod, qa, s_scalar, s_col):
     """Forward on an activation already quantised by a fused norm (layers/nn/fused.py): no prologue launch."""
@@ -149,7 +178,7 @@ class W8A8BFP32OFP32Linear(_W8A8Base):
         q.dequant_scale = alpha.to(torch.float32).to(save_device)
         q.weight = wq.to(save_device)
         if has_bias:
-            q.bias = module.bias.to(torch.float32).to(save_device)
+            q.bias = module.bias.detach().to(torch.float32).to(save_device)
         return q
 
 
@@ -172,6 +201,9 @@ class W8A8BFP32OFP32QKVLinear(_W8A8Base):
             parts = [torch.full((int(n),), v, dtype=torch.float32) for v, n in zip(vals, self.qkv_size)]
             self._scol_cache = (key, torch.cat(parts).to(device))
         return self._scol_cache[1]
+
+    def _epilogue_scales(self, device):
+        return 1.0, self._scale_vector(device)
 
     def forward(self, x):
         if isinstance(x, QuantizedActivation):
@@ -197,7 +229,7 @@ class W8A8BFP32OFP32QKVLinear(_W8A8Base):
         for name, s in zip(W8A8BFP32OFP32QKVLinear._host_scalars, scales):
             setattr(q, name, s.to(torch.float32).to(save_device))
         if has_bias:
-            q.bias = module.bias.to(torch.float32).to(save_device)
+            q.bias = module.bias.detach().to(torch.float32).to(save_device)
         return q
 
 
@@ -211,6 +243,9 @@ class W8A8BFP32OFP32LinearWithQuantScale(_W8A8Base):
         if self.act_quant == "per-tensor":
             self._host_scalars = ("dequant_scale", "quant_scale")
             self.register_buffer("quant_scale", torch.tensor(1.0, dtype=torch.float32, requires_grad=False))
+
+    def _input_mode(self):
+        return ("per-token", 1.0) if self.act_quant == "per-token" else ("per-tensor-div", self._scalar("quant_scale"))
 
     def forward(self, x):
         if isinstance(x, QuantizedActivation):  # already quantised for this module (fused.silu_mul_q)
@@ -239,7 +274,7 @@ class W8A8BFP32OFP32LinearWithQuantScale(_W8A8Base):
         q.dequant_scale = alpha.to(torch.float32).to(save_device)
         q.weight = wq.to(save_device)
         if has_bias:
-            q.bias = module.bias.to(torch.float32).to(save_device)
+            q.bias = module.bias.detach().to(torch.float32).to(save_device)
         return q
 
 

@@ -135,6 +135,31 @@ def norm_quantize(x, weight, bias=None, eps=1e-5, per_token=False):
     return xq, s_row
 
 
+def add_norm_quantize(x, residual, weight, bias=None, eps=1e-5, per_token=False, out=None):
+    """h = residual + x (in x's dtype) and the fused norm -> int8 of h in one pass (the reference's dq_add_layernorm_q,
+    csrc/kernels/fused.cu:5-25, on a floating x).  Returns (h [M,K], xq int8 [M,K], s_row f32 [M] or None); `out`
+    may be `residual` itself (the residual stream is updated in place)."""
+    _dev(x, "x"), _dev(residual, "residual"), _dev(weight, "weight")
+    if x.dtype not in _DT or x.dim() != 2 or residual.shape != x.shape or residual.dtype != x.dtype:
+        raise ValueError("x and residual must be 2-D float tensors of equal shape and dtype")
+    if weight.dtype != x.dtype or weight.numel() != x.shape[1]:
+        raise ValueError("weight must be a [K] tensor of x's dtype")
+    if bias is not None:
+        _dev(bias, "bias")
+        if bias.dtype != x.dtype or bias.numel() != x.shape[1]:
+            raise ValueError("bias must match weight")
+    M, K = x.shape
+    h = torch.empty_like(x) if out is None else _dev(out, "out")
+    if h.shape != x.shape or h.dtype != x.dtype:
+        raise ValueError("out has wrong dtype/shape")
+    xq = torch.empty((M, K), dtype=torch.int8, device=x.device)
+    s_row = torch.empty((M,), dtype=torch.float32, device=x.device) if per_token else None
+    with _on(x.device):
+        L.check(L.lib().asq_add_norm_quantize(x.data_ptr(), residual.data_ptr(), h.data_ptr(), _DT[x.dtype], weight.data_ptr(), _ptr(bias), float(eps),
+                                              1 if per_token else 0, xq.data_ptr(), _ptr(s_row), M, K, _stream(x)), "asq_add_norm_quantize")
+    return h, xq, s_row
+
+
 def silu_mul_quantize(gate, up, per_token=True, quant_scale=1.0):
     """int8(quantise(silu(gate) * up)) in one pass; returns (xq int8 [M,K], s_row f32 [M] or None)."""
     _dev(gate, "gate"), _dev(up, "up")
@@ -174,6 +199,32 @@ def linear_w8a8(xq, w, out_dtype, s_scalar=1.0, s_row=None, s_col=None, bias=Non
                                         _ptr(s_row), _ptr(s_col), _ptr(bias),
                                         L.ASQ_EPI_SCALE_FIRST if order == "scale_first" else L.ASQ_EPI_ACC_FIRST, _ptr(ws), n, _stream(xq)),
                 "asq_linear_w8a8")
+    return out
+
+
+def linear_w8a8_q8(xq, w, mid_dtype, s_scalar=1.0, s_row=None, s_col=None, bias=None, act=None, qmode="per-tensor-round", quant_scale=1.0,
+                   order="scale_first"):
+    """GEMM + dequant/bias + activation + the NEXT linear's per-tensor quantiser in one launch: returns int8 [M,N], bit-identical
+    to linear_w8a8(..., mid_dtype) -> act -> quantize_act(..., qmode, quant_scale).  act in {None, "relu"}."""
+    _dev(xq, "xq"), _dev(w, "weight")
+    if xq.dtype != torch.int8 or w.dtype != torch.int8 or xq.dim() != 2 or w.dim() != 2 or xq.shape[1] != w.shape[1]:
+        raise ValueError("xq [M,K] and weight [N,K] must be int8 with equal K")
+    if qmode not in ("per-tensor-round", "per-tensor-div") or act not in (None, "relu") or mid_dtype not in _DT:
+        raise ValueError("qmode must be per-tensor-round / per-tensor-div, act None / 'relu', mid_dtype a float dtype")
+    M, K = xq.shape
+    N = w.shape[0]
+    for name, t, n in (("s_row", s_row, M), ("s_col", s_col, N), ("bias", bias, N)):
+        if t is not None:
+            _dev(t, name)
+            if t.dtype != torch.float32 or t.numel() != n:
+                raise ValueError(f"{name} must be float32 with {n} elements")
+    out = torch.empty((M, N), dtype=torch.int8, device=xq.device)
+    dev = _same_device(xq, w, s_row, s_col, bias)
+    with _on(dev):
+        ws, n = _gemm_ws(M, N, K, dev)
+        L.check(L.lib().asq_linear_w8a8_q8(xq.data_ptr(), w.data_ptr(), out.data_ptr(), _DT[mid_dtype], M, N, K, float(s_scalar), _ptr(s_row), _ptr(s_col),
+                                           _ptr(bias), L.ASQ_EPI_SCALE_FIRST if order == "scale_first" else L.ASQ_EPI_ACC_FIRST, 1 if act == "relu" else 0,
+                                           _ACT[qmode], float(quant_scale), _ptr(ws), n, _stream(xq)), "asq_linear_w8a8_q8")
     return out
 
 

@@ -99,14 +99,26 @@ int asq_quantize_act(const void *x, int x_dtype, int mode, float quant_scale,
  * models/opt.py:20-29), fused with the activation quantiser of the linears that consume it -- the reference's
  * own unbuilt LayerNormQ (layers/nn/fused.py:10-15).  x, weight, bias share x_dtype; K <= 8192 (16-bit) / 4096 (f32).
  * per_token = 0: xq = int8(clamp(rne(y)));  1: s_row[m] = absmax(y)/127 (in x_dtype), xq = int8(clamp(rne(y / s_row))).
- * Equal to "norm in PyTorch, then asq_quantize_act" except where the fp32 reduction order moves y across a
- * rounding boundary (a +-1 difference in < 1e-3 of the entries). */
+ * Every fp32 operation is fixed (per-thread accumulation order, butterfly reduction, 1/sqrt from one IEEE sqrt and
+ * one IEEE division) and restated step by step in oracle/n1.py: the HIP result equals that restatement bit for bit.
+ * Against "norm in PyTorch, then asq_quantize_act" (ATen's own reduction order) y can differ in its last place, i.e.
+ * the int8 differs by +-1 only where y lies within ~1e-6 relative of a rounding boundary. */
 int asq_norm_quantize(const void *x, int x_dtype, const void *weight, const void *bias, float eps, int per_token,
                       int8_t *xq, float *s_row, int64_t M, int64_t K, void *stream);
 
+/* The residual-add form -- the reference's dq_add_layernorm_q (csrc/kernels/fused.cu:5-25;
+ * layers/functional/fused.py:5-12) with a floating `x` (here the producing GEMM's epilogue has already dequantised):
+ *   h_out = x_dtype(residual + x)        (the new residual stream, written once)
+ *   xq    = quantised norm(h_out)        (exactly asq_norm_quantize applied to h_out)
+ * x, residual, h_out [M,K] of x_dtype; h_out may alias residual or x. */
+int asq_add_norm_quantize(const void *x, const void *residual, void *h_out, int x_dtype, const void *weight, const void *bias,
+                          float eps, int per_token, int8_t *xq, float *s_row, int64_t M, int64_t K, void *stream);
+
 /* SiLU(gate) * up fused with the quantiser of the linear that consumes it (LLaMA / Mixtral down_proj / w2,
  * a W8A8BFP32OFP32LinearWithQuantScale): per_token = 1 -> dynamic row scales (linear.py:283-287),
- * per_token = 0 -> x / quant_scale in x_dtype (linear.py:289-292).  gate, up [M,K] of x_dtype; K <= 16384 (16-bit). */
+ * per_token = 0 -> x / quant_scale in x_dtype (linear.py:289-292).  gate, up [M,K] of x_dtype; K <= 16384 (16-bit).
+ * silu(g) = x_dtype(g / (1 + exp(-g))) with exp evaluated by a fixed fp32 operation sequence (oracle/n1.py::exp_det
+ * repeats it), so this kernel, too, is bit-identical to its oracle. */
 int asq_silu_mul_quantize(const void *gate, const void *up, int x_dtype, int per_token, float quant_scale,
                           int8_t *xq, float *s_row, int64_t M, int64_t K, void *stream);
 
@@ -120,6 +132,17 @@ int asq_linear_w8a8(const int8_t *xq, const int8_t *w, void *out, int out_dtype,
                     int64_t M, int64_t N, int64_t K,
                     float s_scalar, const float *s_row, const float *s_col, const float *bias,
                     int epi_order, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- the same GEMM with an int8-OUT epilogue that feeds the NEXT W8A8 linear directly (the int8-out idea of
+ * bindings.cpp:86-142 with the consumer's real prologue):  y = mid_dtype(dequant(acc) (+bias)) exactly as asq_linear_w8a8
+ * would store it; a = relu(y) if act == 1 (OPT fc1 -> fc2, reference models/opt.py:127-128); then
+ *   qmode ASQ_ACT_ROUND: out_q = int8(clamp(rne(a)))                                   (consumer: per-tensor W8A8BFP32OFP32Linear)
+ *   qmode ASQ_ACT_DIV  : out_q = int8(clamp(rne(mid_dtype(a / quant_scale))))          (consumer: per-tensor ...WithQuantScale)
+ * Bit-identical to "asq_linear_w8a8, activation, asq_quantize_act": every step is elementwise. */
+int asq_linear_w8a8_q8(const int8_t *xq, const int8_t *w, int8_t *out_q, int mid_dtype,
+                       int64_t M, int64_t N, int64_t K,
+                       float s_scalar, const float *s_row, const float *s_col, const float *bias, int epi_order,
+                       int act, int qmode, float quant_scale, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- grouped launch: ngroups independent linears (Mixtral experts, reference models/mixtral.py:99-145 runs
  * them as a Python loop of Int8Linear calls) in ONE kernel launch.

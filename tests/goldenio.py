@@ -101,3 +101,18 @@ def load_g7():
         cases.append(dict(id=int(ci), qc={"qkv": a, "out": b, "fc1": c, "fc2": d}, y=z[f"c{ci}_y"]))
     return dict(H=H, heads=heads, inter=inter, B=B, S=S, eps=float(z["eps"]), x=z["x"], y_float=z["y_float"], scales=z["scales"],
                 W={k[2:]: z[k] for k in z.files if k.startswith("W_")}, cases=cases)
+
+
+def load_g8():
+    """N1 fixtures (tests/golden/make_golden_n1.py): LayerNormQ, dq_add_layernorm_q_py, scale-folded RMSNorm + round."""
+    z = np.load(os.path.join(GOLDEN, "g8_n1.npz"))
+    cases = []
+    for line in z["index"]:
+        kind, ci, dt, H, M, eps = str(line).split("|")
+        key = f"{kind}_{ci}"
+        c = dict(kind=kind, id=key, dt=dt, H=int(H), M=int(M), eps=float(eps))
+        for f in z.files:
+            if f.startswith(key + "_"):
+                c[f[len(key) + 1:]] = z[f]
+        cases.append(c)
+    return cases

@@ -191,3 +191,33 @@ def test_fused_qkv_layer_equals_separate_projections():
             assert not hasattr(b, "q_proj") and b.qkv_proj.weight.shape == (256 + 2 * 128, 256)
             with torch.no_grad():
                 assert torch.equal(a(h), b(h)), (cfg, fuse_norm)
+
+
+def test_both_paths_layer_stack_and_deferred_residual():
+    """to_w8a8(both=True): one set of weights, two forwards.  The fused path with the residual adds moved into asq_add_norm_quantize
+    (DeferredResidual) equals the fused path with torch adds bit for bit (h = dt(residual + x) either way), and stays within
+    quantisation noise of the reference composition."""
+    from autosmoothquant_amd import harness
+    from autosmoothquant_amd.layers.nn.fused import DeferredResidual
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    layers = []
+    h = torch.randn(2, 40, 256, device=dev)
+    for i in range(3):
+        fl = harness.init_llama_layer(harness.LlamaLayer(hidden=256, inter=512, heads=4), std=0.05, seed=i).to(dev)
+        layers.append(harness.to_w8a8(fl.half(), harness.calibrate(fl.float(), h), both=True))
+    x = h.half()
+
+    def run(fused, defer):
+        y = x
+        for l in layers:
+            l.use_fused, l.defer_residual = fused, defer
+            y = l(y)
+        return y.materialize() if isinstance(y, DeferredResidual) else y
+    with torch.no_grad():
+        ref, fused, deferred = run(False, False), run(True, False), run(True, True)
+    assert torch.equal(fused, deferred)
+    assert float((fused.float() - ref.float()).norm() / ref.float().norm()) < 2e-2
+    # the fused QKV module is the three projections' int8 rows and scales, concatenated
+    l0 = layers[0]
+    assert torch.equal(l0.qkv_proj.weight, torch.cat([l0.q_proj.weight, l0.k_proj.weight, l0.v_proj.weight]))

@@ -1,0 +1,173 @@
+"""GPU (-m gpu): the N1 fusions through the C-ABI against oracle/n1.py, BIT FOR BIT (the oracle repeats the kernels' fp32
+operation order, see its header), and against the reference's own outputs in tests/golden/g8_n1.npz up to the documented
+rounding-boundary bound."""
+import numpy as np
+import pytest
+import torch
+
+import goldenio
+from oracle import n1, w8a8 as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TDT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+def _t(a, dt):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(TDT[dt]).contiguous()
+
+
+def _n(t):
+    return t.float().cpu().numpy()
+
+
+def _inputs(seed, M, K, dt, scale=3.0):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((M, K)).astype(np.float32) * scale
+    x[:, 5 % K] *= 12.0
+    if M > 2:
+        x[2] = 0.0                      # an all-zero row (per-token: scale 0, NaN quotients -> 0)
+    w = (rng.standard_normal(K).astype(np.float32) * 0.1 + 1.0) / 0.04
+    b = rng.standard_normal(K).astype(np.float32) * 3.0
+    return O.round_to(x, dt), O.round_to(w, dt), O.round_to(b, dt)
+
+
+SHAPES = [(1, 64), (7, 320), (33, 4096), (5, 8192), (130, 1024)]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("per_token", [False, True])
+@pytest.mark.parametrize("layernorm", [False, True])
+def test_norm_quantize_equals_oracle(dt, per_token, layernorm):
+    from autosmoothquant_amd import ops
+    for si, (M, K) in enumerate(SHAPES):
+        if dt == "f32" and K > 4096:
+            continue
+        x, w, b = _inputs(100 + si, M, K, dt)
+        bias = b if layernorm else None
+        xq, s = ops.norm_quantize(_t(x, dt), _t(w, dt), None if bias is None else _t(bias, dt), 1e-5, per_token)
+        rq, rs = n1.norm_quant_kernel_order(x, dt, w, bias, 1e-5, per_token)
+        assert np.array_equal(xq.cpu().numpy(), rq), (M, K)
+        if per_token:
+            assert np.array_equal(s.cpu().numpy(), rs.reshape(-1))
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("per_token", [False, True])
+@pytest.mark.parametrize("layernorm", [False, True])
+def test_add_norm_quantize_equals_oracle(dt, per_token, layernorm):
+    from autosmoothquant_amd import ops
+    for si, (M, K) in enumerate(SHAPES):
+        if dt == "f32" and K > 4096:
+            continue
+        x, w, b = _inputs(200 + si, M, K, dt)
+        res, _, _ = _inputs(300 + si, M, K, dt, scale=5.0)
+        bias = b if layernorm else None
+        h, xq, s = ops.add_norm_quantize(_t(x, dt), _t(res, dt), _t(w, dt), None if bias is None else _t(bias, dt), 1e-5, per_token)
+        rh, rq, rs = n1.add_norm_quant_kernel_order(x, res, dt, w, bias, 1e-5, per_token)
+        assert np.array_equal(_n(h), rh), (M, K)
+        assert np.array_equal(xq.cpu().numpy(), rq), (M, K)
+        if per_token:
+            assert np.array_equal(s.cpu().numpy(), rs.reshape(-1))
+    # in place on the residual stream
+    x, w, _ = _inputs(7, 9, 512, dt)
+    res, _, _ = _inputs(8, 9, 512, dt)
+    rt = _t(res, dt)
+    h, xq, _ = ops.add_norm_quantize(_t(x, dt), rt, _t(w, dt), None, 1e-5, per_token, out=rt)
+    rh, rq, _ = n1.add_norm_quant_kernel_order(x, res, dt, w, None, 1e-5, per_token)
+    assert h.data_ptr() == rt.data_ptr() and np.array_equal(_n(rt), rh) and np.array_equal(xq.cpu().numpy(), rq)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("per_token", [True, False])
+def test_silu_mul_quantize_equals_oracle(dt, per_token):
+    from autosmoothquant_amd import ops
+    for si, (M, K) in enumerate([(1, 64), (9, 704), (33, 11008), (4, 14336), (70, 2048)]):
+        if dt == "f32" and K > 8192:
+            continue
+        rng = np.random.default_rng(400 + si)
+        g = O.round_to(rng.standard_normal((M, K)).astype(np.float32) * 4, dt)
+        u = O.round_to(rng.standard_normal((M, K)).astype(np.float32) * 4, dt)
+        g[0, :6] = O.round_to(np.array([0.0, -0.0, 30.0, -30.0, 88.0, -100.0], np.float32), dt)   # saturating branches of exp_det
+        xq, s = ops.silu_mul_quantize(_t(g, dt), _t(u, dt), per_token, 0.21)
+        rq, rs = n1.silu_mul_quant_kernel_order(g, u, dt, per_token, 0.21)
+        assert np.array_equal(xq.cpu().numpy(), rq), (M, K)
+        if per_token:
+            assert np.array_equal(s.cpu().numpy(), rs.reshape(-1))
+
+
+@pytest.mark.parametrize("c", [c for c in goldenio.load_g8() if c["kind"] in ("lnq", "rmsq")], ids=lambda c: c["id"])
+def test_reference_fixtures_through_hip(c):
+    """The reference's own LayerNormQ / folded-RMSNorm+round inputs through the HIP kernel: equal to the oracle exactly and to the
+    reference's int8 except on rounding boundaries (+-1)."""
+    from autosmoothquant_amd import ops
+    dt = "f32" if c["kind"] == "lnq" else c["dt"]   # LayerNormQ computes in fp32 whatever x was (fused.py:11)
+    bias = c.get("b")
+    xq, _ = ops.norm_quantize(_t(c["x"], dt), _t(c["w"], dt), None if bias is None else _t(bias, dt), c["eps"], False)
+    rq, _ = n1.norm_quant_kernel_order(c["x"], dt, c["w"], bias, c["eps"], False)
+    got = xq.cpu().numpy()
+    assert np.array_equal(got, rq)
+    d = np.abs(got.astype(np.int32) - c["out"].astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() <= 5e-3
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("shape", [(32, 512, 384), (5, 100, 52), (512, 512, 1024), (3072, 256, 3072), (300, 1024, 1000)], ids=str)
+def test_linear_q8_equals_oracle(dt, shape):
+    """asq_linear_w8a8_q8 (int8-out epilogue feeding the next linear) on every dispatcher path (weight-streaming, generic, p8h,
+    p8, ragged N) == linear -> relu -> consumer's per-tensor prologue, exactly."""
+    from autosmoothquant_amd import ops
+    M, K, N = shape
+    rng = np.random.default_rng(M * 7 + N)
+    xq = rng.integers(-128, 128, (M, K), dtype=np.int8)
+    wq = rng.integers(-128, 128, (N, K), dtype=np.int8)
+    bias = (rng.standard_normal(N) * 20).astype(np.float32)
+    s_row = np.abs(rng.standard_normal(M)).astype(np.float32) * 0.02 + 0.01
+    s_col = np.abs(rng.standard_normal(N)).astype(np.float32) * 0.02 + 0.01
+    txq, tw = torch.from_numpy(xq).to(DEV), torch.from_numpy(wq).to(DEV)
+    cases = [dict(s_scalar=0.004, act="relu", qmode="per-tensor-div", quant_scale=0.37, bias=bias),
+             dict(s_scalar=0.004, act=None, qmode="per-tensor-round", quant_scale=1.0),
+             dict(s_scalar=1.0, s_row=s_row, s_col=s_col, bias=bias, act="relu", qmode="per-tensor-div", quant_scale=0.011)]
+    for c in cases:
+        dev = {k: (torch.from_numpy(v).to(DEV) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+        got = ops.linear_w8a8_q8(txq, tw, TDT[dt], dev["s_scalar"], dev.get("s_row"), dev.get("s_col"), dev.get("bias"), dev["act"], dev["qmode"], dev["quant_scale"])
+        ref = n1.linear_q8_forward(xq, wq, dt, c["s_scalar"], c.get("s_row"), c.get("s_col"), c.get("bias"), c["act"], c["qmode"], c["quant_scale"])
+        assert got.dtype == torch.int8 and np.array_equal(got.cpu().numpy(), ref), (shape, c["qmode"])
+        # and the two-launch path it replaces
+        y = ops.linear_w8a8(txq, tw, TDT[dt], dev["s_scalar"], dev.get("s_row"), dev.get("s_col"), dev.get("bias"))
+        if c["act"] == "relu":
+            y = torch.relu(y)
+        two, _ = ops.quantize_act(y, c["qmode"], c["quant_scale"])
+        assert torch.equal(got, two)
+
+
+def test_opt_mlp_fused_chain_equals_unfused():
+    """OPT MLP (reference models/opt.py:123-128): final_layer_norm(folded) -> fc1 (per-tensor Linear, bias) -> ReLU -> fc2 (per-tensor
+    WithQuantScale, bias).  Fused: LayerNormQ -> fc1.forward_q(relu, consumer=fc2) -> fc2 on the int8 it was handed: three launches,
+    no standalone quantiser, same bits as the module-by-module path fed with the same int8 norm output."""
+    from autosmoothquant_amd.layers.nn.linear import W8A8BFP32OFP32Linear, W8A8BFP32OFP32LinearWithQuantScale
+    from autosmoothquant_amd.layers.nn.fused import LayerNormQ
+    torch.manual_seed(3)
+    H, F, M = 512, 2048, 200
+    fc1f, fc2f = torch.nn.Linear(H, F), torch.nn.Linear(F, H)
+    ln = torch.nn.LayerNorm(H)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.1 * torch.randn(H)); ln.bias.copy_(0.1 * torch.randn(H))
+    x = torch.randn(M, H) * 2
+    with torch.no_grad():
+        a1 = ln(x)
+        a2 = torch.relu(fc1f(a1))
+        ref = fc2f(a2).to(DEV)      # before from_float: like the reference, it rounds an fp32 source weight in place
+    s1, s2 = float(a1.abs().max()) / 127, float(a2.abs().max()) / 127
+    fc1 = W8A8BFP32OFP32Linear.from_float(fc1f, s1, act_quant="per-tensor").to(DEV)
+    fc2 = W8A8BFP32OFP32LinearWithQuantScale.from_float(fc2f, s2, act_quant="per-tensor").to(DEV)
+    lnq = LayerNormQ.from_float(ln, s1).to(DEV)
+    for dt in (torch.float16, torch.float32):
+        xd = x.to(DEV).to(dt)
+        qa = lnq(xd)
+        fused = fc2(fc1.forward_q(qa, fc2, act="relu"))
+        unfused = fc2(torch.relu(fc1(qa)))
+        assert fused.dtype == dt and torch.equal(fused, unfused)
+        assert float((fused.float() - ref).norm() / ref.norm()) < 5e-2
+    with pytest.raises(ValueError):
+        fc1.forward_q(qa, W8A8BFP32OFP32LinearWithQuantScale(F, H, False, "per-token").to(DEV))
