@@ -26,7 +26,6 @@
 #include "asq_common.h"
 #include <string.h>
 #include <type_traits>
-#include <mutex>
 #include <unordered_map>
 
 namespace asq {
@@ -652,16 +651,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 
 namespace asq {
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, size) instead of once per launch
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (thread, device, kernel) instead of once per launch.  The cache is
+// thread-local: launches take no lock (include/asq_hip.h promises a re-entrant, lock-free C-ABI); a second thread
+// repeats the idempotent attribute call once.
 static inline hipError_t ensure_dynamic_lds(const void *kfn, int bytes)
 {
-    static std::mutex mu;
-    static std::unordered_map<uintptr_t, int> done;  // key: kernel address ^ (device << 56): the attribute is per device
+    static thread_local std::unordered_map<uintptr_t, int> done;  // key: kernel address ^ (device << 56): the attribute is per device
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const uintptr_t key = (uintptr_t)kfn ^ ((uintptr_t)(dev + 1) << 56);
-    std::lock_guard<std::mutex> g(mu);
     auto it = done.find(key);
     if (it != done.end() && it->second >= bytes) return hipSuccess;
     e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

@@ -357,6 +357,11 @@ class FP8LinearDynamic(_FP8Base):
         assert act_quant == "per-token"
         qw, wscale = per_tensor_quantize_fp8(module.weight)
         use_bias = module.bias is not None
+        if use_bias:
+            import warnings
+            warnings.warn("FP8LinearDynamic.from_float reproduces the reference's positional-argument slip (linear.py:444-446): the converted "
+                          "module runs the per-tensor branch and DROPS the bias from forward (it stays in the state_dict); construct "
+                          "FP8LinearDynamic(in, out, act_quant, use_bias=True) directly for a biased linear", stacklevel=2)
         m = FP8LinearDynamic(module.in_features, module.out_features, use_bias)
         m.weight = qw
         m.weight_scale = input_scale * wscale

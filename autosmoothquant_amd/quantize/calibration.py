@@ -14,6 +14,28 @@ from collections import defaultdict
 import torch
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def all_experts_routed(model):
+    """Mixtral calibration: route every token to EVERY expert (`block_sparse_moe.top_k = num_local_experts`) for the duration
+    of the run so each expert's w2 sees activations, then restore -- the reference's _model_preprocess / _model_postprocess
+    (quantize/calibration.py:23-42).  A no-op for models without block_sparse_moe modules."""
+    touched = []
+    for m in model.modules():
+        moe = getattr(m, "block_sparse_moe", None)
+        if moe is not None and hasattr(moe, "top_k"):
+            n = getattr(moe, "num_experts", None) or len(getattr(moe, "experts", [])) or moe.top_k
+            touched.append((moe, moe.top_k))
+            moe.top_k = n
+    try:
+        yield len(touched)
+    finally:
+        for moe, k in touched:
+            moe.top_k = k
+
+
 def _run(model, batches):
     model.eval()
     for b in batches:
@@ -102,14 +124,20 @@ def decoder_layer_scales(act_dict, num_layers, model_type="transformers", num_lo
         p = prefix.format(i=i)
         d = {k: act_dict[p + mod][io] / 127 for k, (mod, io) in keys.items()}
         if model_type == "mixtral":
+            missing = [e for e in range(num_local_experts) if "input" not in act_dict.get(f"{p}block_sparse_moe.experts.{e}.w2", {})]
+            if missing:
+                raise RuntimeError(f"layer {i}: experts {missing} received no calibration tokens (no w2 activation statistics); calibrate inside "
+                                   "`with all_experts_routed(model):` (the reference forces top_k = num_local_experts, quantize/calibration.py:23-35)")
             d["down_input_scales"] = [act_dict[f"{p}block_sparse_moe.experts.{e}.w2"]["input"] / 127 for e in range(num_local_experts)]
         out.append(d)
     return out
 
 
 def get_static_decoder_layer_scales(model, batches, num_layers, model_type="transformers", num_local_experts=0):
-    """(decoder_layer_scales, act_dict), as the reference's function of the same name (calibration.py:185-244)."""
-    act_dict = get_io_absmax(model, batches)
+    """(decoder_layer_scales, act_dict), as the reference's function of the same name (calibration.py:185-244).  For Mixtral the run
+    happens with every expert routed (all_experts_routed), as in the reference."""
+    with all_experts_routed(model) if model_type == "mixtral" else contextlib.nullcontext():
+        act_dict = get_io_absmax(model, batches)
     return decoder_layer_scales(act_dict, num_layers, model_type, num_local_experts), act_dict
 
 

@@ -8,6 +8,7 @@ Tolerances: int8 activations, int32 accumulators AND the dequantised outputs are
 BIT-EXACTLY (the epilogue mirrors the reference's op order); the north-star contract is the
 looser rtol 1e-3."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -15,6 +16,8 @@ import torch
 
 import detrng
 import goldenio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from oracle import w8a8 as O
 
 pytestmark = pytest.mark.gpu
@@ -327,6 +330,44 @@ def test_full_size_checksums(shape, dev):
     assert torch.equal(part, out[lo:hi])
 
 
+@pytest.mark.parametrize("shape", [(65536, 11008, 4096), (65536, 4096, 11008), (65536, 4096, 4096)], ids=lambda s: "x".join(map(str, s)))
+def test_cfg3_row_count_checksums(shape, dev):
+    """BASELINE configs[2] at its real row count (batch 32 x 2048 tokens = 65536 rows; LLaMA-2-7B gate/up, down and attention
+    shapes, reference call sites models/llama.py:99-106,206-211).  The oracle would need hours, so: (1) exact-integer row and
+    column checksums of the int32 accumulators, 8 chunks of 8192 rows, reduced on the device in int64 and compared with host
+    integer arithmetic; (2) 2048 sampled accumulators against host dot products; (3) ONE 65536-row launch of the fused
+    per-token fp16 epilogue equals the eight 8192-row launches bit for bit (rows are independent: the replica / chunk
+    invariance the harness relies on)."""
+    from autosmoothquant_amd import ops
+    M, N, K = shape
+    CH = 8192
+    x = detrng.int8_uniform(150, K, (M, K))
+    w = detrng.int8_uniform(151, N, (N, K))
+    xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    wsum = w.astype(np.int64).sum(axis=0)
+    col = torch.zeros(N, dtype=torch.int64, device=dev)
+    acc = torch.empty((CH, N), dtype=torch.int32, device=dev)
+    idx = (detrng.u64(152, M, 2048) % np.uint64(M * N)).astype(np.int64)
+    mi, ni = idx // N, idx % N
+    want = np.einsum("ik,ik->i", x[mi].astype(np.int64), w[ni].astype(np.int64))
+    for c in range(M // CH):
+        ops.gemm_i8_i32(xd[c * CH:(c + 1) * CH], wd, acc)
+        a64 = acc.to(torch.int64)
+        assert np.array_equal(a64.sum(dim=1).cpu().numpy(), x[c * CH:(c + 1) * CH].astype(np.int64) @ wsum), c
+        col += a64.sum(dim=0)
+        sel = (mi >= c * CH) & (mi < (c + 1) * CH)
+        got = acc[torch.from_numpy(mi[sel] - c * CH).to(dev), torch.from_numpy(ni[sel]).to(dev)].cpu().numpy()
+        assert np.array_equal(got.astype(np.int64), want[sel]), c
+        del a64
+    assert np.array_equal(col.cpu().numpy(), w.astype(np.int64) @ x.astype(np.int64).sum(axis=0))
+    del acc
+    s_row = torch.from_numpy((np.abs(detrng.normal(153, 0, (M,))) * 0.01 + 1e-3).astype(np.float32)).to(dev)
+    whole = ops.linear_w8a8(xd, wd, torch.float16, 3.0e-4, s_row)
+    for c in range(M // CH):
+        part = ops.linear_w8a8(xd[c * CH:(c + 1) * CH], wd, torch.float16, 3.0e-4, s_row[c * CH:(c + 1) * CH].contiguous())
+        assert torch.equal(whole[c * CH:(c + 1) * CH], part), c
+
+
 def test_full_size_fused_forward_matches_unfused(dev):
     """4096^3 per-tensor W8A8 forward (north-star shape): fused epilogue == epilogue recomputed
     from the exact accumulators with the oracle's arithmetic."""
@@ -379,3 +420,38 @@ def test_forward_outputs_never_require_grad(dev):
                   W8A8BFP32OFP32QKVLinear([64, 32, 32], 256, 128)):
             y = m.to(dev)(x)
             assert not y.requires_grad and y.grad_fn is None
+
+
+@pytest.mark.parametrize("kern,ksplit", [("p8", 3), ("p8", 1), ("p8h", 4), ("skinny", 0), ("generic", 0)])
+def test_forced_kernel_paths_in_a_child_process(kern, ksplit, dev):
+    """Dispatcher branches the shape heuristics never pick by themselves -- notably split-K on the 256-row kernel (pick_kernel hands
+    p8 only >= 144 tiles, pick_ksplit splits only < 118) -- forced through ASQ_GEMM_KERNEL / ASQ_KSPLIT (read once per process,
+    hence the child) and compared with the oracle's exact GEMM, int32 and fused fp16 epilogue, ragged M and N."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import detrng
+from oracle import w8a8 as O
+from autosmoothquant_amd import ops
+dev = torch.device("cuda:0")
+for (M, N, K) in [(300, 520, 1536), (64, 256, 512)]:
+    x, w = detrng.int8_uniform(160, M, (M, K)), detrng.int8_uniform(161, N, (N, K))
+    xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    out = torch.empty((M, N), dtype=torch.int32, device=dev)
+    ops.gemm_i8_i32(xd, wd, out)
+    acc = O.igemm(x, w)
+    assert np.array_equal(out.cpu().numpy(), acc), ("i32", M, N, K)
+    bias = detrng.normal(162, N, (N,)).astype(np.float32)
+    s_row = (np.abs(detrng.normal(163, M, (M,))) * 0.01 + 1e-3).astype(np.float32)
+    y = ops.linear_w8a8(xd, wd, torch.float16, 2e-3, torch.from_numpy(s_row).to(dev), None, torch.from_numpy(bias).to(dev))
+    ref = O.dequant_epilogue(acc, np.float32(2e-3), s_row, bias, "f16")
+    assert np.array_equal(y.float().cpu().numpy(), ref), ("f16", M, N, K)
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, ASQ_GEMM_KERNEL=kern)
+    if ksplit:
+        env["ASQ_KSPLIT"] = str(ksplit)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
