@@ -151,6 +151,19 @@ def _prequantized_forward(mod, qa, s_scalar, s_col):
     return out.view(*qa.lead, mod.out_features)
 
 
+def _module_forward(mod, x, mode, qs, s_scalar, s_col):
+    """quantise -> GEMM + epilogue for a floating input.  Large activations go through the shared quantiser (one quantisation per
+    tensor: q/k/v and gate/up reuse it, ops.quantize_act_shared); small ones through the single fused C-ABI call."""
+    lead = x.shape[:-1]
+    x2 = mod._flatten(x)
+    if ops.act_cache_enabled and x2.numel() >= ops.ACT_CACHE_MIN_ELEMS:
+        xq, s_row = ops.quantize_act_shared(x, x2, mode, qs)
+        out = ops.linear_w8a8(xq, mod.weight, x.dtype, s_scalar, s_row, s_col, mod._bias_on(x.device))
+    else:
+        out = ops.linear_w8a8_forward(x2, mod.weight, mode, qs, s_scalar, s_col, mod._bias_on(x.device))
+    return out.view(*lead, mod.out_features)
+
+
 class W8A8BFP32OFP32Linear(_W8A8Base):
     """int8 weight, int8 activation, fp32 bias, output in the input's dtype.
     per-tensor: the input is already in int8 units (1/input_scale folded into the preceding
@@ -160,11 +173,7 @@ class W8A8BFP32OFP32Linear(_W8A8Base):
     def forward(self, x):
         if isinstance(x, QuantizedActivation):
             return _prequantized_forward(self, x, self._scalar("dequant_scale"), None)
-        lead = x.shape[:-1]
-        mode = "per-token" if self.act_quant == "per-token" else "per-tensor-round"
-        out = ops.linear_w8a8_forward(self._flatten(x), self.weight, mode, 1.0, self._scalar("dequant_scale"),
-                                      None, self._bias_on(x.device))
-        return out.view(*lead, self.out_features)
+        return _module_forward(self, x, "per-token" if self.act_quant == "per-token" else "per-tensor-round", 1.0, self._scalar("dequant_scale"), None)
 
     @staticmethod
     def from_float(module: torch.nn.Linear, input_scale=1.0, save_device=torch.device("cpu"), act_quant="per-tensor"):
@@ -208,11 +217,7 @@ class W8A8BFP32OFP32QKVLinear(_W8A8Base):
     def forward(self, x):
         if isinstance(x, QuantizedActivation):
             return _prequantized_forward(self, x, 1.0, self._scale_vector(x.xq.device))
-        lead = x.shape[:-1]
-        mode = "per-token" if self.act_quant == "per-token" else "per-tensor-round"
-        out = ops.linear_w8a8_forward(self._flatten(x), self.weight, mode, 1.0, 1.0, self._scale_vector(x.device),
-                                      self._bias_on(x.device))
-        return out.view(*lead, self.out_features)
+        return _module_forward(self, x, "per-token" if self.act_quant == "per-token" else "per-tensor-round", 1.0, 1.0, self._scale_vector(x.device))
 
     @staticmethod
     def from_float(module: torch.nn.Linear, input_scale, qkv_size, save_device=torch.device("cpu"), act_quant="per-tensor"):
@@ -250,14 +255,8 @@ class W8A8BFP32OFP32LinearWithQuantScale(_W8A8Base):
     def forward(self, x):
         if isinstance(x, QuantizedActivation):  # already quantised for this module (fused.silu_mul_q)
             return _prequantized_forward(self, x, self._scalar("dequant_scale"), None)
-        lead = x.shape[:-1]
-        if self.act_quant == "per-token":
-            mode, qs = "per-token", 1.0
-        else:
-            mode, qs = "per-tensor-div", self._scalar("quant_scale")
-        out = ops.linear_w8a8_forward(self._flatten(x), self.weight, mode, qs, self._scalar("dequant_scale"), None,
-                                      self._bias_on(x.device))
-        return out.view(*lead, self.out_features)
+        mode, qs = self._input_mode()
+        return _module_forward(self, x, mode, qs, self._scalar("dequant_scale"), None)
 
     @staticmethod
     def from_float(module: torch.nn.Linear, input_scale, save_device=torch.device("cpu"), act_quant="per-token"):

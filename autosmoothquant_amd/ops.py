@@ -116,6 +116,42 @@ def quantize_act(x, mode, quant_scale=1.0):
     return xq, s_row
 
 
+# ---- one quantisation per activation TENSOR, not per consuming module --------------------------------------------
+# The reference's q/k/v (and gate/up) modules each quantise the very same hidden state (layers/nn/linear.py:88-96 runs inside every
+# forward).  The quantised result is a pure function of (tensor contents, mode, quant_scale), so the last one is kept and handed to
+# the next module that is called with the SAME tensor object, unchanged (same ._version), on the same stream: identical bits, one
+# HBM pass instead of three.  Only a weak reference to the input is held; the int8 copy (1 B/element) lives until the next miss.
+import threading
+import weakref
+
+_ACT_CACHE = threading.local()
+ACT_CACHE_MIN_ELEMS = 1 << 20      # below this the single-call fused path is cheaper than two C-ABI calls (host-bound regime)
+import os as _os
+act_cache_enabled = _os.environ.get("ASQ_ACT_CACHE", "1") != "0"     # ASQ_ACT_CACHE=0: every module quantises its own input, like the reference
+
+
+def quantize_act_shared(x_obj, x2d, mode, quant_scale=1.0):
+    """quantize_act(x2d, ...) memoised on the identity / version / stream of `x_obj` (the tensor the module was called with)."""
+    key = (x_obj._version, mode, float(quant_scale), x_obj.dtype, tuple(x_obj.shape), x_obj.data_ptr(), _stream(x2d))
+    ent = getattr(_ACT_CACHE, "ent", None)
+    if ent is not None and ent[0]() is x_obj and ent[1] == key:
+        return ent[2], ent[3]
+    xq, s_row = quantize_act(x2d, mode, quant_scale)
+    try:
+        _ACT_CACHE.ent = (weakref.ref(x_obj), key, xq, s_row)
+    except TypeError:
+        _ACT_CACHE.ent = None
+    return xq, s_row
+
+
+def _bump_version(t):
+    """A raw C-ABI write into a caller-provided tensor must be visible to torch's version counter (the cache above relies on it)."""
+    try:
+        torch.autograd.graph.increment_version(t)
+    except Exception:
+        _ACT_CACHE.ent = None
+
+
 def norm_quantize(x, weight, bias=None, eps=1e-5, per_token=False):
     """Fused (scale-folded) RMSNorm / LayerNorm -> int8 activation.  x [M,K]; weight (and bias for
     LayerNorm) [K] in x's dtype.  Returns (xq int8 [M,K], s_row f32 [M] or None)."""
@@ -152,6 +188,8 @@ def add_norm_quantize(x, residual, weight, bias=None, eps=1e-5, per_token=False,
     h = torch.empty_like(x) if out is None else _dev(out, "out")
     if h.shape != x.shape or h.dtype != x.dtype:
         raise ValueError("out has wrong dtype/shape")
+    if out is not None:
+        _bump_version(out)
     xq = torch.empty((M, K), dtype=torch.int8, device=x.device)
     s_row = torch.empty((M,), dtype=torch.float32, device=x.device) if per_token else None
     with _on(x.device):
@@ -192,6 +230,7 @@ def linear_w8a8(xq, w, out_dtype, s_scalar=1.0, s_row=None, s_col=None, bias=Non
         _dev(out, "out")
         if out.dtype != out_dtype or tuple(out.shape) != (M, N):
             raise ValueError("out has wrong dtype/shape")
+        _bump_version(out)
     dev = _same_device(xq, w, out, s_row, s_col, bias)
     with _on(dev):
         ws, n = _gemm_ws(M, N, K, dev)

@@ -221,3 +221,48 @@ def test_both_paths_layer_stack_and_deferred_residual():
     # the fused QKV module is the three projections' int8 rows and scales, concatenated
     l0 = layers[0]
     assert torch.equal(l0.qkv_proj.weight, torch.cat([l0.q_proj.weight, l0.k_proj.weight, l0.v_proj.weight]))
+
+
+def test_shared_activation_quantiser_is_transparent():
+    """q/k/v-style modules called with the SAME tensor reuse one quantisation (ops.quantize_act_shared): outputs identical to the
+    uncached path, in-place edits and other tensors with recycled storage are never confused with the cached one."""
+    from autosmoothquant_amd import ops
+    from autosmoothquant_amd.layers.nn.linear import W8A8BFP32OFP32Linear, W8A8BFP32OFP32LinearWithQuantScale
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    M, K, N = 1024, 1024, 512          # M*K >= ops.ACT_CACHE_MIN_ELEMS
+    mods = []
+    for cls, aq in ((W8A8BFP32OFP32Linear, "per-tensor"), (W8A8BFP32OFP32Linear, "per-tensor"), (W8A8BFP32OFP32LinearWithQuantScale, "per-token"),
+                    (W8A8BFP32OFP32LinearWithQuantScale, "per-tensor")):
+        m = cls(K, N, False, aq)
+        m.weight = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8)
+        m.dequant_scale = torch.tensor(1e-3)
+        if "quant_scale" in m._buffers:
+            m.quant_scale = torch.tensor(0.3)
+        mods.append(m.to(dev))
+    x = (torch.randn(M, K, generator=g) * 30).half().to(dev)
+    calls = []
+    real = ops.quantize_act
+    ops.quantize_act = lambda *a, **k: (calls.append(a[1]), real(*a, **k))[1]
+    try:
+        cached = [m(x) for m in mods]
+        assert calls == ["per-tensor-round", "per-token", "per-tensor-div"]      # the second per-tensor module reused the first one's int8
+        ops.act_cache_enabled = False
+        plain = [m(x) for m in mods]
+        ops.act_cache_enabled = True
+        assert all(torch.equal(a, b) for a, b in zip(cached, plain))
+        # an in-place edit bumps the version: no stale hit
+        calls.clear()
+        y0 = mods[0](x)
+        x.mul_(0.5)
+        y1 = mods[0](x)
+        assert calls == ["per-tensor-round", "per-tensor-round"] and not torch.equal(y0, y1)
+        # a different tensor object (even with the same bytes / recycled storage) is a miss
+        calls.clear()
+        x2 = x.clone()
+        del x
+        y2 = mods[0](x2)
+        assert calls == ["per-tensor-round"] and torch.equal(y2, y1)
+    finally:
+        ops.quantize_act = real
+        ops.act_cache_enabled = True
