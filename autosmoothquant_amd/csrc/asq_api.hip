@@ -40,11 +40,6 @@ extern "C" int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t 
 {
     ASQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, ASQ_ERR_DIM, "asq_linear_w8a8_forward: bad dims");
     if (M == 0 || N == 0) return ASQ_OK;
-    ASQ_REQUIRE(x_dtype == ASQ_F32 || x_dtype == ASQ_F16 || x_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_linear_w8a8_forward: bad x_dtype %d", x_dtype);
-    {   // decode-sized per-tensor forwards: ONE launch, the quantiser runs inside the weight-streaming kernel (no workspace needed)
-        const int rc = asq_forward_fused_prologue(x, x_dtype, w, out, M, N, K, act_mode, quant_scale, s_scalar, s_col, bias, stream);
-        if (rc != ASQ_NOT_FUSED) return rc;
-    }
     const size_t need = round_up((size_t)M * (size_t)K, 256) + round_up((size_t)M * 4, 256);  // the GEMM part is optional
     ASQ_REQUIRE(workspace != nullptr && workspace_bytes >= need, ASQ_ERR_WORKSPACE,
                 "asq_linear_w8a8_forward: workspace %zu B < required %zu B", workspace_bytes, need);

@@ -18,11 +18,6 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // host-side error plumbing
 // ---------------------------------------------------------------------------------
 void asq_set_error(const char *fmt, ...);
-// asq_gemm.hip: the module forward with the per-tensor prologue fused into the weight-streaming kernel.  Returns -1000 when the
-// shape / mode / alignment does not qualify (the caller then runs quantise + GEMM), else the launch status.
-#define ASQ_NOT_FUSED (-1000)
-int asq_forward_fused_prologue(const void *x, int x_dtype, const int8_t *w, void *out, int64_t M, int64_t N, int64_t K, int act_mode, float quant_scale,
-                               float s_scalar, const float *s_col, const float *bias, void *stream);
 int asq_debug_sync();  // env ASQ_DEBUG_SYNC=1
 
 #define ASQ_REQUIRE(cond, code, ...)      \

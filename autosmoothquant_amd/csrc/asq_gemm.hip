@@ -30,57 +30,9 @@ static int check_gemm_args(const char *what, const void *x, const void *w, const
     return ASQ_OK;
 }
 
-// Fused prologue (asq_gemm_skinny.h): worth it only while every work item's re-read of the floating X stays small next to its
-// slice of the weight stream.  ASQ_FUSE_PROLOGUE_BYTES overrides the M*K*sizeof(x) limit (0 disables the path).
-static int64_t fuse_prologue_limit()
-{
-    static int64_t v = -1;
-    if (v < 0) {
-        const char *e = getenv("ASQ_FUSE_PROLOGUE_BYTES");
-        v = e ? atoll(e) : (512 << 10);
-    }
-    return v;
-}
-
-static bool fused_prologue_shape_ok(int x_dtype, int act_mode, int64_t M, int64_t N, int64_t K)
-{
-    if (act_mode != ASQ_ACT_ROUND && act_mode != ASQ_ACT_DIV) return false;
-    const int64_t esz = x_dtype == ASQ_F32 ? 4 : 2;
-    if (M <= 0 || N <= 0 || M > (x_dtype == ASQ_F32 ? 32 : 64) || K % 128 != 0 || K < 128 || K > (1 << 24)) return false;
-    if (M * K * esz > fuse_prologue_limit()) return false;
-    const int f = forced_kernel();
-    return f < 0 || f == KERN_SKINNY;
-}
-
 }  // namespace asq
 
 using namespace asq;
-
-extern "C" int asq_linear_w8a8_forward_is_fused(int64_t M, int64_t N, int64_t K, int x_dtype, int act_mode)
-{
-    return fused_prologue_shape_ok(x_dtype, act_mode, M, N, K) ? 1 : 0;
-}
-
-int asq_forward_fused_prologue(const void *x, int x_dtype, const int8_t *w, void *out, int64_t M, int64_t N, int64_t K, int act_mode, float quant_scale,
-                               float s_scalar, const float *s_col, const float *bias, void *stream)
-{
-    if (!fused_prologue_shape_ok(x_dtype, act_mode, M, N, K)) return ASQ_NOT_FUSED;
-    if (((((uintptr_t)x) | ((uintptr_t)w)) & 15) != 0) return ASQ_NOT_FUSED;
-    if (act_mode == ASQ_ACT_DIV && !(quant_scale > 0.0f && quant_scale < __builtin_inff())) return ASQ_NOT_FUSED;  // odd scales: the two-kernel path defines them
-    ASQ_REQUIRE(out != nullptr && x != nullptr && w != nullptr, ASQ_ERR_NULL, "asq_linear_w8a8_forward: NULL x / w / out");
-    ASQ_REQUIRE(((uintptr_t)out % asq_dtype_size(x_dtype)) == 0 && ((((uintptr_t)s_col | (uintptr_t)bias) & 3) == 0), ASQ_ERR_ALIGN,
-                "asq_linear_w8a8_forward: out / scale / bias misaligned");
-    const size_t vbytes = x_dtype == ASQ_F32 ? 16 : 8;
-    const bool vec_ok = (N % 4 == 0) && (((uintptr_t)out & (vbytes - 1)) == 0);
-    DequantArgs a{(const int8_t *)x, w, out, M, N, K, s_scalar, nullptr, s_col, bias, ASQ_EPI_SCALE_FIRST, vec_ok, nullptr, 0};
-    SkXQuant xq{act_mode, quant_scale, 1.0f / quant_scale, quant_scale > 0x1p-60f && quant_scale < 0x1p60f};
-    hipStream_t s = (hipStream_t)stream;
-    switch (x_dtype) {
-    case ASQ_F32: return launch_dequant_fused<ASQ_F32>(a, xq, s);
-    case ASQ_F16: return launch_dequant_fused<ASQ_F16>(a, xq, s);
-    default: return launch_dequant_fused<ASQ_BF16>(a, xq, s);
-    }
-}
 
 extern "C" const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K)
 {

@@ -3,5 +3,4 @@
 namespace asq {
 template <> int launch_dequant<ASQ_F32>(const DequantArgs &a, hipStream_t s) { return launch_dequant_impl<ASQ_F32>(a, s); }
 template <> int launch_dequant_q<ASQ_F32>(const DequantQArgs &a, hipStream_t s) { return launch_dequant_q_impl<ASQ_F32>(a, s); }
-template <> int launch_dequant_fused<ASQ_F32>(const DequantArgs &a, const SkXQuant &xq, hipStream_t s) { return launch_dequant_fused_impl<ASQ_F32>(a, xq, s); }
 }  // namespace asq

@@ -320,59 +320,6 @@ template <int DT> struct EpiDequantQ {
     }
 };
 
-// EpiDequant with RUNTIME-optional per-channel scales and bias (no per-token scales): one instantiation per output dtype for the
-// fused-prologue weight-streaming kernel, whose epilogue is a few stores per wave (the compile-time variants pay off in the tiled
-// kernels' store loops, not here).  Same arithmetic, same roundings as EpiDequant.
-template <int DT> struct EpiDequantRt {
-    using Mma = MmaI8;
-    static constexpr bool kHasRow = false, kHasCol = true, kHasBias = true;
-    static constexpr int kOutBytes = (DT == ASQ_F32) ? 4 : 2;
-    void *out;
-    int64_t N;
-    float s_scalar;
-    const float *s_col, *bias;
-    int order;
-    bool vec_ok;
-    __device__ __forceinline__ EpiDequantRt rebased(int, int, int64_t, int64_t) const { return *this; }
-    __device__ __forceinline__ float row(int64_t) const { return 1.0f; }
-    __device__ __forceinline__ void cols(int64_t n, int64_t Ncols, v4f &sc, v4f &b) const
-    {
-        sc = (v4f){s_scalar, s_scalar, s_scalar, s_scalar};
-        b = (v4f){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (n + i < Ncols) {
-                if (s_col) sc[i] = s_col[n + i];
-                if (bias) b[i] = bias[n + i];
-            }
-    }
-    __device__ __forceinline__ float one(int acc, float sc, float b) const
-    {
-        const float a = (float)acc;
-        float v = (order == ASQ_EPI_SCALE_FIRST) ? __fmul_rn(sc, a) : __fmul_rn(a, sc);
-        if (bias) v = __fadd_rn(v, b);
-        return v;
-    }
-    __device__ __forceinline__ void store4(int64_t m, int64_t n, const v4i &a, float, const v4f &sc, const v4f &b, int64_t Ncols) const
-    {
-        using E = ElemT<DT>;
-        typename E::type *p = (typename E::type *)out + m * N + n;
-        const float v0 = one(a[0], sc[0], b[0]), v1 = one(a[1], sc[1], b[1]), v2 = one(a[2], sc[2], b[2]), v3 = one(a[3], sc[3], b[3]);
-        if (vec_ok && n + 3 < Ncols) {
-            if constexpr (DT == ASQ_F32) {
-                *(v4f *)p = (v4f){v0, v1, v2, v3};
-            } else {
-                *(uint2 *)p = make_uint2((uint32_t)E::store(v0) | ((uint32_t)E::store(v1) << 16), (uint32_t)E::store(v2) | ((uint32_t)E::store(v3) << 16));
-            }
-        } else {
-            if (n < Ncols) p[0] = E::store(v0);
-            if (n + 1 < Ncols) p[1] = E::store(v1);
-            if (n + 2 < Ncols) p[2] = E::store(v2);
-            if (n + 3 < Ncols) p[3] = E::store(v3);
-        }
-    }
-};
-
 struct EpiI8 {  // out = sat_i8(rne(alpha*acc + beta*c)), c = previous out
     using Mma = MmaI8;
     static constexpr bool kHasRow = false, kHasCol = false, kHasBias = false;
@@ -822,13 +769,12 @@ static inline int pick_ksplit_p8h(int64_t tiles, int64_t K, int64_t M, int64_t N
     return s < 1 ? 1 : (int)s;
 }
 
-template <class Epi, int MT, int NT, int XDT = -1>
-int launch_skinny_mt(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, int mblocks, const Epi &epi, hipStream_t s, const SkXQuant &xq = SkXQuant{})
+template <class Epi, int MT, int NT> int launch_skinny_mt(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, int mblocks, const Epi &epi, hipStream_t s)
 {
     constexpr int64_t LDS_CU = 160 * 1024;
     const int64_t ntiles = (N + 16 * NT - 1) / (16 * NT);
     const int64_t nitems = ((ntiles + 7) / 8) * 8 * mblocks;  // tiles padded to groups of 8 so m-blocks of a tile share an XCD
-    const int64_t perwave = SK_STAGES * (NT * 2048 + MT * SkX<XDT>::TILE) + NT * MT * 1024;  // DMA ring + reduction slot
+    const int64_t perwave = SK_STAGES * (NT + MT) * 2048 + NT * MT * 1024;  // DMA ring + reduction slot
     // the most waves per block (K parallelism inside a work item) that still gives EVERY item a resident block
     int wpb = 8;
     while (wpb > 1 && (wpb * perwave > LDS_CU || 256 * (LDS_CU / (wpb * perwave)) < nitems)) wpb >>= 1;
@@ -839,33 +785,14 @@ int launch_skinny_mt(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
     int64_t grid = 256 * per_cu;   // persistent beyond that: blocks walk the items grid-stride
     if (grid > nitems) grid = nitems;
     const size_t lds = (size_t)(wpb * perwave);
-    auto kfn = gemm_i8_skinny<Epi, MT, NT, XDT>;
+    auto kfn = gemm_i8_skinny<Epi, MT, NT>;
     hipError_t e = ensure_dynamic_lds((const void *)kfn, (int)lds);
     if (e != hipSuccess) {
         asq_set_error("skinny: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return (int)e;
     }
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)(wpb * 64)), lds, s, x, w, M, N, K, wpb, mblocks, epi, xq);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)(wpb * 64)), lds, s, x, w, M, N, K, wpb, mblocks, epi);
     return ASQ_OK;
-}
-
-// The fused-prologue form: x is the module's floating input [M,K] of XDT, quantised per-tensor inside the kernel (see
-// asq_gemm_skinny.h).  M <= 64 (16-bit) / 32 (f32); the caller has checked alignment and K % 128 == 0.
-template <class Epi, int XDT> int launch_skinny_fused(const void *x, const int8_t *w, int64_t M, int64_t N, int64_t K, const Epi &epi, hipStream_t s, const SkXQuant &xq)
-{
-    const int mt = (int)((M + 15) / 16);
-    const int8_t *xb = (const int8_t *)x;
-    int rc;
-    if constexpr (XDT == ASQ_F32) {
-        rc = mt <= 1 ? launch_skinny_mt<Epi, 1, 1, XDT>(xb, w, M, N, K, 1, epi, s, xq) : launch_skinny_mt<Epi, 2, 1, XDT>(xb, w, M, N, K, 1, epi, s, xq);
-    } else {
-        switch (mt) {
-        case 1: rc = launch_skinny_mt<Epi, 1, 1, XDT>(xb, w, M, N, K, 1, epi, s, xq); break;
-        case 2: rc = launch_skinny_mt<Epi, 2, 1, XDT>(xb, w, M, N, K, 1, epi, s, xq); break;
-        default: rc = launch_skinny_mt<Epi, 4, 1, XDT>(xb, w, M, N, K, 1, epi, s, xq); break;
-        }
-    }
-    return rc ? rc : asq_after_launch(s, "asq_linear_w8a8_forward(fused prologue)");
 }
 
 template <class Epi> int launch_skinny(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, const Epi &epi, hipStream_t s)
@@ -989,12 +916,6 @@ struct DequantArgs {
     int ngroups = 0;
 };
 template <int DT> int launch_dequant(const DequantArgs &a, hipStream_t s);
-// module forward with the per-tensor prologue fused into the weight-streaming kernel: a.xq is the FLOATING x of dtype DT (= out dtype)
-template <int DT> int launch_dequant_fused(const DequantArgs &a, const SkXQuant &xq, hipStream_t s);
-template <int DT> static inline int launch_dequant_fused_impl(const DequantArgs &a, const SkXQuant &xq, hipStream_t s)
-{
-    return launch_skinny_fused<EpiDequantRt<DT>, DT>(a.xq, a.w, a.M, a.N, a.K, EpiDequantRt<DT>{a.out, a.N, a.s_scalar, a.s_col, a.bias, a.order, a.vec_ok}, s, xq);
-}
 struct DequantQArgs {
     DequantArgs d;  // d.out = int8 [M,N]
     int act, qmode;

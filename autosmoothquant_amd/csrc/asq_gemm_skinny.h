@@ -28,14 +28,6 @@
 //
 // Requirements: K % 128 == 0, K <= 2^24, x / w 16-B aligned.  Ragged N, M: rows are clamped for loading
 // and masked at the store.
-//
-// Fused prologue (XDT >= 0; reference layers/nn/linear.py:95-96 round / :289-292 divide, i.e. the per-tensor activation
-// quantisers): X arrives as the module's FLOATING input (f32 / f16 / bf16) instead of pre-quantised int8.  The X part of a
-// K unit is then 16 rows x 128 elements of XDT (256 or 512 B per row), DMA'd in full rows into the same wave-private ring
-// with its own swizzle, read back as 2 (16-bit) or 4 (f32) ds_read_b128 per fragment and converted in registers with exactly
-// the arithmetic of asq_quantize_act (QRound / QDiv of asq_quant.hip: same bits), so a decode-sized module forward is ONE
-// launch: no int8 round trip through HBM, no second kernel.  The work item re-reads 2-4x more X bytes from L2, so the launcher
-// uses it only while M x K x sizeof(XDT) is small (asq_api.hip).
 #pragma once
 #include <type_traits>
 
@@ -52,87 +44,26 @@ __device__ __forceinline__ void sk_dma16(const int8_t *sbase, unsigned voff, uns
                  : "memory");
 }
 
-// x -> int8 with the per-tensor prologues' arithmetic (asq_quant.hip QRound / QDiv; bit-identical by construction):
-//   mode ASQ_ACT_ROUND: clamp(rne(x));   ASQ_ACT_DIV: clamp(rne(XDT(x / s)))  -- the IEEE quotient via the 5-op sequence of
-//   RowDivisor/QRowFast (y = RN(1/s) from the host) when that is provably exact, else the division itself.
-struct SkXQuant {
-    int mode;
-    float s, y;
-    bool fast;  // 2^-60 < s < 2^60
-};
-template <int XDT> __device__ __forceinline__ int sk_quant1(float x, const SkXQuant &q)
-{
-    if (q.mode == ASQ_ACT_ROUND) return quant_i8(x);
-    float v;
-    if (q.fast && absbits(x) < 0x5D800000u) {  // |x| < 2^60: finite, no overflow in the remainders
-        const float q0 = __fmul_rn(x, q.y);
-        const float q1 = __fmaf_rn(__fmaf_rn(-q.s, q0, x), q.y, q0);
-        v = __fmaf_rn(__fmaf_rn(-q.s, q1, x), q.y, q1);
-    } else {
-        v = x / q.s;
-    }
-    return quant_i8(ElemT<XDT>::round(v));
-}
-// 16 consecutive k-elements of XDT (2 or 4 v4i) -> one int8 MFMA fragment
-template <int XDT> __device__ __forceinline__ v4i sk_convert16(const v4i *src, const SkXQuant &q)
-{
-    v4i out;
-    if constexpr (XDT == ASQ_F32) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int a = sk_quant1<XDT>(__int_as_float(src[j][0]), q), b = sk_quant1<XDT>(__int_as_float(src[j][1]), q);
-            const int c = sk_quant1<XDT>(__int_as_float(src[j][2]), q), d = sk_quant1<XDT>(__int_as_float(src[j][3]), q);
-            out[j] = (int)((uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) | ((uint32_t)(d & 0xFF) << 24));
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {  // output dword j = elements 4j .. 4j+3 = dwords 2j, 2j+1 of the 32 source bytes
-            const uint32_t w0 = (uint32_t)src[j >> 1][(2 * j) & 3], w1 = (uint32_t)src[j >> 1][(2 * j + 1) & 3];
-            const int a = sk_quant1<XDT>(ElemT<XDT>::load((uint16_t)(w0 & 0xFFFF)), q), b = sk_quant1<XDT>(ElemT<XDT>::load((uint16_t)(w0 >> 16)), q);
-            const int c = sk_quant1<XDT>(ElemT<XDT>::load((uint16_t)(w1 & 0xFFFF)), q), d = sk_quant1<XDT>(ElemT<XDT>::load((uint16_t)(w1 >> 16)), q);
-            out[j] = (int)((uint32_t)(a & 0xFF) | ((uint32_t)(b & 0xFF) << 8) | ((uint32_t)(c & 0xFF) << 16) | ((uint32_t)(d & 0xFF) << 24));
-        }
-    }
-    return out;
-}
-// LDS swizzle of the floating X rows (16-byte chunk index ^= sk_xsw(row)): conflict-free for the 16-lane service groups of
-// ds_read_b128 ({0-3,12-15,20-27}, ...), which mix two k-groups whose logical chunks differ by 2 (16-bit rows, 16 chunks) or
-// 4 (f32 rows, 32 chunks): row r itself for the former, its two 2-bit halves swapped for the latter.
-template <int XDT> __device__ __forceinline__ int sk_xsw(int r)
-{
-    if constexpr (XDT == ASQ_F32) return ((r & 3) << 2) | ((r >> 2) & 3);
-    else return r & 15;
-}
-
 #define SK_VM_CASE(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 template <int N> __device__ __forceinline__ void sk_wait_vm()
 {
     static_assert(N >= 0 && N <= 63 && N % 2 == 0, "vmcnt is a 6-bit counter; unit sizes are even");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SK_VM_CASE(4); SK_VM_CASE(6); SK_VM_CASE(8); SK_VM_CASE(10); SK_VM_CASE(12); SK_VM_CASE(14); SK_VM_CASE(16); SK_VM_CASE(18);
-    SK_VM_CASE(20); SK_VM_CASE(22); SK_VM_CASE(24); SK_VM_CASE(28); SK_VM_CASE(32); SK_VM_CASE(36); SK_VM_CASE(40); SK_VM_CASE(44); SK_VM_CASE(48);
+    SK_VM_CASE(20); SK_VM_CASE(24); SK_VM_CASE(28); SK_VM_CASE(32); SK_VM_CASE(36);
 }
 #undef SK_VM_CASE
 
 // MT = 16-row token tiles per m-block (1..4); NT = 16-channel tiles per work item (1 or 2).  NT = 2 halves the
 // number of items that each re-read the X rows from L2 (the kernel's bound once N is large): the launcher
 // picks it when there are still >= 256 items.
-template <int XDT> struct SkX {  // geometry of the X part of a K unit
-    static constexpr int ESZ = XDT < 0 ? 1 : (XDT == ASQ_F32 ? 4 : 2);  // bytes per element (int8 when pre-quantised)
-    static constexpr int TILE = 2048 * ESZ;                             // 16 rows x 128 elements
-    static constexpr int NI = 2 * ESZ;                                  // 1-KiB DMA instructions per 16-row tile
-    static constexpr int C = 8 * ESZ;                                   // 16-byte chunks per row
-};
-
-template <class Epi, int MT, int NT, int XDT = -1>
+template <class Epi, int MT, int NT>
 __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
-                                                      int wpb, int mblocks, Epi epi, SkXQuant xqa)
+                                                      int wpb, int mblocks, Epi epi)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    using XG = SkX<XDT>;
-    constexpr int UNIT = NT * 2048 + MT * XG::TILE;  // one 128-element K unit: NT x 16 W rows + MT x 16 X rows
-    constexpr int D = 2 * NT + MT * XG::NI;          // DMA instructions per unit per wave
-    static_assert(2 * D <= 48, "two units in flight must fit the counted vmcnt cases");
+    constexpr int UNIT = (NT + MT) * 2048;  // one 128-byte K unit: NT x 16 W rows + MT x 16 X rows
+    constexpr int D = 2 * (NT + MT);        // DMA instructions per unit per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
@@ -158,7 +89,7 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
     // ---- DMA lane mapping: instruction i of a 16-row tile covers rows 8i .. 8i+7, 128 B each;
     // lane = 8*row + physical 16-B chunk; the logical chunk it fetches is swizzled by (row>>1)&7
     const int rr = lane >> 3, cp = lane & 7;
-    unsigned xoff[MT][XG::NI];  // refreshed per work item (depends on the m-block)
+    unsigned xoff[MT][2];  // refreshed per work item (depends on the m-block)
     // ---- fragment read addresses (per stage, per k-step): lane (r, g) reads row r, logical chunk 4h+g
     const int fr = lane & 15, fg = lane >> 4;
     unsigned faddr[SK_STAGES][2];
@@ -169,18 +100,6 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
             faddr[s][h] = ring + s * UNIT + fr * 128 + (((4 * h + fg) ^ ((fr >> 1) & 7)) << 4);
             asm volatile("" : "+v"(faddr[s][h]));  // keep as loop-invariant VGPRs
         }
-
-    unsigned xfa[2][XG::ESZ];  // floating X: byte offset of (row fr, logical chunk of half h, piece j) inside an X tile
-    if constexpr (XDT >= 0) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < XG::ESZ; ++j) {
-                const int c = ((64 * h + 16 * fg) * XG::ESZ) / 16 + j;
-                xfa[h][j] = (unsigned)(fr * (128 * XG::ESZ) + ((c ^ sk_xsw<XDT>(fr)) << 4));
-                asm volatile("" : "+v"(xfa[h][j]));
-            }
-    }
 
     // issue cursor (runs two items ahead of the consume cursor)
     int it_tile = 0, it_u = 0, issued = 0;
@@ -204,23 +123,16 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int i = 0; i < XG::NI; ++i) {
-                    if constexpr (XDT < 0) {
-                        int64_t m = (int64_t)mb * (MT * 16) + mt * 16 + 8 * i + rr;
-                        m = m < M ? m : M - 1;
-                        xoff[mt][i] = (unsigned)(m * K) + (unsigned)((cp ^ (((8 * i + rr) >> 1) & 7)) << 4);
-                    } else {  // instruction i: rows i*(64/C) + lane/C of the tile, physical chunk lane % C
-                        const int r = i * (64 / XG::C) + lane / XG::C, pch = lane % XG::C;
-                        int64_t m = (int64_t)mb * (MT * 16) + mt * 16 + r;
-                        m = m < M ? m : M - 1;
-                        xoff[mt][i] = (unsigned)(m * K * XG::ESZ) + (unsigned)((pch ^ sk_xsw<XDT>(r)) << 4);
-                    }
+                for (int i = 0; i < 2; ++i) {
+                    int64_t m = (int64_t)mb * (MT * 16) + mt * 16 + 8 * i + rr;
+                    m = m < M ? m : M - 1;
+                    xoff[mt][i] = (unsigned)(m * K) + (unsigned)((cp ^ (((8 * i + rr) >> 1) & 7)) << 4);
                 }
         }
         const int64_t n0 = it_n0;
         const int u = wave + it_u * wpb;
         const int8_t *wb = uniform_ptr(w + n0 * K + (int64_t)u * 128);
-        const int8_t *xb = uniform_ptr(x + (int64_t)u * 128 * XG::ESZ);
+        const int8_t *xb = uniform_ptr(x + (int64_t)u * 128);
         const unsigned dst = ring + stage * UNIT;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -229,7 +141,7 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int i = 0; i < XG::NI; ++i) sk_dma16(xb, xoff[mt][i], dst + NT * 2048 + mt * XG::TILE + i * 1024);
+            for (int i = 0; i < 2; ++i) sk_dma16(xb, xoff[mt][i], dst + (NT + mt) * 2048 + i * 1024);
         ++issued;
         if (++it_u == upt) {
             it_u = 0;
@@ -285,17 +197,7 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wf[nt][h] = *(const __attribute__((address_space(3))) v4i *)(uintptr_t)(faddr[S][h] + nt * 2048);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if constexpr (XDT < 0) {
-                    xf[mt][h] = *(const __attribute__((address_space(3))) v4i *)(uintptr_t)(faddr[S][h] + (NT + mt) * 2048);
-                } else {
-                    v4i raw[XG::ESZ];
-#pragma unroll
-                    for (int j = 0; j < XG::ESZ; ++j)
-                        raw[j] = *(const __attribute__((address_space(3))) v4i *)(uintptr_t)(ring + S * UNIT + NT * 2048 + mt * XG::TILE + xfa[h][j]);
-                    xf[mt][h] = sk_convert16<XDT>(raw, xqa);
-                }
-            }
+            for (int mt = 0; mt < MT; ++mt) xf[mt][h] = *(const __attribute__((address_space(3))) v4i *)(uintptr_t)(faddr[S][h] + (NT + mt) * 2048);
         }
         if constexpr (MMA::kIsInt) {
 #pragma unroll

@@ -312,22 +312,13 @@ def linear_w8a8_forward(x2d, w, act_mode, quant_scale, s_scalar, s_col=None, bia
     if M == 0 or N == 0:
         return out
     lib = L.lib()
-    key = (M, N, K, x2d.dtype, act_mode)
-    nbytes = _FWD_WS.get(key)
-    if nbytes is None:   # 0: the prologue is fused into the weight-streaming kernel for this shape (one launch, no scratch)
-        fused = lib.asq_linear_w8a8_forward_is_fused(M, N, K, _DT[x2d.dtype], _ACT[act_mode])
-        nbytes = _FWD_WS[key] = 0 if fused else lib.asq_linear_w8a8_workspace_bytes(M, N, K)
-    if nbytes == 0 and (((x2d.data_ptr() | w.data_ptr()) & 15) or (act_mode == "per-tensor-div" and not (0.0 < float(quant_scale) < float("inf")))):
-        nbytes = lib.asq_linear_w8a8_workspace_bytes(M, N, K)   # unaligned operands / degenerate scales fall back to the two-kernel path
-    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None  # caching allocator: 512-B aligned, stream-ordered
+    nbytes = lib.asq_linear_w8a8_workspace_bytes(M, N, K)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)  # caching allocator: 512-B aligned, stream-ordered
     with _on(dev):
         L.check(lib.asq_linear_w8a8_forward(x2d.data_ptr(), _DT[x2d.dtype], w.data_ptr(), out.data_ptr(), M, N, K,
                                             _ACT[act_mode], float(quant_scale), float(s_scalar), _ptr(s_col), _ptr(bias),
-                                            _ptr(ws), nbytes, _stream(x2d)), "asq_linear_w8a8_forward")
+                                            ws.data_ptr(), nbytes, _stream(x2d)), "asq_linear_w8a8_forward")
     return out
-
-
-_FWD_WS = {}
 
 
 _FP8 = {"per-token": L.ASQ_FP8_PER_TOKEN, "per-tensor": L.ASQ_FP8_PER_TENSOR, "static": L.ASQ_FP8_STATIC}

@@ -160,13 +160,8 @@ int asq_linear_w8a8_grouped(const int8_t *xq, const int8_t *w, void *out, int ou
 /* ---- whole module forward: W8A8BFP32OFP32Linear / ...QKVLinear / ...LinearWithQuantScale .forward
  * (linear.py:83-106, :158-208, :278-302) = asq_quantize_act + asq_linear_w8a8 on `stream`.
  * out has x's dtype.  workspace: asq_linear_w8a8_workspace_bytes(M,N,K) bytes (int8 activations + row scales +
- * the GEMM scratch above), 256-B aligned.
- * Decode-sized per-tensor forwards (ASQ_ACT_ROUND / ASQ_ACT_DIV, M <= 64 rows (32 for f32), K % 128 == 0, 16-B aligned x / w,
- * M*K*sizeof(x) <= 512 KiB or ASQ_FUSE_PROLOGUE_BYTES) run as ONE launch: the weight-streaming kernel reads the floating x and
- * quantises it in registers with asq_quantize_act's own arithmetic (same bits).  asq_linear_w8a8_forward_is_fused tells whether a
- * shape qualifies; for those calls `workspace` may be NULL. */
+ * the GEMM scratch above), 256-B aligned. */
 size_t asq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K);
-int asq_linear_w8a8_forward_is_fused(int64_t M, int64_t N, int64_t K, int x_dtype, int act_mode);
 int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t *w, void *out,
                             int64_t M, int64_t N, int64_t K,
                             int act_mode, float quant_scale,
