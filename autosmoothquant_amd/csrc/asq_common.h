@@ -65,7 +65,7 @@ __device__ __forceinline__ uint16_t f32_to_f16_bits(float f)
     // which rounds the EXACT product once to fp16 (and turns -0 into +0) -- not the
     // "round to fp32, then to fp16" the reference's separate ATen ops perform.  Caught by the
     // bit-exact parity tests (-144951 * 0.0040789647 = -591.25000126 -> -591.5 instead of -591.0).
-    asm volatile("" : "+v"(f));
+    asm("" : "+v"(f));  // (not volatile: the value dependency is all that is needed; volatile asms would also pin their mutual order)
     return __half_as_ushort(__float2half_rn(f));
 }
 

@@ -14,6 +14,7 @@ int forced_kernel()
             if (!strcmp(e, "generic")) v = KERN_GENERIC;
             else if (!strcmp(e, "p8")) v = KERN_P8;
             else if (!strcmp(e, "p8h")) v = KERN_P8H;
+            else if (!strcmp(e, "p4")) v = KERN_P4;
             else if (!strcmp(e, "skinny")) v = KERN_SKINNY;
         }
     }
@@ -39,6 +40,7 @@ extern "C" const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K)
     switch (pick_kernel(nullptr, nullptr, M, N, K)) {
     case KERN_P8: return "p8";
     case KERN_P8H: return "p8h";
+    case KERN_P4: return "p4";
     case KERN_SKINNY: return "skinny";
     default: return "generic";
     }

@@ -646,6 +646,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 }  // namespace asq
 
 #include "asq_gemm_p8.h"
+#include "asq_gemm_p4.h"
 #include "asq_gemm_p8h.h"
 #include "asq_gemm_skinny.h"
 
@@ -691,7 +692,7 @@ __global__ void __launch_bounds__(256) splitk_reduce(const int32_t *__restrict__
 // ---------------------------------------------------------------------------------
 // dispatch + launch
 // ---------------------------------------------------------------------------------
-enum GemmKernel { KERN_GENERIC = 0, KERN_SKINNY = 1, KERN_P8 = 2, KERN_P8H = 3 };
+enum GemmKernel { KERN_GENERIC = 0, KERN_SKINNY = 1, KERN_P8 = 2, KERN_P8H = 3, KERN_P4 = 4 };
 
 int forced_kernel();  // env ASQ_GEMM_KERNEL=generic|skinny|p8|p8h (development / A-B aid), asq_gemm.hip
 
@@ -701,7 +702,7 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
     const bool tiled_ok = aligned && K % 128 == 0 && K >= 128 && K <= (1 << 24);
     const int f = forced_kernel();
     if (f == KERN_GENERIC) return KERN_GENERIC;
-    if (tiled_ok && (f == KERN_P8 || f == KERN_P8H)) return (GemmKernel)f;
+    if (tiled_ok && (f == KERN_P8 || f == KERN_P8H || f == KERN_P4)) return (GemmKernel)f;
     if (tiled_ok && M <= 1024 && M * K < (1ll << 32) && f == KERN_SKINNY) return KERN_SKINNY;  // (32-bit row offsets in the DMA address)
     if (tiled_ok && f < 0) {
         // measured crossover (tools/cold_grid.sh: 48..256 rows x 8 LLaMA/OPT/Mixtral weight shapes, weights rotated
@@ -837,6 +838,19 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
     }
     constexpr bool kInt = Epi::Mma::kIsInt;
     GemmKernel kern = pick_kernel(x, w, M, N, K);
+    if (kern == KERN_P4 && !kInt) kern = KERN_P8;  // the 4-wave kernel is int8 only
+    if constexpr (kInt) if (kern == KERN_P4) {
+        const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
+        ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
+        auto kfn = gemm_i8_p4<Epi>;
+        hipError_t e = ensure_dynamic_lds((const void *)kfn, P4_LDS_BYTES);
+        if (e != hipSuccess) {
+            asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+            return (int)e;
+        }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(256), P4_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, epi);
+        return asq_after_launch(s, what);
+    }
     if (kern == KERN_P8) {
         const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
         ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);

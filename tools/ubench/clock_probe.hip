@@ -299,6 +299,43 @@ template <class Epi, int XABL = 0> static void run_gemm(const char *name, const 
     printf("\n");
 }
 
+// the 4-wave kernel (gemm_i8_p4) with the same stamps
+template <class Epi, int PB = 1> static void run_gemm_p4(const char *name, const int8_t *x, const int8_t *w, Epi epi, int64_t M, int64_t N, int64_t K, double seconds, Sampler &smp)
+{
+    auto kfn = gemm_i8_p4<Epi, PB>;
+    CK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P4_LDS_BYTES));
+    const int tm = (int)((M + 255) / 256), tn = (int)((N + 255) / 256), nb = tm * tn < 4096 ? tm * tn : 4096;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int BATCH = 50;
+    auto launch = [&]() { hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(256), P4_LDS_BYTES, 0, x, w, M, N, K, tm, tn, epi); };
+    for (int i = 0; i < 5; ++i) launch();
+    CK(hipDeviceSynchronize());
+    smp.start();
+    const auto tstart = std::chrono::steady_clock::now();
+    std::vector<double> s_clk, s_us, s_cyc[4];
+    static unsigned long long h[4096][8];
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count() < seconds) {
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < BATCH; ++i) launch();
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(p8_blk), sizeof(h)));
+        double clk = 0, c[4] = {0, 0, 0, 0};
+        for (int b = 0; b < nb; ++b) {
+            clk += (double)(h[b][3] - h[b][0]) / (double)(h[b][7] - h[b][6]) * 0.1;
+            c[0] += (double)(h[b][1] - h[b][0]); c[1] += (double)(h[b][2] - h[b][1]); c[2] += (double)(h[b][3] - h[b][2]); c[3] += (double)(h[b][3] - h[b][0]);
+        }
+        s_clk.push_back(clk / nb); s_us.push_back(ms * 1e3 / BATCH);
+        for (int i = 0; i < 4; ++i) s_cyc[i].push_back(c[i] / nb);
+    }
+    smp.stop(name);
+    auto tail = [](const std::vector<double> &v) { double s = 0; size_t a = v.size() / 2; for (size_t i = a; i < v.size(); ++i) s += v[i]; return s / (v.size() - a); };
+    const double us = tail(s_us), clk = tail(s_clk), cyc = tail(s_cyc[3]);
+    printf("  gemm_i8_p4 %-8s M=%lld N=%lld K=%lld: %.2f us/launch -> %.0f TOPS = %.1f %% of 5033; clock %.3f GHz; block %.0f cycles (prologue %.0f + K-loop %.0f + epilogue %.0f), MFMA floor %.1f %%\n",
+           name, (long long)M, (long long)N, (long long)K, us, 2.0 * M * N * K / us / 1e6, 2.0 * M * N * K / us / 1e6 / 50.33, clk, cyc, tail(s_cyc[0]), tail(s_cyc[1]), tail(s_cyc[2]),
+           100.0 * (double)(K / 128) * 2048.0 / cyc);
+}
+
 __global__ void empty_kernel(int *p) { if (p && threadIdx.x == 9999) *p = 1; }
 
 int main(int argc, char **argv)
@@ -375,6 +412,19 @@ int main(int argc, char **argv)
         run_gemm("uniform", dxu, dwu, e16, M, N, K, seconds, smp);
         run_gemm("zeros", dz, dz, e16, M, N, K, seconds, smp);
         run_gemm("benchK16k", dxb, dwb, e16, M, N, KL, seconds, smp);
+    }
+    if (what == "p4") {
+        run_gemm("p8 bench", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm_p4("bench", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm_p4<decltype(e16), 3>("noDMA", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm_p4<decltype(e16), 5>("noSync", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm_p4<decltype(e16), 9>("noDSRD", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm_p4<decltype(e16), 7>("noDMA+Sy", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm_p4<decltype(e16), 15>("MFMAonly", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm_p4("zeros", dz, dz, e16, M, N, K, seconds, smp);
+        run_gemm_p4("benchK16k", dxb, dwb, e16, M, N, KL, seconds, smp);
+        run_gemm("p8 bench", dxb, dwb, e16, M, N, K, seconds, smp);
+        run_gemm_p4("bench", dxb, dwb, e16, M, N, K, seconds, smp);
     }
     if (what == "all" || what == "abl") {
         printf("== gemm_i8_p8 ablations on bench data: what each part of the schedule costs in time, clock and power (results invalid) ==\n");
