@@ -714,7 +714,12 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
         // 128-row tiles when the 256-row tiling cannot fill 256 CUs (or wastes half a tile row).  Measured
         // (tools/ksplit_sweep.sh): p8h is ~14 % slower per op on a full chip but wins up to 1.45x below ~144 tiles
         const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-        return t256 < 144 ? KERN_P8H : KERN_P8;
+        if (t256 < 144) return KERN_P8H;
+        // 256 x 256 tiles, 8 waves (p8) or 4 waves with 128 x 128 per wave (p4: fewer LDS bytes per MFMA, but a one-wave-per-SIMD epilogue
+        // that costs 6k cycles more per tile).  Measured (ASQ_GEMM_KERNEL=p8|p4 tools/kbench.py, alternating, profiles/r2_p4_experiment.md):
+        // p4 wins once the K loop is >= 64 K-tiles long -- 4096x4096x8192 +1.7 %, x11008 (LLaMA down_proj) +1.9 %, x16384 +3.0 %,
+        // 8192^3 +2.4 % -- and loses 1 % at 4096^3.  (launch_gemm sends fp8 and grouped launches to p8.)
+        return K >= 8192 ? KERN_P4 : KERN_P8;
     }
     return KERN_GENERIC;
 }
