@@ -11,8 +11,14 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
+# the traced passes run WITHOUT the cfg3 block: the same kernel templates also serve its M = 65536 launches, which would pollute the
+# per-kernel averages of the 4096^3 launches the roofline block is about; cfg3 gets its own --stats pass below
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --no-cfg3 > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
 for C in FETCH_SIZE WRITE_SIZE MfmaUtil SQ_INSTS_VALU_MFMA_I8 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- python "$ROOT/bench.py" --no-cpu-baseline --steps 5 --warmup 2 > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err"
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- python "$ROOT/bench.py" --no-cpu-baseline --no-cfg3 --steps 5 --warmup 2 > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err"
+done
+for F in "" "--fuse-norm --fuse-qkv"; do
+  T=cfg3$( [ -n "$F" ] && echo _fused )
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$T" -o cfg3 -- python "$ROOT/bench.py" --workload llama7b_decoder_b32_s2048 $F --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/$T.json" 2> "$OUT/$T.err"
 done
 ls -R "$OUT" | head -40

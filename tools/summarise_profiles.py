@@ -41,7 +41,7 @@ def pmc_means(counter):
 fetch, write = pmc_means("FETCH_SIZE"), pmc_means("WRITE_SIZE")
 bench = last_json_line(os.path.join(src, "bench.json"))
 out = {
-    "command": "rocprofv3 --kernel-trace --pmc <C> --output-format csv -- python bench.py --no-cpu-baseline --steps 5 --warmup 2  (one pass per counter, C in {FETCH_SIZE, WRITE_SIZE})",
+    "command": "rocprofv3 --kernel-trace --pmc <C> --output-format csv -- python bench.py --no-cpu-baseline --no-cfg3 --steps 5 --warmup 2  (one pass per counter, C in {FETCH_SIZE, WRITE_SIZE})",
     "units": "rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KiB per dispatch",
     "gfx950_correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md 'HBM'); check: quant_flat_vec reads exactly M*K*2 B and writes M*K B",
     "workload": bench["config"]["workload"],
@@ -77,10 +77,24 @@ for counter in ("MfmaUtil", "SQ_INSTS_VALU_MFMA_I8", "SQ_LDS_BANK_CONFLICT", "SQ
     except (IndexError, KeyError):
         pass
 if extra:
-    json.dump({"command": "rocprofv3 --kernel-trace --pmc <C> -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 (one pass per counter)",
+    json.dump({"command": "rocprofv3 --kernel-trace --pmc <C> -- python bench.py --no-cpu-baseline --no-cfg3 --steps 5 --warmup 2 (one pass per counter)",
                "notes": "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * SIMD_NUM) in percent (rocprofv3 derived metric); "
                         "SQ_INSTS_VALU_MFMA_I8: 4096^3 with 32x32x32 tiles needs 2*4096^3 / (2*32*32*32) = 2097152 wave-level MFMAs",
                "kernels": extra}, open(os.path.join(dst, f"{tag}_pmc_mfma_lds.json"), "w"), indent=1)
     print(json.dumps(extra, indent=1)[:2500])
+# cfg3 (32-layer LLaMA-2-7B decoder forward, 65536 tokens): per-kernel share of the GPU time, reference composition and N1-fused
+import re
+for t in ("cfg3", "cfg3_fused"):
+    fs = glob.glob(os.path.join(src, t, "**", "*kernel_stats.csv"), recursive=True)
+    if not fs:
+        continue
+    rows = list(csv.DictReader(open(fs[0])))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    with open(os.path.join(dst, f"{tag}_{t}_kernel_stats.txt"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --workload llama7b_decoder_b32_s2048 {'--fuse-norm --fuse-qkv ' if 'fused' in t else ''}--steps 2 --warmup 1 --no-cpu-baseline\n")
+        f.write("# 3 forwards + set-up + the dominant-kernel timing batch (gate GEMM at M = 8192, 400 launches); share of total GPU kernel time\n")
+        for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:24]:
+            f.write("%5.1f%%  calls %6s  avg %9.1f us  %s\n" % (float(r["TotalDurationNs"]) / tot * 100, r["Calls"], float(r["AverageNs"]) / 1e3, re.sub(r"\(.*", "", r["Name"])[:110]))
+        f.write("total %.1f ms\n" % (tot / 1e6))
 print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read())
 print(json.dumps(out["kernels"], indent=1)[:3000])
