@@ -12,6 +12,8 @@ tokens -> M = 4096, i.e. four 4096x4096x4096 GEMMs: BASELINE.json configs[1]'s b
 batch the north-star target is quoted on.  Multi-GPU = replica-parallel (weak scaling): every
 rank runs the same step on its own rows after one RCCL broadcast of the quantised buffers.
 
+Timing: an untimed settle phase (--settle-ms, default 40 ms of steps: the power controller needs ~20 ms of sustained load to reach its
+operating clock), then W warm-up steps, then EXACTLY K timed steps between barrier + synchronize, max over ranks.
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around the
 dominant kernel (the fused GEMM); `cpu_baseline` times the oracle on the host cores on a
 bounded row sample of the same workload (rank 0, N=1 only).
@@ -337,9 +339,10 @@ def pmc_traffic(kernel_key, M, N, K):
     return best
 
 
-def cpu_baseline(spec, M_sample, dtype_tag, budget_s=10.0):
-    """The oracle's module forwards on the host cores, on M_sample rows of the same workload, repeated for about
-    budget_s seconds of CPU work (one untimed warm-up pass first)."""
+def cpu_baseline(spec, M_sample, dtype_tag, budget_s=10.0, mods=None, xs=None):
+    """The oracle's module forwards on the host cores, on the first M_sample rows of the SAME workload -- the step's own quantised
+    weights, scales and activations copied from the device when `mods` / `xs` are given (synthetic stand-ins of the same shapes
+    otherwise) -- repeated for about budget_s seconds of CPU work (one untimed warm-up pass first)."""
     import numpy as np
     from oracle import w8a8 as O
     rng = np.random.default_rng(0)
@@ -361,19 +364,29 @@ def cpu_baseline(spec, M_sample, dtype_tag, budget_s=10.0):
     O.set_igemm_backend(best)
     ops_total, t_total, reps = 0.0, 0.0, 0
     data = []
+    real = mods is not None and xs is not None and all(l in mods for (l, *_r) in spec)
     for label, kind, K, N, aq, bias in spec:
-        wq = rng.integers(-128, 128, (N, K), dtype=np.int8)
-        x = O.round_to((rng.standard_normal((M_sample, K)) * 40).astype(np.float32), dtype_tag)
-        b = rng.standard_normal(N).astype(np.float32) if bias else None
-        data.append((kind, K, N, aq, wq, x, b))
+        if real:
+            m = mods[label]
+            wq = m.weight.detach().cpu().numpy()
+            x = xs[(K, aq, kind)][:M_sample].float().cpu().numpy()
+            b = m.bias.detach().cpu().numpy() if bias else None
+            ds = float(m.dequant_scale)
+            qs = float(m.quant_scale) if "quant_scale" in m._buffers else 0.5
+        else:
+            wq = rng.integers(-128, 128, (N, K), dtype=np.int8)
+            x = O.round_to((rng.standard_normal((M_sample, K)) * 40).astype(np.float32), dtype_tag)
+            b = rng.standard_normal(N).astype(np.float32) if bias else None
+            ds, qs = 1e-4, 0.5
+        data.append((kind, K, N, aq, wq, x, b, ds, qs))
     def one_pass(timed):
         nonlocal t_total, ops_total
-        for kind, K, N, aq, wq, x, b in data:
+        for kind, K, N, aq, wq, x, b, ds, qs in data:
             t0 = time.perf_counter()
             if kind == "linear":
-                O.linear_forward(x, dtype_tag, wq, 1e-4, b, aq)
+                O.linear_forward(x, dtype_tag, wq, ds, b, aq)
             else:
-                O.linear_with_quant_scale_forward(x, dtype_tag, wq, 1e-4, 0.5, b, aq)
+                O.linear_with_quant_scale_forward(x, dtype_tag, wq, ds, qs, b, aq)
             if timed:
                 t_total += time.perf_counter() - t0
                 ops_total += 2.0 * M_sample * N * K
@@ -384,8 +397,8 @@ def cpu_baseline(spec, M_sample, dtype_tag, budget_s=10.0):
     O.set_igemm_backend("numpy")
     return {"value": ops_total / t_total / 1e12, "unit": "TOPS", "cores": os.cpu_count(), "kind": "port",
             "tokens_per_s": M_sample * reps / t_total,
-            "sample": f"oracle/w8a8.py module forwards (igemm backend={best}, all host threads) on {M_sample} rows of the same "
-                      f"{len(spec)} linears, {reps} rep(s), {t_total:.1f} s"}
+            "sample": f"oracle/w8a8.py module forwards (igemm backend={best}, all host threads) on the first {M_sample} rows of the "
+                      f"{'step' + chr(39) + 's own quantised weights and activations' if real else 'same shapes (synthetic operands)'}, {len(spec)} linears, {reps} rep(s), {t_total:.1f} s"}
 
 
 def main():
@@ -400,6 +413,10 @@ def main():
     ap.add_argument("--fuse-qkv", action="store_true", help="layer workloads: q/k/v as one W8A8BFP32OFP32QKVLinear (the reference's own fused class, used by its Baichuan model)")
     ap.add_argument("--fp8", action="store_true", help="mixtral_experts only: FP8LinearDynamic math (e4m3 weights, per-token e4m3 activations) on the fp8 matrix cores")
     ap.add_argument("--graph", action="store_true", help="capture one step in a hipGraph and replay it in the timed loop (launch-bound decode shapes)")
+    ap.add_argument("--settle-ms", type=float, default=40.0,
+                    help="untimed steps run for this long BEFORE the --warmup steps: after an idle period the power controller starts ~15-25 %% below "
+                         "the clock it settles at under sustained GEMM load and takes ~20 ms to get there (profiles/r2_clock_power_evidence.md section 4); "
+                         "0 disables; reported as dvfs_settle_ms")
     ap.add_argument("--no-cfg3", action="store_true", help="default workload only: skip the LLaMA-2-7B 32-layer decoder forward (BASELINE configs[2]) that is timed after the main step")
     args = ap.parse_args()
 
@@ -486,6 +503,13 @@ def main():
         with torch.cuda.graph(graph):
             graph_out = step()
         eager_step, step = step, graph.replay
+    if args.settle_ms > 0:   # sustained-load clock first (not part of the W warmup / K timed steps)
+        torch.cuda.synchronize()
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -547,7 +571,7 @@ def main():
         out = {
             "metric": "INT8 GEMM TOPS + tokens/sec, LLaMA-7B W8A8 fwd, 1/2/4/8 MI355X vs CPU ref",
             "value": round(tops, 2), "unit": "TOPS", "tokens_per_s": round(tokens_per_s, 1),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dvfs_settle_ms": args.settle_ms, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8_e4m3" if (moe_mode and args.fp8) else "int8",
             "data": "synthetic (random-init N(0,0.02^2) weights quantised by from_float; N(0,1) activations with 1% outlier channels x20)",
             "config": {"workload": f"{args.workload}: {desc}", "M_per_gpu": M, "act_dtype": args.dtype,
@@ -583,7 +607,7 @@ def main():
             out["config"]["layers"] = nlayers
             out["config"]["norm"] = "fused RMSNorm->int8 (N1)" if args.fuse_norm else "torch RMSNorm (weight/input_scale) + per-linear quantise"
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec, min(M, 256), args.dtype)
+            out["cpu_baseline"] = cpu_baseline(spec, min(M, 256), args.dtype, mods=None if (layer_mode or moe_mode) else mods, xs=None if (layer_mode or moe_mode) else xs)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
