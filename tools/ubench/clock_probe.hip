@@ -386,6 +386,20 @@ int main(int argc, char **argv)
             RUN_MF(2, 0, "p8", "bench-sw", ab_s, 8);
             RUN_MF(0, 0, "distinct", "bench-sw", ab_s, 8);
         }
+        {   // does the SIGN toggling of the small activations cost matrix-core energy?  X + 3 (mostly 0..6, all high bits zero) vs X; |X| (sign removed)
+            std::vector<int8_t> xo(xb), xa(xb);
+            for (auto &v : xo) { int t = (int)v + 3; v = (int8_t)(t > 127 ? 127 : t); }
+            for (auto &v : xa) v = (int8_t)(v < 0 ? (v == -128 ? 127 : -v) : v);
+            v4i *ab_o = mf_operands(wb, xo), *ab_a = mf_operands(wb, xa);
+            RUN_MF(2, 0, "p8", "bench", ab_b, 8);
+            RUN_MF(2, 0, "p8", "bench X+3", ab_o, 8);
+            RUN_MF(2, 0, "p8", "bench |X|", ab_a, 8);
+            std::vector<int8_t> wa2(wb);
+            for (auto &v : wa2) v = (int8_t)(v < 0 ? (v == -128 ? 127 : -v) : v);
+            v4i *ab_w = mf_operands(wa2, xb), *ab_ww = mf_operands(wa2, xa);
+            RUN_MF(2, 0, "p8", "bench |W|", ab_w, 8);
+            RUN_MF(2, 0, "p8", "|W|,|X|", ab_ww, 8);
+        }
         RUN_MF(0, 0, "distinct", "uniform", ab_u, 8);
         RUN_MF(1, 0, "r1", "uniform", ab_u, 8);
         RUN_MF(2, 0, "p8", "uniform", ab_u, 8);
