@@ -78,16 +78,17 @@ class QuantArena:
         _, _, dt, shape, off, nb = e
         return self.buf[off:off + nb].view(dt).view(shape)
 
-    def pack(self, device):
-        """Allocate the arena on `device`, copy every buffer in (source rank: the real data; receivers: whatever
-        they hold, about to be overwritten) and re-home the module buffers as views of it."""
+    def pack(self, device, copy=True):
+        """Allocate the arena on `device` and re-home the module buffers as views of it; with copy=True (the source rank) every
+        buffer's contents are copied in first (receivers skip the copy: their arena is about to be overwritten)."""
         self.buf = torch.zeros(self.total, dtype=torch.uint8, device=device)
         for e in self.entries:
             m, n = self.mods[e[0]], e[1]
             v = self._view(e)
-            v.copy_(m._buffers[n].detach().to(device))
+            if copy:
+                v.copy_(m._buffers[n].detach().to(device))
             m._buffers[n] = v
-        if self.scalars:
+        if self.scalars and copy:
             vals = torch.tensor([float(self.mods[i]._buffers[n]) for i, n in self.scalars], dtype=torch.float32)
             self.buf[self.scalar_off:self.scalar_off + 4 * len(self.scalars)].view(torch.float32).copy_(vals.to(device))
         return self
@@ -124,21 +125,37 @@ def broadcast_arena(arena, src=0, group=None):
     dist.all_gather_into_tensor(arena.buf, mine.clone(), group=group)
 
 
-def broadcast_quantized(root, src=0, group=None, device=None):
+def broadcast_quantized(root, src=0, group=None, device=None, timing=None):
     """Make every rank's quantised buffers (W8A8 *and* FP8 modules) equal to rank `src`'s: flat-pack, scatter,
     all-gather.  Module buffers are views of the arena afterwards (kept alive by `root._asq_arena`).
-    Returns the number of payload bytes (for GB/s reporting)."""
+    Returns the number of payload bytes (for GB/s reporting).  `timing` (a dict) receives the wall time of the three phases
+    on this rank: "pack_s" (arena allocation + one copy of every buffer), "collective_s" (scatter + all-gather between
+    barriers: the xGMI part), "unpack_s" (scalar scales back to the host)."""
+    import time
     world = dist.get_world_size(group)
     arena = QuantArena(root, world)
     if not arena.mods:
         return 0
     dev = device if device is not None else arena.mods[0].weight.device
+
+    def tick():
+        if torch.device(dev).type == "cuda":
+            torch.cuda.synchronize(dev)
+        return time.perf_counter()
     if not all_ranks_equal(arena.signature, group=group, device=dev):
         raise RuntimeError("broadcast_quantized: ranks hold different module structures (class / buffer names / shapes); "
                            "every rank must build the same quantised model skeleton before the broadcast")
-    arena.pack(dev)
+    t0 = tick()
+    arena.pack(dev, copy=dist.get_rank(group) == src)
+    t1 = tick()
+    dist.barrier(group=group)
+    t1b = tick()
     broadcast_arena(arena, src=src, group=group)
+    t2 = tick()
     arena.unpack_scalars()
+    t3 = tick()
+    if timing is not None:
+        timing.update(pack_s=t1 - t0, collective_s=t2 - t1b, unpack_s=t3 - t2)
     try:
         root._asq_arena = arena
     except Exception:
@@ -161,10 +178,14 @@ def buffers_fingerprint(root):
     return acc
 
 
-def broadcast_report(nbytes, seconds, world):
-    """The `weight_broadcast` block of the bench line: achieved GB/s next to one xGMI link and the scatter +
-    all-gather model (payload/G over one link, then (G-1)/G of the payload over G-1 links)."""
+def broadcast_report(nbytes, seconds, world, timing=None):
+    """The `weight_broadcast` block of the bench line: achieved GB/s of the collective phase next to one xGMI link and the
+    scatter + all-gather model (payload/G over one link, then (G-1)/G of the payload over G-1 links)."""
     model_s = (nbytes / world / (XGMI_LINK_GBPS * 1e9) + nbytes * (world - 1) / world / ((world - 1) * XGMI_LINK_GBPS * 1e9)) if world > 1 else 0.0
-    return {"bytes": nbytes, "ms": seconds * 1e3, "GBps": nbytes / seconds / 1e9 if seconds > 0 else None, "xgmi_link_GBps": XGMI_LINK_GBPS,
-            "x_one_link": (nbytes / seconds / 1e9 / XGMI_LINK_GBPS) if seconds > 0 else None, "model_ms_scatter_allgather": model_s * 1e3,
-            "collectives": "1 scatter + 1 all-gather over one flat arena" if world > 1 else "none"}
+    coll = (timing or {}).get("collective_s", seconds)
+    out = {"bytes": nbytes, "ms_total_incl_pack": seconds * 1e3, "ms": coll * 1e3, "GBps": nbytes / coll / 1e9 if coll > 0 else None,
+           "xgmi_link_GBps": XGMI_LINK_GBPS, "x_one_link": (nbytes / coll / 1e9 / XGMI_LINK_GBPS) if coll > 0 else None,
+           "model_ms_scatter_allgather": model_s * 1e3, "collectives": "1 scatter + 1 all-gather over one flat arena" if world > 1 else "none"}
+    if timing:
+        out.update({k.replace("_s", "_ms"): v * 1e3 for k, v in timing.items()})
+    return out

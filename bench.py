@@ -480,13 +480,14 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        nbytes = replica.broadcast_quantized(root, src=0, device=device)
+        btiming = {}
+        nbytes = replica.broadcast_quantized(root, src=0, device=device, timing=btiming)
         torch.cuda.synchronize()
         dist.barrier()
         bt = time.perf_counter() - t0
         fp = replica.buffers_fingerprint(root)
         assert replica.all_ranks_equal(fp, device=device), "quantised buffers differ across ranks after broadcast"
-        bcast = replica.broadcast_report(nbytes, bt, world)
+        bcast = replica.broadcast_report(nbytes, bt, world, btiming)
 
     def sync_all():
         if world > 1:
