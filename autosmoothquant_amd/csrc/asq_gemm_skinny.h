@@ -35,13 +35,23 @@ namespace asq {
 
 constexpr int SK_STAGES = 3;
 
-__device__ __forceinline__ void sk_dma16(const int8_t *sbase, unsigned voff, unsigned lds_dst)
+#ifndef SK_W_NT
+#define SK_W_NT 0   // 1: weight rows fetched with the streaming (nt) cache policy.  Measured (skinny_probe, M = 32): 20480x5120 -4 %, 8192x8192 -3.5 %,
+                    // 5120x20480 -2.5 %, but 4096x4096 +5 %, 4096x11008 +7 %, M = 64 +9 %: not adopted
+#endif
+template <bool NT = false> __device__ __forceinline__ void sk_dma16(const int8_t *sbase, unsigned voff, unsigned lds_dst)
 {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory");
+    if constexpr (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(sbase), "s"(lds_dst)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(sbase), "s"(lds_dst)
+                     : "memory");
 }
 
 #define SK_VM_CASE(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -137,7 +147,7 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny(const int8_t *__restrict__
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) sk_dma16(wb, woff[nt][i], dst + nt * 2048 + i * 1024);
+            for (int i = 0; i < 2; ++i) sk_dma16<SK_W_NT != 0>(wb, woff[nt][i], dst + nt * 2048 + i * 1024);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
