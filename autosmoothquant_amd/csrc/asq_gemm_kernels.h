@@ -843,8 +843,10 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
     }
     constexpr bool kInt = Epi::Mma::kIsInt;
     GemmKernel kern = pick_kernel(x, w, M, N, K);
-    if (kern == KERN_P4 && !kInt) kern = KERN_P8;  // the 4-wave kernel is int8 only
-    if constexpr (kInt) if (kern == KERN_P4) {
+    constexpr bool kP4 = kInt && Epi::kOutBytes == 2;  // the 4-wave kernel: int8 operands, 2-byte outputs (its row epilogue; the int32 / int8-out
+                                                       // epilogues next to 256 accumulator registers would spill)
+    if (kern == KERN_P4 && !kP4) kern = KERN_P8;
+    if constexpr (kP4) if (kern == KERN_P4) {
         const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
         ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
         auto kfn = gemm_i8_p4<Epi>;

@@ -257,30 +257,13 @@ __global__ void __launch_bounds__(256, 1) gemm_i8_p4(const int8_t *__restrict__ 
     P8_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
     const int64_t mw0 = m0 + wm * 128, nw0 = n0 + wn * 128;
-    bool staged = false;
-    if constexpr (Epi::kOutBytes >= 2) staged = ((((uintptr_t)epi.out) & 15) == 0) && ((N * Epi::kOutBytes) % 16 == 0);
-    if constexpr (Epi::kOutBytes == 2) {
-        if (staged) {
-            p4_epilogue_rows(epi, [&](int in, int im) -> const v16i & { return acc[in][im]; }, mw0, nw0, lane, M, N, lds0 + wave * 16384);
-            staged = false;
-#ifdef ASQ_P8_PROBE
-            if constexpr (PROBE) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                P4_BLK(3);
-                P4_BLK_RT(7);
-            }
-#endif
-            return;
-        }
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        auto get = [&](int in, int im) -> const v16i & { return acc[2 * half + in][im]; };
-        if (staged) {
-            if constexpr (Epi::kOutBytes >= 2) epilogue_wave_staged<4>(epi, get, mw0, nw0 + 64 * half, lane, M, N, lds0 + wave * 16384);
-        } else {
-            epilogue_wave<2, 4>(epi, get, [](int im) { return im * 32; }, mw0, nw0 + 64 * half, lane, M, N);
-        }
+    static_assert(Epi::kOutBytes == 2, "gemm_i8_p4: 2-byte outputs (launch_gemm sends the other epilogues to p8)");
+    const bool staged = ((((uintptr_t)epi.out) & 15) == 0) && ((N * Epi::kOutBytes) % 16 == 0);
+    if (staged) {
+        p4_epilogue_rows(epi, [&](int in, int im) -> const v16i & { return acc[in][im]; }, mw0, nw0, lane, M, N, lds0 + wave * 16384);
+    } else {  // unaligned output / ragged row pitch: direct stores in the matrix-core layout, two 128 x 64 halves
+        epilogue_wave<2, 4>(epi, [&](int in, int im) -> const v16i & { return acc[in][im]; }, [](int im) { return im * 32; }, mw0, nw0, lane, M, N);
+        epilogue_wave<2, 4>(epi, [&](int in, int im) -> const v16i & { return acc[2 + in][im]; }, [](int im) { return im * 32; }, mw0, nw0 + 64, lane, M, N);
     }
 #ifdef ASQ_P8_PROBE
     if constexpr (PROBE) {
