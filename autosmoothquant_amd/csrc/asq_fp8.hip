@@ -201,8 +201,8 @@ int launch_fp8_linear(const int8_t *xq, const int8_t *w, void *out, int64_t M, i
                       float a_scale_host, float w_scale, const float *bias, bool vec_ok, hipStream_t s)
 {
     if (bias)
-        return launch_gemm(xq, w, M, N, K, EpiFp8<DT, true, MMA>{out, N, a_scale_dev, a_per_token, a_scale_host, w_scale, bias, vec_ok}, s, "asq_linear_fp8");
-    return launch_gemm(xq, w, M, N, K, EpiFp8<DT, false, MMA>{out, N, a_scale_dev, a_per_token, a_scale_host, w_scale, bias, vec_ok}, s, "asq_linear_fp8");
+        return launch_gemm(xq, w, M, N, K, EpiFp8<DT, true, MMA>{out, N, a_scale_dev, bias, nullptr, a_scale_host, w_scale, a_per_token, vec_ok}, s, "asq_linear_fp8");
+    return launch_gemm(xq, w, M, N, K, EpiFp8<DT, false, MMA>{out, N, a_scale_dev, bias, nullptr, a_scale_host, w_scale, a_per_token, vec_ok}, s, "asq_linear_fp8");
 }
 
 template <int DT>
@@ -210,9 +210,9 @@ int launch_fp8_grouped(const int8_t *xq, const int8_t *w, void *out, int64_t M, 
                        const float *bias, bool vec_ok, const int *goffs, int ngroups, hipStream_t s)
 {
     if (bias)
-        return launch_gemm(xq, w, M, N, K, EpiFp8<DT, true, MmaFp8>{out, N, a_scale, true, 1.0f, 1.0f, bias, vec_ok, w_scale_group}, s, "asq_linear_fp8_grouped",
+        return launch_gemm(xq, w, M, N, K, EpiFp8<DT, true, MmaFp8>{out, N, a_scale, bias, w_scale_group, 1.0f, 1.0f, true, vec_ok}, s, "asq_linear_fp8_grouped",
                            nullptr, 0, goffs, ngroups);
-    return launch_gemm(xq, w, M, N, K, EpiFp8<DT, false, MmaFp8>{out, N, a_scale, true, 1.0f, 1.0f, bias, vec_ok, w_scale_group}, s, "asq_linear_fp8_grouped",
+    return launch_gemm(xq, w, M, N, K, EpiFp8<DT, false, MmaFp8>{out, N, a_scale, bias, w_scale_group, 1.0f, 1.0f, true, vec_ok}, s, "asq_linear_fp8_grouped",
                        nullptr, 0, goffs, ngroups);
 }
 

@@ -26,6 +26,7 @@
 #include "asq_common.h"
 #include <string.h>
 #include <type_traits>
+#include <utility>
 #include <unordered_map>
 
 namespace asq {
@@ -168,20 +169,22 @@ template <int DT, bool HAS_ROW, bool HAS_COL, bool HAS_BIAS> struct EpiDequant {
     using Mma = MmaI8;
     static constexpr bool kHasRow = HAS_ROW, kHasCol = HAS_COL, kHasBias = HAS_BIAS;
     static constexpr int kOutBytes = (DT == ASQ_F32) ? 4 : 2;
+    // (pointers first, 4-byte scalars together: a float followed by padding and a pointer keeps SROA from promoting the by-value
+    // kernel argument, which costs the skinny kernel 32 B/lane of scratch)
     void *out;
     int64_t N;
+    const float *s_row;    // [M]   (HAS_ROW)
+    const float *s_col;    // [N]   (HAS_COL)
+    const float *bias;     // [N]   (HAS_BIAS)
+    const float *s_group;  // grouped launches: per-group scalar dequant scale [ngroups] (device) or null
     float s_scalar;
-    const float *s_row;  // [M]   (HAS_ROW)
-    const float *s_col;  // [N]   (HAS_COL)
-    const float *bias;   // [N]   (HAS_BIAS)
     int order;
     bool vec_ok;
-    const float *s_group;  // grouped launches: per-group scalar dequant scale [ngroups] (device) or null
 
     __device__ __forceinline__ EpiDequant rebased(int grp, int, int64_t, int64_t Ncols) const
     {
-        return EpiDequant{out, N, s_group ? s_group[grp] : s_scalar, s_row, HAS_COL ? s_col + (int64_t)grp * Ncols : s_col,
-                          HAS_BIAS ? bias + (int64_t)grp * Ncols : bias, order, vec_ok, s_group};
+        return EpiDequant{out, N, s_row, HAS_COL ? s_col + (int64_t)grp * Ncols : s_col, HAS_BIAS ? bias + (int64_t)grp * Ncols : bias, s_group,
+                          s_group ? s_group[grp] : s_scalar, order, vec_ok};
     }
     __device__ __forceinline__ float row(int64_t m) const { return HAS_ROW ? s_row[m] : 1.0f; }
 
@@ -273,10 +276,9 @@ template <int DT> struct EpiDequantQ {
     static constexpr int kOutBytes = 1;
     int8_t *out;
     int64_t N;
-    float s_scalar;
     const float *s_row, *s_col, *bias;
+    float s_scalar, quant_scale;
     int order, act, qmode;
-    float quant_scale;
     bool vec_ok;
     __device__ __forceinline__ EpiDequantQ rebased(int, int, int64_t, int64_t) const { return *this; }
     __device__ __forceinline__ float row(int64_t m) const { return s_row ? s_row[m] : 1.0f; }
@@ -383,15 +385,14 @@ template <int DT, bool HAS_BIAS, class MMA_ = MmaFp8> struct EpiFp8 {
     void *out;
     int64_t N;
     const float *a_scale_dev;
-    bool a_per_token;
-    float a_scale_host, w_scale;
     const float *bias;
-    bool vec_ok;
-    const float *w_scale_group = nullptr;  // grouped launches: per-group weight scale [ngroups] (device)
+    const float *w_scale_group;  // grouped launches: per-group weight scale [ngroups] (device) or null
+    float a_scale_host, w_scale;
+    bool a_per_token, vec_ok;
     __device__ __forceinline__ EpiFp8 rebased(int grp, int, int64_t, int64_t Ncols) const
     {
-        return EpiFp8{out, N, a_scale_dev, a_per_token, a_scale_host, w_scale_group ? w_scale_group[grp] : w_scale,
-                      HAS_BIAS ? bias + (int64_t)grp * Ncols : bias, vec_ok, w_scale_group};
+        return EpiFp8{out, N, a_scale_dev, HAS_BIAS ? bias + (int64_t)grp * Ncols : bias, w_scale_group, a_scale_host,
+                      w_scale_group ? w_scale_group[grp] : w_scale, a_per_token, vec_ok};
     }
     __device__ __forceinline__ float row(int64_t m) const { return a_scale_dev ? (a_per_token ? a_scale_dev[m] : a_scale_dev[0]) : a_scale_host; }
     __device__ __forceinline__ void cols(int64_t n, int64_t Ncols, v4f &sc, v4f &b) const
@@ -436,6 +437,12 @@ template <int DT, bool HAS_BIAS, class MMA_ = MmaFp8> struct EpiFp8 {
     }
 };
 
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // Wave-level epilogue over NTN x NTM accumulator tiles; tile (in, im) covers
 // n in [nw0 + 32*in, +32), m in [mw0 + mstep(im), +32).  `get(in, im)` returns the v16i.
 template <int NTN, int NTM, class Epi, class Get, class MOff>
@@ -461,20 +468,19 @@ __device__ __forceinline__ void epilogue_wave(const Epi &epi, Get get, MOff moff
             bb[in][g] = (v4f){0.f, 0.f, 0.f, 0.f};
             if (n < N) epi.cols(n, N, sc[in][g], bb[in][g]);
         }
+    // compile-time (in, im): with a runtime loop the compiler sometimes keeps the tile loop rolled (large bodies: bf16 rounding +
+    // int8 re-quantisation) and then indexes the accumulators through a 512-B/lane scratch copy
+    static_for<NTM * NTN>([&](auto t) __attribute__((always_inline)) {
+        constexpr int im = decltype(t)::value / NTN, in = decltype(t)::value % NTN;
+        if (mrow[im] >= M) return;
+        const typename Epi::Mma::acc_t a = get(in, im);
 #pragma unroll
-    for (int im = 0; im < NTM; ++im) {
-        if (mrow[im] >= M) continue;
-#pragma unroll
-        for (int in = 0; in < NTN; ++in) {
-            const typename Epi::Mma::acc_t a = get(in, im);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int64_t n = nw0 + in * 32 + 8 * g + 4 * (lane >> 5);
-                if (n < N)
-                    epi.store4(mrow[im], n, (typename Epi::Mma::acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g], N);
-            }
+        for (int g = 0; g < 4; ++g) {
+            const int64_t n = nw0 + in * 32 + 8 * g + 4 * (lane >> 5);
+            if (n < N)
+                epi.store4(mrow[im], n, (typename Epi::Mma::acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g], N);
         }
-    }
+    });
 }
 
 // Coalescing epilogue of the 256x256 kernel (wave tile 128(m) x 64(n): NTN = 2, NTM = 4).
@@ -947,13 +953,13 @@ template <int DT> static inline int launch_dequant_q_impl(const DequantQArgs &q,
 {
     const DequantArgs &a = q.d;
     return launch_gemm(a.xq, a.w, a.M, a.N, a.K,
-                       EpiDequantQ<DT>{(int8_t *)a.out, a.N, a.s_scalar, a.s_row, a.s_col, a.bias, a.order, q.act, q.qmode, q.quant_scale, a.vec_ok}, s,
+                       EpiDequantQ<DT>{(int8_t *)a.out, a.N, a.s_row, a.s_col, a.bias, a.s_scalar, q.quant_scale, a.order, q.act, q.qmode, a.vec_ok}, s,
                        "asq_linear_w8a8_q8", a.ws, a.ws_bytes);
 }
 
 template <int DT, bool R, bool C, bool B> static inline int launch_dequant_one(const DequantArgs &a, hipStream_t s)
 {
-    return launch_gemm(a.xq, a.w, a.M, a.N, a.K, EpiDequant<DT, R, C, B>{a.out, a.N, a.s_scalar, a.s_row, a.s_col, a.bias, a.order, a.vec_ok, a.s_group},
+    return launch_gemm(a.xq, a.w, a.M, a.N, a.K, EpiDequant<DT, R, C, B>{a.out, a.N, a.s_row, a.s_col, a.bias, a.s_group, a.s_scalar, a.order, a.vec_ok},
                        s, "asq_linear_w8a8", a.ws, a.ws_bytes, a.goffs, a.ngroups);
 }
 
