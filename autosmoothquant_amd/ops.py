@@ -2,6 +2,8 @@
 
 Every function validates dtype / device / contiguity / shape and raises instead of
 falling back: the reference passes raw ``data_ptr`` with no checks (bindings.cpp:73-80)."""
+import threading
+
 import torch
 
 from . import _lib as L
@@ -57,6 +59,42 @@ def _gemm_ws(M, N, K, dev):
     comes from torch's stream-ordered caching allocator, so concurrent streams never share it"""
     n = L.lib().asq_gemm_workspace_bytes(M, N, K)
     return (torch.empty((n,), dtype=torch.uint8, device=dev), n) if n else (None, 0)
+
+
+_WS_CACHE_MAX = 8 << 20   # decode-sized calls only: the quantised activation of a 65536-row call is 256 MiB and not worth pinning
+_ws_tls = threading.local()
+
+
+def _forward_ws(lib, M, N, K, dev, stream):
+    """Workspace of asq_linear_w8a8_forward (int8 activation + row scales + split-K slabs).  Decode-sized calls are host-bound
+    (two launches ~7 us): their workspace is kept per (thread, device, stream) instead of going through
+    torch.empty + a size query on every call (-2 us).  Same-stream launches are ordered, so consecutive calls may share it;
+    another stream or thread gets its own.  A buffer that is outgrown is retired, not freed: a captured hipGraph may still
+    replay launches that point at it."""
+    if M * K > _WS_CACHE_MAX:
+        n = lib.asq_linear_w8a8_workspace_bytes(M, N, K)
+        return torch.empty((n,), dtype=torch.uint8, device=dev), n
+    cache = _ws_tls.__dict__.setdefault("c", {})
+    key = (dev.index, stream, M, N, K)
+    hit = cache.get(key)
+    if hit is not None:
+        return hit
+    n = lib.asq_linear_w8a8_workspace_bytes(M, N, K)
+    slot = cache.get((dev.index, stream))
+    if slot is None or slot.numel() < n:
+        if n > _WS_CACHE_MAX:
+            return torch.empty((n,), dtype=torch.uint8, device=dev), n
+        if slot is not None:
+            _ws_tls.__dict__.setdefault("retired", []).append(slot)
+        slot = torch.empty((max(2 * n, 1 << 20),), dtype=torch.uint8, device=dev)
+        cache[(dev.index, stream)] = slot
+        for k in [k for k in cache if len(k) == 5 and k[:2] == key[:2]]:   # shape entries of this stream point at the old slot
+            del cache[k]
+    if len(cache) > 256:
+        for k in [k for k in cache if len(k) == 5]:
+            del cache[k]
+    cache[key] = (slot, n)
+    return cache[key]
 
 
 def _same_device(*ts):
@@ -312,12 +350,12 @@ def linear_w8a8_forward(x2d, w, act_mode, quant_scale, s_scalar, s_col=None, bia
     if M == 0 or N == 0:
         return out
     lib = L.lib()
-    nbytes = lib.asq_linear_w8a8_workspace_bytes(M, N, K)
-    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)  # caching allocator: 512-B aligned, stream-ordered
+    stream = _stream(x2d)
+    ws, nbytes = _forward_ws(lib, M, N, K, dev, stream)
     with _on(dev):
         L.check(lib.asq_linear_w8a8_forward(x2d.data_ptr(), _DT[x2d.dtype], w.data_ptr(), out.data_ptr(), M, N, K,
                                             _ACT[act_mode], float(quant_scale), float(s_scalar), _ptr(s_col), _ptr(bias),
-                                            ws.data_ptr(), nbytes, _stream(x2d)), "asq_linear_w8a8_forward")
+                                            ws.data_ptr(), nbytes, stream), "asq_linear_w8a8_forward")
     return out
 
 

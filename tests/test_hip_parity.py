@@ -455,3 +455,45 @@ print("ok")
         env["ASQ_KSPLIT"] = str(ksplit)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_forward_workspace_cache_streams_growth_and_graph_replay(dev):
+    """Decode-sized module calls reuse one workspace per (thread, device, stream): results stay exact when the shapes
+    grow (the slot is re-allocated), when two streams run interleaved, and when a hipGraph captured against an outgrown
+    slot is replayed afterwards (retired slots stay alive)."""
+    from autosmoothquant_amd import ops
+    rng = np.random.default_rng(77)
+    K = 512
+    w_np = rng.integers(-127, 128, size=(320, K), dtype=np.int8)
+    w = torch.from_numpy(w_np).to(dev)
+
+    def want(x_np, mode):
+        return O.linear_forward(x_np, "f16", w_np, 0.01, None, "per-token" if mode == "per-token" else "per-tensor")
+
+    def case(M, mode):
+        x_np = (rng.standard_normal((M, K)) * 30).astype(np.float16).astype(np.float32)
+        return x_np, t_in(x_np, "f16", dev), want(x_np, mode)
+
+    # 1. capture a graph on a side stream while its slot is small
+    x_np, xg, want_g = case(4, "per-tensor-round")
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        ops.linear_w8a8_forward(xg, w, "per-tensor-round", 1.0, 0.01)   # warm (allocates the slot outside capture)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            yg = ops.linear_w8a8_forward(xg, w, "per-tensor-round", 1.0, 0.01)
+    # 2. growing shapes on the default stream and on the side stream, interleaved
+    for M in (1, 7, 64, 700, 3000, 9000, 5):
+        for mode in ("per-tensor-round", "per-token"):
+            x_np, x, ref = case(M, mode)
+            y0 = ops.linear_w8a8_forward(x, w, mode, 1.0, 0.01)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                y1 = ops.linear_w8a8_forward(x, w, mode, 1.0, 0.01)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            assert np.array_equal(t_out(y0), ref) and np.array_equal(t_out(y1), ref)
+    # 3. replay the early graph: its workspace pointer must still be valid
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(t_out(yg), want_g)

@@ -44,3 +44,18 @@ t0 = time.perf_counter()
 for _ in range(2000): ops.linear_w8a8_forward(x, m.weight, "per-tensor-round", 1.0, 1.0)
 t1 = time.perf_counter(); torch.cuda.synchronize()
 print('ops.linear_w8a8_forward us', (t1 - t0) / 2000 * 1e6)
+
+# ---- A/B of the per-stream workspace cache (ops._forward_ws) in this process
+def _uncached(lib_, M_, N_, K_, dev_, stream_):
+    n_ = lib_.asq_linear_w8a8_workspace_bytes(M_, N_, K_)
+    return torch.empty((n_,), dtype=torch.uint8, device=dev_), n_
+cached = ops._forward_ws
+for name, fn in (("cached", cached), ("uncached", _uncached), ("cached", cached), ("uncached", _uncached)):
+    ops._forward_ws = fn
+    for _ in range(200): m(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4000): m(x)
+    t1 = time.perf_counter(); torch.cuda.synchronize()
+    print(f'module call, workspace {name}: {(t1 - t0) / 4000 * 1e6:.2f} us')
+ops._forward_ws = cached
