@@ -93,11 +93,13 @@ template <> struct ElemT<ASQ_BF16> {
 };
 
 // .round().clamp(-128,127).to(int8): half-to-even; NaN -> 0 (reference CPU path), +-inf saturate
+// Three instructions: v_rndne_f32, v_cvt_i32_f32 (the hardware conversion saturates out-of-range values and +-inf and turns NaN
+// into 0 -- the C cast is undefined there, hence the asm), v_med3_i32.
 __device__ __forceinline__ int quant_i8(float v)
 {
-    float r = rintf(v);
-    r = fminf(fmaxf(r, -128.0f), 127.0f);
-    return (v != v) ? 0 : (int)r;
+    int q;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(q) : "v"(rintf(v)));
+    return q < -128 ? -128 : (q > 127 ? 127 : q);
 }
 
 // ---------------------------------------------------------------------------------
@@ -170,4 +172,13 @@ struct QRowFast {
         return __fmaf_rn(__fmaf_rn(-s, q1, x), y, q1);
     }
     __device__ __forceinline__ int operator()(float x) const { return quant_i8(div(x)); }
+    // two quotients per instruction (v_pk_mul_f32 / v_pk_fma_f32): the same five IEEE operations per element
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    __device__ __forceinline__ v2f_ div2(v2f_ x) const
+    {
+        const v2f_ ms = {-s, -s}, yy = {y, y};
+        const v2f_ q0 = x * yy;
+        const v2f_ q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(ms, q0, x), yy, q0);
+        return __builtin_elementwise_fma(__builtin_elementwise_fma(ms, q1, x), yy, q1);
+    }
 };

@@ -430,9 +430,10 @@ if constexpr (MMA::kIsInt) {
         P8_BLK(3);
         P8_BLK_RT(7);
         if (wave == 0 && lane == 0 && blockIdx.x < 4096) {
-            unsigned xcc;
+            unsigned xcc, hwid;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            p8_blk[blockIdx.x][4] = xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            p8_blk[blockIdx.x][4] = (xcc & 7) | ((unsigned long long)hwid << 8);  // bits 0-2 XCC; HW_ID above (cu_id 8-11, sh_id 12, se_id 13-15 of it)
             p8_blk[blockIdx.x][5] = (unsigned)(tile_m * 65536 + tile_n);
         }
     }

@@ -237,6 +237,34 @@ __device__ __forceinline__ float exp_det(float x)
     return __fmul_rn(__fmul_rn(p, pow2i(n1)), pow2i(n2));
 }
 
+// The same function on a PAIR of values: every multiply / add is one v_pk_mul_f32 / v_pk_add_f32 (gfx950 issues two IEEE fp32
+// operations per lane per instruction), operation for operation the sequence of exp_det -- the SiLU kernel is VALU-bound on exactly
+// this polynomial.  Two shortcuts that cannot change a result the caller sees:
+//  * the final scaling p * 2^n1 * 2^n2 is one v_ldexp_f32: identical whenever the result is a normal number or overflows (the
+//    first product is exact, the second rounds once, as ldexp does); for subnormal results both round once from the same exact
+//    value;
+//  * NAN_SELECT = false skips the "NaN in, NaN out" select: the caller's g / (1 + e) is NaN through g anyway.
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <bool NAN_SELECT = true> __device__ __forceinline__ v2f exp_det2(v2f x0)
+{
+    const v2f x = {__builtin_amdgcn_fmed3f(x0[0], -104.0f, 89.0f), __builtin_amdgcn_fmed3f(x0[1], -104.0f, 89.0f)};  // (a NaN lane computes on -104)
+    const v2f t = x * 1.44269502162933349609375f;
+    const v2f n = {rintf(t[0]), rintf(t[1])};
+    v2f r = x - n * 0.693138122558593750f;
+    r = r - n * 9.05800061445916071534156799316e-06f;
+    v2f p = {1.0f / 5040.0f, 1.0f / 5040.0f};
+    p = p * r + 1.0f / 720.0f;
+    p = p * r + 1.0f / 120.0f;
+    p = p * r + 1.0f / 24.0f;
+    p = p * r + 1.0f / 6.0f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    const v2f e = {__builtin_ldexpf(p[0], (int)n[0]), __builtin_ldexpf(p[1], (int)n[1])};
+    if constexpr (!NAN_SELECT) return e;
+    else return (v2f){x0[0] == x0[0] ? e[0] : x0[0], x0[1] == x0[1] ? e[1] : x0[1]};
+}
+
 __device__ __forceinline__ float block_sum_256(float v, float *red)
 {
 #pragma unroll
@@ -401,30 +429,48 @@ __global__ void __launch_bounds__(256) silu_mul_quant_cached(const void *__restr
                                                              int8_t *__restrict__ xq, float *__restrict__ s_row, int K)
 {
     constexpr int VEC = ElemT<DT>::VEC;
+    // fp16: the product of two fp16 values is exact in fp32, so dt(fp32(sl) * fp32(u)) IS the IEEE fp16 product: one v_pk_mul_f16 per
+    // pair on the raw `up` words (no unpack, no round trip), the activation kept as packed halves (half the registers)
+    constexpr bool H = DT == ASQ_F16;
+    typedef _Float16 v2h __attribute__((ext_vector_type(2)));
     __shared__ float red[4];
     const int64_t row = blockIdx.x;
     const char *grow = (const char *)gv + row * (int64_t)K * (16 / VEC);
     const char *urow = (const char *)uv + row * (int64_t)K * (16 / VEC);
     const int nvec = K / VEC;
-    float a[NV][VEC];
-    uint32_t amax = 0;  // |a| maximum as an fp32 bit pattern (see AbsMax)
+    float a[H ? 1 : NV][H ? 1 : VEC];
+    uint32_t ah[H ? NV : 1][4];
+    uint32_t amax = 0;  // |a| maximum as an fp32 bit pattern (see AbsMax); fp16: two packed 15-bit patterns
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = i * 256 + threadIdx.x;
         if (idx < nvec) {
-            float g[VEC], u[VEC];
+            float g[VEC];
             vec_unpack<DT>(*(const v4i *)(grow + (int64_t)idx * 16), g);
-            vec_unpack<DT>(*(const v4i *)(urow + (int64_t)idx * 16), u);
+            const v4i uw = *(const v4i *)(urow + (int64_t)idx * 16);
+            [[maybe_unused]] float u[VEC];
+            if constexpr (!H) vec_unpack<DT>(uw, u);
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const float sl = ElemT<DT>::round(__fdiv_rn(g[j], __fadd_rn(1.0f, exp_det(-g[j]))));
-                a[i][j] = ElemT<DT>::round(__fmul_rn(sl, u[j]));
-                if constexpr (PER_TOKEN) amax = umax32(amax, absbits(a[i][j]));
+            for (int j = 0; j < VEC; j += 2) {  // two elements per packed instruction
+                const v2f den = exp_det2<false>((v2f){-g[j], -g[j + 1]}) + 1.0f;
+                const float q0 = __fdiv_rn(g[j], den[0]), q1 = __fdiv_rn(g[j + 1], den[1]);
+                if constexpr (H) {
+                    const v2h sl = {(_Float16)q0, (_Float16)q1};
+                    const uint32_t pr = __builtin_bit_cast(uint32_t, sl * __builtin_bit_cast(v2h, (uint32_t)uw[j / 2]));
+                    ah[i][j / 2] = pr;
+                    if constexpr (PER_TOKEN) amax = pk_max_u16(amax, pr & 0x7FFF7FFFu);
+                } else {
+                    const v2f pr = (v2f){ElemT<DT>::round(q0), ElemT<DT>::round(q1)} * (v2f){u[j], u[j + 1]};
+                    a[i][j] = ElemT<DT>::round(pr[0]);
+                    a[i][j + 1] = ElemT<DT>::round(pr[1]);
+                    if constexpr (PER_TOKEN) amax = umax32(amax, umax32(absbits(a[i][j]), absbits(a[i][j + 1])));
+                }
             }
         }
     }
     float qs = quant_scale, rowmax = __builtin_inff();
     if constexpr (PER_TOKEN) {
+        if constexpr (H) amax = __float_as_uint(ElemT<DT>::load((uint16_t)umax32(amax & 0xFFFFu, amax >> 16)));  // widening keeps the order, NaN stays NaN
         rowmax = block_absmax_256(amax, red);
         qs = ElemT<DT>::round(rowmax / 127.0f);
         if (threadIdx.x == 0) s_row[row] = qs;
@@ -438,7 +484,28 @@ __global__ void __launch_bounds__(256) silu_mul_quant_cached(const void *__restr
         if (idx < nvec) {
             int q[VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) q[j] = PER_TOKEN ? quant_i8(d.fast ? qf.div(a[i][j]) : a[i][j] / qs) : quant_i8(ElemT<DT>::round(a[i][j] / qs));
+            for (int j = 0; j < VEC; j += 2) {
+                v2f av;
+                if constexpr (H) {
+                    const v2h hh = __builtin_bit_cast(v2h, ah[i][j / 2]);
+                    av = (v2f){(float)hh[0], (float)hh[1]};
+                } else {
+                    av = (v2f){a[i][j], a[i][j + 1]};
+                }
+                if constexpr (PER_TOKEN) {
+                    if (d.fast) {
+                        const v2f t = qf.div2(av);
+                        q[j] = quant_i8(t[0]);
+                        q[j + 1] = quant_i8(t[1]);
+                    } else {
+                        q[j] = quant_i8(av[0] / qs);
+                        q[j + 1] = quant_i8(av[1] / qs);
+                    }
+                } else {
+                    q[j] = quant_i8(ElemT<DT>::round(av[0] / qs));
+                    q[j + 1] = quant_i8(ElemT<DT>::round(av[1] / qs));
+                }
+            }
             if constexpr (DT == ASQ_F32) {
                 *(uint32_t *)(orow + (int64_t)idx * 4) = pack4(q[0], q[1], q[2], q[3]);
             } else {

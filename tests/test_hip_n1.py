@@ -96,6 +96,29 @@ def test_silu_mul_quantize_equals_oracle(dt, per_token):
             assert np.array_equal(s.cpu().numpy(), rs.reshape(-1))
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("per_token", [True, False])
+def test_silu_mul_quantize_every_16bit_gate(dt, per_token):
+    """Exhaustive in the gate: all 65 536 bit patterns of the 16-bit type (zeros, subnormals, every exponent, +-inf, NaNs),
+    each against several `up` values -- the whole domain of exp_det and of the division, not a sample of it."""
+    from autosmoothquant_amd import ops
+    bits = np.arange(65536, dtype=np.uint32)
+    if dt == "f16":
+        g = bits.astype(np.uint16).view(np.float16).astype(np.float32)
+    else:
+        g = (bits << 16).astype(np.uint32).view(np.float32)
+    g = g.reshape(64, 1024)
+    rng = np.random.default_rng(5)
+    for k, scale in enumerate([1.0, 1e-3, 300.0]):
+        u = O.round_to(rng.standard_normal(g.shape).astype(np.float32) * scale, dt)
+        with np.errstate(all="ignore"):
+            rq, rs = n1.silu_mul_quant_kernel_order(g, u, dt, per_token, 0.21)
+        xq, s = ops.silu_mul_quantize(_t(g, dt), _t(u, dt), per_token, 0.21)
+        assert np.array_equal(xq.cpu().numpy(), rq), (dt, k)
+        if per_token:
+            assert np.array_equal(s.cpu().numpy(), rs.reshape(-1), equal_nan=True)
+
+
 @pytest.mark.parametrize("c", [c for c in goldenio.load_g8() if c["kind"] in ("lnq", "rmsq")], ids=lambda c: c["id"])
 def test_reference_fixtures_through_hip(c):
     """The reference's own LayerNormQ / folded-RMSNorm+round inputs through the HIP kernel: equal to the oracle exactly and to the

@@ -24,6 +24,8 @@
 #include "../../autosmoothquant_amd/csrc/asq_gemm_inst_bf16.hip"
 #include "../../autosmoothquant_amd/csrc/asq_gemm.hip"
 #include <vector>
+#include <map>
+#include <algorithm>
 #include <string>
 #include <thread>
 #include <atomic>
@@ -356,7 +358,7 @@ int main(int argc, char **argv)
     CK(hipMemcpy(dxb, xb.data(), xb.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(dwb, wb.data(), wb.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(dxu, xu.data(), xu.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(dwu, wu.data(), wu.size(), hipMemcpyHostToDevice));
     CK(hipMemset(dz, 0, z.size()));
-    EpiDequant<ASQ_F16, false, false, false> e16{o16, N, 1e-4f, nullptr, nullptr, nullptr, 0, true, nullptr};
+    EpiDequant<ASQ_F16, false, false, false> e16{o16, N, nullptr, nullptr, nullptr, nullptr, 1e-4f, 0, true};
 
     if (what == "pmc") {
         // for rocprofv3 --pmc: the PRODUCTION kernel on bench data at two K depths (a fixed per-dispatch overhead in
@@ -369,6 +371,69 @@ int main(int argc, char **argv)
             hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(512), 0, 0, (int *)nullptr);
         }
         CK(hipDeviceSynchronize());
+        return 0;
+    }
+
+    if (what == "multi") {
+        // Many tiles per CU (the cfg3 regime): per-CU timeline of consecutive blocks from the stamps -- how long a block takes when its
+        // neighbours are out of step, and how long a CU sits between the end of one block and the start of the next.
+        struct Shape { int64_t M, N; };
+        for (Shape sh : {Shape{4096, 4096}, Shape{16384, 4096}, Shape{8192, 11008}}) {
+            const int64_t M2 = sh.M, N2 = sh.N;
+            int8_t *x2, *w2; void *o2;
+            CK(hipMalloc(&x2, M2 * K)); CK(hipMalloc(&w2, N2 * K)); CK(hipMalloc(&o2, M2 * N2 * 2));
+            for (int64_t off = 0; off < M2 * K; off += M * K) CK(hipMemcpy(x2 + off, dxb, std::min<int64_t>(M * K, M2 * K - off), hipMemcpyDeviceToDevice));
+            for (int64_t off = 0; off < N2 * K; off += N * K) CK(hipMemcpy(w2 + off, dwb, std::min<int64_t>(N * K, N2 * K - off), hipMemcpyDeviceToDevice));
+            EpiDequant<ASQ_F16, false, false, false> e2{o2, N2, nullptr, nullptr, nullptr, nullptr, 1e-4f, 0, true};
+            auto kfn = gemm_i8_p8<decltype(e2), 128>;
+            auto kprod = gemm_i8_p8<decltype(e2), 0>;
+            CK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES));
+            CK(hipFuncSetAttribute((const void *)kprod, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES));
+            const int tm = (int)(M2 / 256), tn = (int)(N2 / 256), nb = tm * tn;
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            auto t_start = std::chrono::steady_clock::now();
+            float ms = 0, msp = 0;
+            const int BATCH = 20;
+            while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() < seconds) {
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < BATCH; ++i) hipLaunchKernelGGL(kprod, dim3(nb), dim3(512), P8_LDS_BYTES, 0, x2, w2, M2, N2, K, tm, tn, 1, (const int *)nullptr, 0, e2);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&msp, e0, e1));
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < BATCH; ++i) hipLaunchKernelGGL(kfn, dim3(nb), dim3(512), P8_LDS_BYTES, 0, x2, w2, M2, N2, K, tm, tn, 1, (const int *)nullptr, 0, e2);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+            }
+            static unsigned long long h[4096][8];
+            CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(p8_blk), sizeof(h)));
+            // group by CU (XCC + se/sh/cu bits of HW_ID), order by start time
+            std::map<unsigned, std::vector<int>> per_cu;
+            for (int b = 0; b < nb && b < 4096; ++b) per_cu[(unsigned)((h[b][4] & 7) | (((h[b][4] >> 16) & 0xFF) << 3))].push_back(b);
+            double dur_first = 0, dur_rest = 0, gap = 0, cyc_first[3] = {0, 0, 0}, cyc_rest[3] = {0, 0, 0}; int nf = 0, nr = 0, ng = 0; double gmax = 0, span = 0;
+            std::vector<double> gaps;
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (auto &kv : per_cu) {
+                auto &v = kv.second;
+                std::sort(v.begin(), v.end(), [&](int a, int b) { return h[a][6] < h[b][6]; });
+                for (size_t i = 0; i < v.size(); ++i) {
+                    const int b = v[i];
+                    const double d = (double)(h[b][7] - h[b][6]) * 0.01;  // us (100 MHz)
+                    t0 = std::min(t0, h[b][6]); t1 = std::max(t1, h[b][7]);
+                    double *c = i == 0 ? cyc_first : cyc_rest;
+                    for (int j = 0; j < 3; ++j) c[j] += (double)(h[b][j + 1] - h[b][j]);
+                    if (i == 0) { dur_first += d; ++nf; } else { dur_rest += d; ++nr; }
+                    if (i > 0) { const double g = ((double)h[b][6] - (double)h[v[i - 1]][7]) * 0.01; gap += g; ++ng; gmax = std::max(gmax, g); gaps.push_back(g); }
+                }
+            }
+            span = (double)(t1 - t0) * 0.01;
+            std::sort(gaps.begin(), gaps.end());
+            printf("  p8 M=%lld N=%lld K=%lld: %d tiles on %zu CUs (%.2f per CU); production %.1f us/launch = %.0f TOPS; stamped %.1f us; first-to-last stamp span %.1f us\n", (long long)M2, (long long)N2,
+                   (long long)K, nb, per_cu.size(), (double)nb / per_cu.size(), msp * 1e3 / BATCH, 2.0 * M2 * N2 * K / (msp * 1e3 / BATCH) / 1e6, ms * 1e3 / BATCH, span);
+            printf("      block wall time: first on its CU %.2f us (%d), later ones %.2f us (%d); cycles prologue/K-loop/epilogue first %.0f/%.0f/%.0f later %.0f/%.0f/%.0f\n", nf ? dur_first / nf : 0, nf,
+                   nr ? dur_rest / nr : 0, nr, nf ? cyc_first[0] / nf : 0, nf ? cyc_first[1] / nf : 0, nf ? cyc_first[2] / nf : 0, nr ? cyc_rest[0] / nr : 0, nr ? cyc_rest[1] / nr : 0, nr ? cyc_rest[2] / nr : 0);
+            if (ng) printf("      CU idle between consecutive blocks: mean %.2f us, median %.2f, p90 %.2f, max %.2f (%d gaps)\n", gap / ng, gaps[gaps.size() / 2], gaps[gaps.size() * 9 / 10], gmax, ng);
+            CK(hipFree(x2)); CK(hipFree(w2)); CK(hipFree(o2));
+        }
         return 0;
     }
     Sampler smp;

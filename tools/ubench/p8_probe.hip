@@ -89,7 +89,7 @@ int main()
     CK(hipMemcpy(x, hx.data(), hx.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), hw.size(), hipMemcpyHostToDevice));
     {
         void* o16; CK(hipMalloc(&o16, MMAX * N * 2));
-        EpiDequant<ASQ_F16, false, false, false> e16{o16, N, 1e-4f, nullptr, nullptr, nullptr, 0, true};
+        EpiDequant<ASQ_F16, false, false, false> e16{o16, N, nullptr, nullptr, nullptr, nullptr, 1e-4f, 0, true};
         blk_timeline(x, w, e16, 4096, N, K, "4096^3 f16 epilogue");
         blk_timeline(x, w, e16, 256, N, K, "M=256 f16 epilogue");
         EpiI32 e32{out, N, true};
