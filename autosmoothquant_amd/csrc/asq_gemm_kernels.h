@@ -227,9 +227,31 @@ template <int DT, bool HAS_ROW, bool HAS_COL, bool HAS_BIAS> struct EpiDequant {
     }
 
     // 4 finished outputs in their storage encoding: v4i of fp32 bit patterns, or uint2 of 4 x 16-bit
+    // two outputs per instruction (v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations as one(), pairwise)
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    __device__ __forceinline__ v2f_ two(int acc0, int acc1, v2f_ sc, float sr, v2f_ b) const
+    {
+        const v2f_ a = {(float)acc0, (float)acc1};
+        v2f_ v;
+        if (order == ASQ_EPI_SCALE_FIRST) {
+            v = (HAS_ROW ? sc * sr : sc) * a;
+        } else {
+            v = a * sc;
+            if constexpr (HAS_ROW) v = v * sr;
+        }
+        if constexpr (HAS_BIAS) v = v + b;
+        return v;
+    }
+
     __device__ __forceinline__ auto pack(const v4i &a, float sr, const v4f &sc, const v4f &b) const
     {
         using E = ElemT<DT>;
+        if constexpr (DT == ASQ_F16) {  // v_cvt_pk_f16_f32: two conversions and the pack in one instruction
+            typedef _Float16 v2h_ __attribute__((ext_vector_type(2)));
+            v2f_ lo = two(a[0], a[1], (v2f_){sc[0], sc[1]}, sr, (v2f_){b[0], b[1]}), hi = two(a[2], a[3], (v2f_){sc[2], sc[3]}, sr, (v2f_){b[2], b[3]});
+            asm("" : "+v"(lo), "+v"(hi));  // opaque: keeps fptrunc(fmul) from becoming one v_fma_mix (a single rounding; see f32_to_f16_bits)
+            return (v2u){__builtin_bit_cast(uint32_t, __builtin_convertvector(lo, v2h_)), __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, v2h_))};
+        }
         const float v0 = one(a[0], sc[0], sr, b[0]), v1 = one(a[1], sc[1], sr, b[1]);
         const float v2 = one(a[2], sc[2], sr, b[2]), v3 = one(a[3], sc[3], sr, b[3]);
         if constexpr (DT == ASQ_F32) {
