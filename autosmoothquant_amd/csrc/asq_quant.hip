@@ -5,6 +5,7 @@
 // per-token scale).  The reference spends >= 37 B/element on the same work (abs, max, div,
 // cast, div, round, clamp, cast as separate ATen launches).
 #include "asq_common.h"
+#include <type_traits>
 
 namespace asq {
 
@@ -37,8 +38,15 @@ template <int DT, class Q> __device__ __forceinline__ void quant_vec(const v4i &
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             uint32_t w = (uint32_t)v[i];
-            r[2 * i] = q(ElemT<DT>::load((uint16_t)(w & 0xFFFF)));
-            r[2 * i + 1] = q(ElemT<DT>::load((uint16_t)(w >> 16)));
+            const float lo = ElemT<DT>::load((uint16_t)(w & 0xFFFF)), hi = ElemT<DT>::load((uint16_t)(w >> 16));
+            if constexpr (std::is_same<Q, QRowFast>::value) {  // the row division on both halves at once (v_pk_mul_f32 / v_pk_fma_f32)
+                const auto t = q.div2((QRowFast::v2f_){lo, hi});
+                r[2 * i] = quant_i8(t[0]);
+                r[2 * i + 1] = quant_i8(t[1]);
+            } else {
+                r[2 * i] = q(lo);
+                r[2 * i + 1] = q(hi);
+            }
         }
         o[0] = pack4(r[0], r[1], r[2], r[3]);
         o[1] = pack4(r[4], r[5], r[6], r[7]);
