@@ -463,6 +463,9 @@ def main():
         mods, xs = make_layer_workload(spec, device, seed=1234 if rank == 0 else 99 + rank, dtype=tdt, fuse_norm=args.fuse_norm, fuse_qkv=args.fuse_qkv)
         nlayers = len(mods)
         spec = LLAMA7B_SPEC
+        if args.fuse_norm:
+            for l in mods:
+                l.defer_residual = True    # as the default line's fused_n1 block: residual adds inside asq_add_norm_quantize
         step = lambda: run_layers(mods, xs)
     else:
         mods, xs = make_workload(spec, M, device, seed=1234 if rank == 0 else 99 + rank, dtype=tdt)
