@@ -147,6 +147,9 @@ struct EpiI32 {
     // the functor a block works with: split-K slab `split` of [M, Ncols] int32, group `grp` of a grouped launch.
     // One by-value expression (no conditionally modified copy: that ended up in scratch memory).
     __device__ __forceinline__ EpiI32 rebased(int, int split, int64_t M, int64_t Ncols) const { return EpiI32{out + (int64_t)split * M * Ncols, N, vec_ok}; }
+    // the same epilogue for the sub-problem that starts at output column n0 (host side; n0 % 256 == 0 keeps every alignment)
+    static constexpr bool kColView = true;
+    EpiI32 col_view(int64_t n0) const { return EpiI32{out + n0, N, vec_ok}; }
     __device__ __forceinline__ float row(int64_t) const { return 1.0f; }
     __device__ __forceinline__ void cols(int64_t, int64_t, v4f &, v4f &) const {}
     __device__ __forceinline__ void store4(int64_t m, int64_t n, const v4i &a, float, const v4f &, const v4f &, int64_t Ncols) const
@@ -187,6 +190,11 @@ template <int DT, bool HAS_ROW, bool HAS_COL, bool HAS_BIAS> struct EpiDequant {
                           s_group ? s_group[grp] : s_scalar, order, vec_ok};
     }
     __device__ __forceinline__ float row(int64_t m) const { return HAS_ROW ? s_row[m] : 1.0f; }
+    static constexpr bool kColView = true;
+    EpiDequant col_view(int64_t n0) const  // host side: the sub-problem starting at output column n0 (n0 % 256 == 0)
+    {
+        return EpiDequant{(char *)out + n0 * kOutBytes, N, s_row, s_col ? s_col + n0 : s_col, bias ? bias + n0 : bias, s_group, s_scalar, order, vec_ok};
+    }
 
     __device__ __forceinline__ void cols(int64_t n, int64_t Ncols, v4f &sc, v4f &b) const
     {
@@ -303,6 +311,11 @@ template <int DT> struct EpiDequantQ {
     int order, act, qmode;
     bool vec_ok;
     __device__ __forceinline__ EpiDequantQ rebased(int, int, int64_t, int64_t) const { return *this; }
+    static constexpr bool kColView = true;
+    EpiDequantQ col_view(int64_t n0) const
+    {
+        return EpiDequantQ{out + n0, N, s_row, s_col ? s_col + n0 : s_col, bias ? bias + n0 : bias, s_scalar, quant_scale, order, act, qmode, vec_ok};
+    }
     __device__ __forceinline__ float row(int64_t m) const { return s_row ? s_row[m] : 1.0f; }
     __device__ __forceinline__ void cols(int64_t n, int64_t Ncols, v4f &sc, v4f &b) const
     {
@@ -581,7 +594,7 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
             v4i v = *(lds_v4i)(uintptr_t)(stage + i * 1024 + lane * 16);
             if ((lane >> 3) & 1) v = (v4i){v[2], v[3], v[0], v[1]};  // odd rows were staged with their 8-byte halves flipped
             const int64_t m = mw0 + row, n = nw0 + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
-            if (m < M && n < N) store16_policy<POL>(outb + (m * N + n) * 2, v);
+            if (m < M && n < N) store16_policy<POL>(outb + (m * epi.N + n) * 2, v);  // (epi.N: the row stride; N bounds the columns of this launch)
         }
     } else {
 #pragma unroll
@@ -606,7 +619,7 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
                 const int row = 4 * i + (lane >> 4);
                 const v4i v = *(lds_v4i)(uintptr_t)(stage + i * 1024 + lane * 16);
                 const int64_t m = mw0 + 64 * h + row, n = nw0 + (((lane & 15) ^ (row & 15)) << 2);
-                if (m < M && n < N) store16_policy<POL>(outb + (m * N + n) * 4, v);
+                if (m < M && n < N) store16_policy<POL>(outb + (m * epi.N + n) * 4, v);
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
@@ -850,9 +863,42 @@ template <class Epi> int launch_skinny(const int8_t *x, const int8_t *w, int64_t
 #undef ASQ_SK
 }
 
+// Tail peel (hybrid of data-parallel tiles and a split-K'd remainder).  A tile grid that is a few tiles over a multiple of 256 pays a whole
+// extra wave for them (1536 x 11008: 258 tiles -> 90 us against 51 us for the 172 tiles of 1024 rows).  When the last wave would be < 3/8 full and <= 24 tiles cover it, the
+// last `c` tile columns (all of the remainder and a little more) become their own launch: 256-row tiles, K split 4-8 ways into int32 slabs + the
+// reduce pass, ~16 us regardless of the shape, and the main launch is left with <= 256 * waves tiles.  Needs the caller's workspace.
+struct TailPeel {
+    int64_t n_main = 0;  // columns [0, n_main) stay with the main launch; 0 = no peel
+    int ksplit = 1;
+    size_t ws_bytes = 0;
+};
+static inline TailPeel plan_tail_peel(GemmKernel kern, int64_t M, int64_t N, int64_t K)
+{
+    TailPeel p;
+    // 256-row kernels only: the remainder launch (slabs + reduce) costs ~18 us whatever the shape; the extra wave of the 128-row kernel
+    // costs about the same at K = 4096 (768 x 11008: 51.4 -> 49.7 us), that of the 256-row kernels 35-45 us
+    if (kern != KERN_P8 && kern != KERN_P4) return p;
+    static const bool disabled = getenv("ASQ_NO_TAIL") != nullptr;  // development / A-B aid
+    if (disabled || forced_kernel() >= 0 || forced_ksplit() > 0 || N % 4 != 0 || K < 4096) return p;  // (a short K loop makes the extra wave cheap and the slabs dear)
+    const int64_t rows = 256, tm = (M + rows - 1) / rows, tn = (N + 255) / 256, tiles = tm * tn;
+    const int64_t full = tiles / 256, r = tiles % 256;
+    if (full < 1 || r == 0 || r > 96) return p;
+    const int64_t c = (r + tm - 1) / tm, tm256 = (M + 255) / 256, nt = K / 128;
+    if (c >= tn || tm256 * c > 24) return p;  // measured: 6-24 remainder tiles gain 3-15 %, 36 (1536 x 12288: 66 MB of slabs) lose 2 %
+    int64_t ks = nt / 4 < 8 ? nt / 4 : 8;     // >= 4 K-tiles per split; <= 192 blocks
+    if (ks < 4) return p;
+    p.n_main = (tn - c) * 256;
+    p.ksplit = (int)ks;
+    p.ws_bytes = (size_t)ks * (size_t)M * (size_t)(N - p.n_main) * 4;
+    return p;
+}
+
+template <class Epi, class = void> struct HasColView : std::false_type {};
+template <class Epi> struct HasColView<Epi, std::enable_if_t<Epi::kColView>> : std::true_type {};
+
 template <class Epi>
 int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, Epi epi, hipStream_t s, const char *what, void *ws = nullptr,
-                size_t ws_bytes = 0, const int *goffs = nullptr, int ngroups = 0)
+                size_t ws_bytes = 0, const int *goffs = nullptr, int ngroups = 0, int peel_role = 0 /* 0 top level, 1 main part, 2+ remainder with that K split */)
 {
     if (M == 0 || N == 0) return ASQ_OK;
     if (goffs != nullptr) {  // grouped: tiled kernel only; grid = host-side upper bound on the number of tiles
@@ -870,7 +916,17 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
         return asq_after_launch(s, what);
     }
     constexpr bool kInt = Epi::Mma::kIsInt;
-    GemmKernel kern = pick_kernel(x, w, M, N, K);
+    GemmKernel kern = peel_role >= 2 ? KERN_P8 : pick_kernel(x, w, M, N, K);
+    if constexpr (kInt && HasColView<Epi>::value) {
+        if (peel_role == 0 && ws != nullptr && (((uintptr_t)ws) & 15) == 0 && (N * Epi::kOutBytes) % 16 == 0) {
+            const TailPeel tp = plan_tail_peel(kern, M, N, K);
+            if (tp.n_main > 0 && tp.ws_bytes <= ws_bytes) {
+                const int rc = launch_gemm(x, w, M, tp.n_main, K, epi, s, what, ws, ws_bytes, nullptr, 0, 1);
+                if (rc) return rc;
+                return launch_gemm(x, w + tp.n_main * K, M, N - tp.n_main, K, epi.col_view(tp.n_main), s, what, ws, ws_bytes, nullptr, 0, tp.ksplit);
+            }
+        }
+    }
     constexpr bool kP4 = kInt && Epi::kOutBytes == 2;  // the 4-wave kernel: int8 operands, 2-byte outputs (its row epilogue; the int32 / int8-out
                                                        // epilogues next to 256 accumulator registers would spill)
     if (kern == KERN_P4 && !kP4) kern = KERN_P8;
@@ -889,7 +945,7 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
     if (kern == KERN_P8) {
         const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
         ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
-        const int ksplit = (kInt && ws != nullptr && (((uintptr_t)ws) & 15) == 0) ? pick_ksplit(tm * tn, K, M, N, ws_bytes) : 1;
+        const int ksplit = peel_role >= 2 ? peel_role : (kInt && ws != nullptr && (((uintptr_t)ws) & 15) == 0) ? pick_ksplit(tm * tn, K, M, N, ws_bytes) : 1;
         if constexpr (kInt) if (ksplit > 1) {
             // pass 1: int32 partial slabs; pass 2: reduce + the caller's epilogue
             EpiI32 slab{(int32_t *)ws, N, true};

@@ -105,7 +105,7 @@ __device__ __forceinline__ void p4_epilogue_rows(const Epi &epi, Get get, int64_
             v4i v = *(lds_v4i)(uintptr_t)(img + i * 1024 + lane * 16);
             if (p >> 3) v = (v4i){v[2], v[3], v[0], v[1]};
             const int64_t m = mw0 + im * 32 + row, n = nw0 + ((p ^ (row & 15)) << 3);
-            if (m < M && n < N) *(v4i *)(outb + (m * N + n) * 2) = v;
+            if (m < M && n < N) *(v4i *)(outb + (m * epi.N + n) * 2) = v;
         }
     }
 }
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256, 1) gemm_i8_p4(const int8_t *__restrict__ 
     __builtin_amdgcn_s_barrier();
     const int64_t mw0 = m0 + wm * 128, nw0 = n0 + wn * 128;
     static_assert(Epi::kOutBytes == 2, "gemm_i8_p4: 2-byte outputs (launch_gemm sends the other epilogues to p8)");
-    const bool staged = ((((uintptr_t)epi.out) & 15) == 0) && ((N * Epi::kOutBytes) % 16 == 0);
+    const bool staged = ((((uintptr_t)epi.out) & 15) == 0) && (((N | epi.N) * Epi::kOutBytes) % 16 == 0);  // N: this launch's column bound, epi.N: the row stride
     if (staged) {
         p4_epilogue_rows(epi, [&](int in, int im) -> const v16i & { return acc[in][im]; }, mw0, nw0, lane, M, N, lds0 + wave * 16384);
     } else {  // unaligned output / ragged row pitch: direct stores in the matrix-core layout, two 128 x 64 halves

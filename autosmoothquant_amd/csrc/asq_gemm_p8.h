@@ -415,7 +415,7 @@ if constexpr (MMA::kIsInt) {
     // accumulator tile (in = n-half, im = 2*m-half + j) -> rows m0 + wm*128 + 32*im, cols n0 + wn*64 + 32*in
     auto get = [&](int in, int im) -> const acc_t & { return acc[im >> 1][in][im & 1]; };
     bool staged = false;
-    if constexpr (Epi::kOutBytes >= 2) staged = ((((uintptr_t)epi.out) & 15) == 0) && ((N * Epi::kOutBytes) % 16 == 0);
+    if constexpr (Epi::kOutBytes >= 2) staged = ((((uintptr_t)epi.out) & 15) == 0) && (((N | epi.N) * Epi::kOutBytes) % 16 == 0);  // N: this launch's column bound, epi.N: the row stride
     if (staged) {
         if constexpr (Epi::kOutBytes >= 2) {
             P8_BAR();  // every wave's ring reads are done and every wave's (dead) DMAs have landed: the ring becomes staging space

@@ -201,7 +201,7 @@ if constexpr (MMA::kIsInt) {
     // accumulator tile (in = n-half, im = j) -> rows m0 + wm*64 + 32*im, cols n0 + wn*64 + 32*in
     auto get = [&](int in, int im) -> const acc_t & { return acc[in][im]; };
     bool staged = false;
-    if constexpr (Epi::kOutBytes >= 2) staged = ((((uintptr_t)epi.out) & 15) == 0) && ((N * Epi::kOutBytes) % 16 == 0);
+    if constexpr (Epi::kOutBytes >= 2) staged = ((((uintptr_t)epi.out) & 15) == 0) && (((N | epi.N) * Epi::kOutBytes) % 16 == 0);  // N: this launch's column bound, epi.N: the row stride
     if (staged) {
         if constexpr (Epi::kOutBytes >= 2) {
             __builtin_amdgcn_s_barrier();  // all ring reads done, all (dead) DMAs landed: the ring becomes staging space

@@ -497,3 +497,44 @@ def test_forward_workspace_cache_streams_growth_and_graph_replay(dev):
     g.replay()
     torch.cuda.synchronize()
     assert np.array_equal(t_out(yg), want_g)
+
+
+@pytest.mark.parametrize("shape", [(1536, 11008, 4096), (4352, 4096, 4096), (1536, 11000, 4096), (3072, 11008, 8192)], ids=lambda s: "x".join(map(str, s)))
+def test_tail_peel_launches(shape, dev):
+    """Tile grids a few tiles over a multiple of 256 run as a main launch + a split-K'd column remainder (launch_gemm's tail peel): int32
+    accumulators against the oracle, every epilogue operand on the peeled columns (s_col / bias offsets, per-token rows, int8-out), and
+    bit-equality with the un-peeled launch (no workspace -> no peel)."""
+    from autosmoothquant_amd import ops, _lib as L
+    M, N, K = shape
+    lib = L.lib()
+    assert lib.asq_gemm_kernel_name(M, N, K).endswith(b"+tail") and lib.asq_gemm_workspace_bytes(M, N, K) > 0
+    xq = detrng.int8_uniform(901, M, (M, K))
+    w = detrng.int8_uniform(902, N, (N, K))
+    s_row = (np.abs(detrng.normal(903, 0, (M,))) * 0.01 + 1e-3).astype(np.float32)
+    s_col = (np.abs(detrng.normal(903, 1, (N,))) * 0.01 + 1e-3).astype(np.float32)
+    bias = detrng.normal(903, 2, (N,)).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    txq, tw, tr, tc, tb = d(xq), d(w), d(s_row), d(s_col), d(bias)
+    acc = torch.empty((M, N), dtype=torch.int32, device=dev)
+    ops.gemm_i8_i32(txq, tw, acc)
+    # un-peeled reference launches straight through the C-ABI with no workspace
+    st = torch.cuda.current_stream().cuda_stream
+    acc0 = torch.empty_like(acc)
+    L.check(lib.asq_gemm_i8_i32(txq.data_ptr(), tw.data_ptr(), acc0.data_ptr(), M, N, K, None, 0, st), "plain")
+    assert torch.equal(acc, acc0)
+    # sampled rows against the oracle (all columns, so every tile column incl. the peeled ones is covered)
+    rows = np.unique(np.concatenate([np.arange(0, M, 61), [M - 1]]))
+    assert np.array_equal(acc.cpu().numpy()[rows], O.igemm(xq[rows], w))
+    for dt in ("f16", "bf16", "f32"):
+        got = ops.linear_w8a8(txq, tw, TDT[dt], 1.0, tr, tc, tb)
+        out0 = torch.empty_like(got)
+        L.check(lib.asq_linear_w8a8(txq.data_ptr(), tw.data_ptr(), out0.data_ptr(), {"f32": L.ASQ_F32, "f16": L.ASQ_F16, "bf16": L.ASQ_BF16}[dt], M, N, K, 1.0,
+                                    tr.data_ptr(), tc.data_ptr(), tb.data_ptr(), L.ASQ_EPI_SCALE_FIRST, None, 0, st), "plain")
+        assert torch.equal(got, out0), dt
+        rows = np.arange(0, M, 131)
+        ref = O.dequant_epilogue(acc.cpu().numpy()[rows], s_col, s_row[rows], bias, dt, "scale_first")
+        assert np.array_equal(t_out(got)[rows], ref), dt
+    q = ops.linear_w8a8_q8(txq, tw, torch.float16, 0.0007, None, None, tb, "relu", "per-tensor-div", 0.31)
+    y = ops.linear_w8a8(txq, tw, torch.float16, 0.0007, None, None, tb)
+    want, _ = ops.quantize_act(torch.relu(y), "per-tensor-div", 0.31)
+    assert torch.equal(q, want)
