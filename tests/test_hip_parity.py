@@ -233,6 +233,30 @@ def test_quantize_act_vs_oracle(dt, shape, dev):
     assert np.array_equal(xq.cpu().numpy(), O.act_quant_div(x, dt, np.float32(0.7312)))
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+def test_per_tensor_div_quantiser_whole_domain(dt, dev):
+    """per-tensor-div (`x / quant_scale` in x's dtype, then round / clamp: linear.py:289-292) without a per-element IEEE division: every
+    16-bit input pattern (zeros, subnormals, +-inf, NaN, bf16 values beyond 2^60 that must take the plain division) against scales that put
+    the quotients on and around half-integers, plus scales outside the fast range; fp32: 2^22 random bit patterns + the same edge values."""
+    from autosmoothquant_amd import ops
+    if dt == "f32":
+        rng = np.random.default_rng(11)
+        x = rng.integers(0, 2 ** 32, size=1 << 22, dtype=np.uint64).astype(np.uint32).view(np.float32).copy()
+        x[:8] = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 3e38, -2.0 ** 60], np.float32)
+        x[8:4104] = (np.arange(4096, dtype=np.float32) - 2048.0) * np.float32(0.25)
+    elif dt == "f16":
+        x = np.arange(65536, dtype=np.uint32).astype(np.uint16).view(np.float16).astype(np.float32)
+    else:
+        x = (np.arange(65536, dtype=np.uint32) << 16).view(np.float32).copy()
+    x = x.reshape(-1, 1024)
+    xt = t_in(x, dt, dev)
+    for qs in (0.5, 0.7312, 1.0, 3.0, 1e-3, 0.0999755859375, 517.0, 2.0 ** -61, 2.0 ** 61, 1e-30, 6e4):
+        with np.errstate(all="ignore"):
+            want = O.act_quant_div(x, dt, np.float32(qs))
+        got, _ = ops.quantize_act(xt, "per-tensor-div", qs)
+        assert np.array_equal(got.cpu().numpy(), want), (dt, qs)
+
+
 @pytest.mark.parametrize("out_dt", ["f32", "f16", "bf16"])
 @pytest.mark.parametrize("order", ["scale_first", "acc_first"])
 @pytest.mark.parametrize("shape", [(67, 50, 96), (256, 384, 256), (130, 258, 128)])
