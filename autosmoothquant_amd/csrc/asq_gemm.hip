@@ -15,6 +15,7 @@ int forced_kernel()
             else if (!strcmp(e, "p8")) v = KERN_P8;
             else if (!strcmp(e, "p8h")) v = KERN_P8H;
             else if (!strcmp(e, "p4")) v = KERN_P4;
+            else if (!strcmp(e, "p8q")) v = KERN_P8Q;
             else if (!strcmp(e, "skinny")) v = KERN_SKINNY;
         }
     }
@@ -43,6 +44,7 @@ extern "C" const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K)
     case KERN_P8: return "p8";
     case KERN_P8H: return "p8h";
     case KERN_P4: return "p4";
+    case KERN_P8Q: return "p8q";
     case KERN_SKINNY: return "skinny";
     default: return "generic";
     }
@@ -54,9 +56,10 @@ extern "C" size_t asq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K)
     const GemmKernel kern = pick_kernel(nullptr, nullptr, M, N, K);
     const TailPeel tp = plan_tail_peel(kern, M, N, K);
     if (tp.n_main > 0) return tp.ws_bytes;  // (a launch with >= 256 tiles never splits K as a whole)
-    if (kern != KERN_P8 && kern != KERN_P8H) return 0;
-    const int s = kern == KERN_P8 ? pick_ksplit(((M + 255) / 256) * ((N + 255) / 256), K, M, N, (size_t)-1)
-                                  : pick_ksplit_p8h(((M + 127) / 128) * ((N + 255) / 256), K, M, N, (size_t)-1);
+    if (kern != KERN_P8 && kern != KERN_P8H && kern != KERN_P8Q) return 0;
+    const int s = kern == KERN_P8    ? pick_ksplit(((M + 255) / 256) * ((N + 255) / 256), K, M, N, (size_t)-1)
+                  : kern == KERN_P8H ? pick_ksplit_p8h(((M + 127) / 128) * ((N + 255) / 256), K, M, N, (size_t)-1)
+                                     : pick_ksplit_p8q(((M + 127) / 128) * ((N + 127) / 128), K, M, N, (size_t)-1);
     return s > 1 ? (size_t)s * (size_t)M * (size_t)N * 4 : 0;
 }
 

@@ -544,7 +544,7 @@ template <int NTM, int POL = 0, class Epi, class Get>  // NTM = 32-row token til
 __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, int64_t M, int64_t N, unsigned stage)
 {
     constexpr int EB = Epi::kOutBytes;
-    static_assert(NTM == 2 || NTM == 4, "wave tile of 64 or 128 rows");
+    static_assert(NTM == 1 || NTM == 2 || NTM == 4, "wave tile of 32, 64 or 128 rows");
     static_assert(EB == 2 || EB == 4, "staged epilogue: 2- or 4-byte outputs");
     typedef __attribute__((address_space(3))) v4i *lds_v4i;
     typedef __attribute__((address_space(3))) v2u *lds_u2;
@@ -597,11 +597,12 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
             if (m < M && n < N) store16_policy<POL>(outb + (m * epi.N + n) * 2, v);  // (epi.N: the row stride; N bounds the columns of this launch)
         }
     } else {
+        constexpr int TP = NTM >= 2 ? 2 : 1;  // 32-row tiles per staging pass (4-byte outputs: 64 rows fill the wave's 16 KiB)
 #pragma unroll
-        for (int h = 0; h < NTM / 2; ++h) {
+        for (int h = 0; h < NTM / TP; ++h) {
 #pragma unroll
-            for (int imh = 0; imh < 2; ++imh) {
-                const int im = 2 * h + imh, row = 32 * imh + ml;
+            for (int imh = 0; imh < TP; ++imh) {
+                const int im = TP * h + imh, row = 32 * imh + ml;
 #pragma unroll
                 for (int in = 0; in < 2; ++in) {
                     const typename Epi::Mma::acc_t a = get(in, im);
@@ -615,10 +616,10 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 8 * TP; ++i) {
                 const int row = 4 * i + (lane >> 4);
                 const v4i v = *(lds_v4i)(uintptr_t)(stage + i * 1024 + lane * 16);
-                const int64_t m = mw0 + 64 * h + row, n = nw0 + (((lane & 15) ^ (row & 15)) << 2);
+                const int64_t m = mw0 + 32 * TP * h + row, n = nw0 + (((lane & 15) ^ (row & 15)) << 2);
                 if (m < M && n < N) store16_policy<POL>(outb + (m * epi.N + n) * 4, v);
             }
             __builtin_amdgcn_wave_barrier();
@@ -689,6 +690,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 #include "asq_gemm_p8.h"
 #include "asq_gemm_p4.h"
 #include "asq_gemm_p8h.h"
+#include "asq_gemm_p8q.h"
 #include "asq_gemm_skinny.h"
 
 namespace asq {
@@ -733,7 +735,7 @@ __global__ void __launch_bounds__(256) splitk_reduce(const int32_t *__restrict__
 // ---------------------------------------------------------------------------------
 // dispatch + launch
 // ---------------------------------------------------------------------------------
-enum GemmKernel { KERN_GENERIC = 0, KERN_SKINNY = 1, KERN_P8 = 2, KERN_P8H = 3, KERN_P4 = 4 };
+enum GemmKernel { KERN_GENERIC = 0, KERN_SKINNY = 1, KERN_P8 = 2, KERN_P8H = 3, KERN_P4 = 4, KERN_P8Q = 5 };
 
 int forced_kernel();  // env ASQ_GEMM_KERNEL=generic|skinny|p8|p8h (development / A-B aid), asq_gemm.hip
 
@@ -743,7 +745,7 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
     const bool tiled_ok = aligned && K % 128 == 0 && K >= 128 && K <= (1 << 24);
     const int f = forced_kernel();
     if (f == KERN_GENERIC) return KERN_GENERIC;
-    if (tiled_ok && (f == KERN_P8 || f == KERN_P8H || f == KERN_P4)) return (GemmKernel)f;
+    if (tiled_ok && (f == KERN_P8 || f == KERN_P8H || f == KERN_P4 || f == KERN_P8Q)) return (GemmKernel)f;
     if (tiled_ok && M <= 1024 && M * K < (1ll << 32) && f == KERN_SKINNY) return KERN_SKINNY;  // (32-bit row offsets in the DMA address)
     if (tiled_ok && f < 0) {
         // measured crossover (tools/cold_grid.sh: 48..256 rows x 8 LLaMA/OPT/Mixtral weight shapes, weights rotated
@@ -755,7 +757,14 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
         // 128-row tiles when the 256-row tiling cannot fill 256 CUs (or wastes half a tile row).  Measured
         // (tools/ksplit_sweep.sh): p8h is ~14 % slower per op on a full chip but wins up to 1.45x below ~144 tiles
         const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-        if (t256 < 144) return KERN_P8H;
+        if (t256 < 144) {
+            // 128 x 128 tiles (p8q) where the 128 x 256 tiling has at most 128 tiles, i.e. leaves half of the CUs without one: twice the
+            // tiles at twice the L2->LDS bytes per MFMA.  Measured (tools/kbench.py, forced vs default, 48 shapes): -3 ... -22 % for 32..128
+            // p8h tiles (512 x 4096 x 4096: 22.8 -> 17.7 us), +15 ... +35 % above 128; with a long K and few tiles p8h's deeper split-K wins.
+            const int64_t th = ((M + 127) / 128) * ((N + 255) / 256);
+            if (th >= 32 && th <= 128 && (K < 8192 || th >= 80)) return KERN_P8Q;
+            return KERN_P8H;
+        }
         // 256 x 256 tiles, 8 waves (p8) or 4 waves with 128 x 128 per wave (p4: fewer LDS bytes per MFMA, but a one-wave-per-SIMD epilogue
         // that costs 6k cycles more per tile).  Measured (ASQ_GEMM_KERNEL=p8|p4 tools/kbench.py, alternating, profiles/r2_p4_experiment.md):
         // p4 wins once the K loop is >= 64 K-tiles long -- 4096x4096x8192 +1.7 %, x11008 (LLaMA down_proj) +1.9 %, x16384 +3.0 %,
@@ -793,6 +802,24 @@ static inline int pick_ksplit(int64_t tiles, int64_t K, int64_t M, int64_t N, si
     if (tiles >= 118) return 1;
     int64_t s = (176 + tiles / 2) / tiles;
     if (s > nt / 4) s = nt / 4;              // >= 4 K-tiles (512 k) per split: keep the pipeline efficient
+    while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ws_bytes) --s;
+    return s < 1 ? 1 : (int)s;
+}
+
+// K splits for the 128 x 128 kernel: fill ~224 CUs, >= 8 K-tiles per split
+static inline int pick_ksplit_p8q(int64_t tiles, int64_t K, int64_t M, int64_t N, size_t ws_bytes)
+{
+    if (N % 4 != 0) return 1;
+    const int64_t nt = K / 128;
+    const int forced = forced_ksplit();
+    int64_t s;
+    if (forced > 0) {
+        s = forced > nt ? nt : forced;
+    } else {
+        if (tiles >= 160) return 1;
+        s = 224 / tiles;
+        if (s > nt / 8) s = nt / 8;
+    }
     while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ws_bytes) --s;
     return s < 1 ? 1 : (int)s;
 }
@@ -993,6 +1020,31 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
             return (int)e;
         }
         hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8H_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, epi);
+    } else if (kern == KERN_P8Q) {
+        const int64_t tm = (M + 127) / 128, tn = (N + 127) / 128;
+        ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
+        const int ksplit = (kInt && ws != nullptr && (((uintptr_t)ws) & 15) == 0) ? pick_ksplit_p8q(tm * tn, K, M, N, ws_bytes) : 1;
+        if constexpr (kInt) if (ksplit > 1) {
+            EpiI32 slab{(int32_t *)ws, N, true};
+            auto kfn = gemm_i8_p8q<EpiI32>;
+            hipError_t e = ensure_dynamic_lds((const void *)kfn, P8Q_LDS_BYTES);
+            if (e != hipSuccess) {
+                asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+                return (int)e;
+            }
+            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn * ksplit)), dim3(512), P8Q_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, ksplit, slab);
+            int64_t blocks = (M * (N / 4) + 255) / 256;
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL((splitk_reduce<Epi>), dim3((unsigned)blocks), dim3(256), 0, s, (const int32_t *)ws, ksplit, M, N, epi);
+            return asq_after_launch(s, what);
+        }
+        auto kfn = gemm_i8_p8q<Epi>;
+        hipError_t e = ensure_dynamic_lds((const void *)kfn, P8Q_LDS_BYTES);
+        if (e != hipSuccess) {
+            asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+            return (int)e;
+        }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8Q_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, epi);
     } else if (kern == KERN_SKINNY) {
         const int rc = launch_skinny(x, w, M, N, K, epi, s);
         if (rc) return rc;

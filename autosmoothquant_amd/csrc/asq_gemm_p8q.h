@@ -1,0 +1,171 @@
+// "p8q": 128(m) x 128(n) x 128(k) member of the p8 family for the mid-size row counts whose 128 x 256 tiling (p8h) leaves half the
+// chip idle -- 1024 x 4096: 128 tiles of p8h on 256 CUs; here 256.  Same machinery as p8h (LDS-DMA in full 128-B rows, XOR-swizzled
+// 16 KiB units, counted vmcnt, two wave groups staggered by one barrier, staged coalescing epilogue, split-K slabs) with ONE phase per
+// K-tile:
+//
+//   8 waves = 4 (m) x 2 (n); wave (wm, wn) owns out[wm*32 .. +32][wn*64 .. +64] = 2 MFMA tiles (n-halves) of 32 x 32.
+//   K-tile image = 2 units {X: tile rows 0..127, W: tile columns 0..127} = 32 KiB; ring of FOUR K-tiles (128 KiB): tile t+3 is fetched
+//   while tile t is consumed -- three K-tiles (~2000 cycles) of lead, what p8 / p8h have with their longer K-tiles.
+//   Per K-tile and wave: 4 DMAs (X[0] X[1] W[0] W[1] of tile t+3), 12 fragment reads (4 X + 8 W), 8 MFMAs.
+//   Counted wait: tile t+1 must have landed before its fragments are read; tiles t+2, t+3 (8 DMAs) may stay in flight -> vmcnt(8).
+//   Unlike p8 / p8h (two wave groups that alternate load and MFMA segments between barriers) the fragments are double-buffered in
+//   registers: tile t+1 is read from LDS while the matrix cores work on tile t, ONE barrier per K-tile.  (With the p8h structure the load
+//   segment -- 4 DMAs + 12 ds_reads + their latency -- is as long as two MFMA segments of this small tile: 1100 cycles per K-tile measured.)
+//
+// The small tile pays for its parallelism: 32 KiB of DMA and 12 KiB of fragment reads per wave for 8 MFMAs per K-tile are twice p8's
+// bytes per MFMA, so its K loop runs at the vector-memory path's pace, not the matrix cores' (see DESIGN 4 for the measured cycles).
+// The dispatcher uses it only where p8h would leave CUs idle.
+#pragma once
+#include <type_traits>
+
+namespace asq {
+
+constexpr int P8Q_STAGE = 2 * P8_UNIT;        // 32 KiB
+constexpr int P8Q_LDS_BYTES = 4 * P8Q_STAGE;  // 128 KiB
+
+template <class Epi>
+__global__ void __launch_bounds__(512, 2) gemm_i8_p8q(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
+                                                      int tiles_m, int tiles_n, int ksplit, Epi epi_in)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // logical id = split * ntiles + tile (see p8); groups of GM tile rows share their X panels in L2
+    constexpr int GM = 8;
+    const int nwg = tiles_m * tiles_n;
+    const int lid = xcd_remap(blockIdx.x, nwg * ksplit);
+    const int split = lid / nwg, id = lid - split * nwg;
+    const Epi epi = epi_in.rebased(0, split, M, N);
+    const int per_group = GM * tiles_n;
+    const int group = id / per_group, in_group = id - group * per_group;
+    const int first_m = group * GM;
+    const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int tile_m = first_m + in_group % gm, tile_n = in_group / gm;
+    const int64_t m0 = (int64_t)tile_m * 128, n0 = (int64_t)tile_n * 128;
+
+    const int nt_all = (int)(K / 128);
+    const int kt0 = (int)((int64_t)nt_all * split / ksplit), kt1 = (int)((int64_t)nt_all * (split + 1) / ksplit);
+    const int8_t *const xbase = uniform_ptr(x + m0 * K + (int64_t)kt0 * 128);
+    const int8_t *const wbase = uniform_ptr(w + n0 * K + (int64_t)kt0 * 128);
+    const int64_t mrem = M - m0 - 1, nrem = N - n0 - 1;  // last valid local row
+    unsigned voff[2][2];  // [kind: X, W][i]; this wave fills row-groups 2*wave, 2*wave+1 (8 rows each) of both units
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ru = (wave * 2 + i) * 8 + (lane >> 3);                       // row within the unit, 0..127
+        const unsigned cb = (unsigned)(((lane & 7) ^ ((ru >> 1) & 7)) * 16);  // swizzled source chunk
+        const int64_t rx = ru < mrem ? ru : mrem, rw = ru < nrem ? ru : nrem;
+        voff[0][i] = (unsigned)(rx * K) + cb;
+        voff[1][i] = (unsigned)(rw * K) + cb;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
+    const unsigned dma_dst = lds0 + wave * 2048;  // + stage*P8Q_STAGE + kind*P8_UNIT + i*1024
+
+    // fragment read addresses: one VGPR per (stage, k-substep) and operand; the rest is an immediate
+    const int frow = lane & 31, sw = (frow >> 1) & 7, hi = lane >> 5;
+    unsigned xb[4][4], wbp[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const unsigned off = lds0 + frow * 128 + ((((ks * 2 + hi) ^ sw)) << 4) + s * P8Q_STAGE;
+            xb[s][ks] = off + wm * 32 * 128;             // X unit: this wave's 32 rows
+            wbp[s][ks] = off + P8_UNIT + wn * 64 * 128;  // W unit: this wave's 64 rows (+ in * 4096)
+            asm volatile("" : "+v"(xb[s][ks]), "+v"(wbp[s][ks]));
+        }
+
+    using MMA = typename Epi::Mma;
+    using acc_t = typename MMA::acc_t;
+    acc_t acc[2];  // [n-half]
+    acc[0] = (acc_t){0};
+    acc[1] = (acc_t){0};
+
+    const int nt = kt1 - kt0;  // K-tiles of this block (>= 1)
+    const int klast = (nt - 1) * 128;
+
+    auto issue = [&](int stage, int k0) {
+        p8_dma16(xbase + k0, voff[0][0], dma_dst + stage * P8Q_STAGE);
+        p8_dma16(xbase + k0, voff[0][1], dma_dst + stage * P8Q_STAGE + 1024);
+        p8_dma16(wbase + k0, voff[1][0], dma_dst + stage * P8Q_STAGE + P8_UNIT);
+        p8_dma16(wbase + k0, voff[1][1], dma_dst + stage * P8Q_STAGE + P8_UNIT + 1024);
+    };
+
+    // ---- prologue: K-tiles 0, 1, 2 (clamped); fragments of tile 0
+    issue(0, 0);
+    issue(1, 128 < klast ? 128 : klast);
+    issue(2, 256 < klast ? 256 : klast);
+    P8_WAIT_VM(8);
+    __builtin_amdgcn_s_barrier();
+    v4i xf[2][4], wf[2][2][4];  // [register set = K-tile parity]
+    auto read_frags = [&](auto stage_tag, auto set_tag) {
+        constexpr int S = decltype(stage_tag)::value, R = decltype(set_tag)::value;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xf[R][ks] = *(p8_lds_v4i)(uintptr_t)(xb[S][ks]);
+#pragma unroll
+        for (int in = 0; in < 2; ++in)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wf[R][in][ks] = *(p8_lds_v4i)(uintptr_t)(wbp[S][ks] + in * 4096);
+    };
+    read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+
+    // One barrier per K-tile.  Iteration t: re-fill the slot of tile t-1 with tile t+3 (its fragments were read during iteration t-2 and
+    // waited for in iteration t-1, before the barrier every wave has passed to get here); make sure tile t+1 has landed and the
+    // fragments of tile t are in registers; barrier; read the fragments of tile t+1 into the other register set WHILE the matrix
+    // cores work on tile t.
+    auto ktile = [&](auto stage_tag, int t) {
+        constexpr int S = decltype(stage_tag)::value, NS = (S + 3) % 4, S1 = (S + 1) % 4, R = S & 1;
+        int kn = (t + 3) * 128;  // SALU
+        kn = kn < klast ? kn : klast;
+        issue(NS, kn);
+        P8_WAIT_VM(8);   // tile t+1 has landed (this wave's part); tiles t+2, t+3 stay in flight
+        P8_WAIT_LGKM0();  // fragments of tile t
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(std::integral_constant<int, S1>{}, std::integral_constant<int, R ^ 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (MMA::kIsInt) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int in = 0; in < 2; ++in) acc[in] = MMA::mma(wf[R][in][ks], xf[R][ks], acc[in]);
+        } else {  // fp8: K = 64 block-scaled instruction over two consecutive fragments
+#pragma unroll
+            for (int kp = 0; kp < 4; kp += 2)
+#pragma unroll
+                for (int in = 0; in < 2; ++in) acc[in] = MMA::mma2(wf[R][in][kp], wf[R][in][kp + 1], xf[R][kp], xf[R][kp + 1], acc[in]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    int t = 0;
+    for (; t + 3 < nt; t += 4) {
+        ktile(std::integral_constant<int, 0>{}, t);
+        ktile(std::integral_constant<int, 1>{}, t + 1);
+        ktile(std::integral_constant<int, 2>{}, t + 2);
+        ktile(std::integral_constant<int, 3>{}, t + 3);
+    }
+    if (t < nt) ktile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nt) ktile(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 < nt) ktile(std::integral_constant<int, 2>{}, t + 2);
+
+    P8_WAIT_VM(0);    // drain the dead prefetches
+    P8_WAIT_LGKM0();  // ... and the fragment reads past the last tile, before LDS becomes staging space
+
+    // accumulator tile (in = n-half, im = 0) -> rows m0 + wm*32, cols n0 + wn*64 + 32*in
+    auto get = [&](int in, int) -> const acc_t & { return acc[in]; };
+    bool staged = false;
+    if constexpr (Epi::kOutBytes >= 2) staged = ((((uintptr_t)epi.out) & 15) == 0) && (((N | epi.N) * Epi::kOutBytes) % 16 == 0);
+    if (staged) {
+        if constexpr (Epi::kOutBytes >= 2) {
+            __builtin_amdgcn_s_barrier();  // all ring reads done, all (dead) DMAs landed: the ring becomes staging space
+            epilogue_wave_staged<1>(epi, get, m0 + wm * 32, n0 + wn * 64, lane, M, N, lds0 + wave * 16384);
+        }
+    } else {
+        epilogue_wave<2, 1>(epi, get, [](int im) { return im * 32; }, m0 + wm * 32, n0 + wn * 64, lane, M, N);
+    }
+}
+
+}  // namespace asq

@@ -212,9 +212,10 @@ int asq_linear_fp8_grouped(const uint8_t *xq, const uint8_t *w, void *out, int o
 int asq_cast_e5m2(const void *x, int x_dtype, uint8_t *xq, int64_t n, void *stream);
 
 /* ---- introspection for tests / bench: which GEMM kernel the dispatcher picks for a shape (aligned operands):
- * "skinny" (weight streaming), "p8h" (128x256x128 tiles), "p8" (256x256x128 tiles, 8 waves), "p4" (the same tile, 4 waves: long K) or "generic";
+ * "skinny" (weight streaming), "p8q" (128x128x128 tiles), "p8h" (128x256x128 tiles), "p8" (256x256x128 tiles, 8 waves), "p4" (the same tile,
+ * 4 waves: long K) or "generic";
  * "p8+tail" / "p4+tail" when a workspace makes the call a main launch + a split-K'd column remainder.
- * Development overrides (read once per process): ASQ_GEMM_KERNEL=generic|skinny|p8h|p8|p4, ASQ_KSPLIT=n, ASQ_SK_NT=1|2, ASQ_NO_TAIL=1. */
+ * Development overrides (read once per process): ASQ_GEMM_KERNEL=generic|skinny|p8q|p8h|p8|p4, ASQ_KSPLIT=n, ASQ_SK_NT=1|2, ASQ_NO_TAIL=1. */
 const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K);
 
 #ifdef __cplusplus

@@ -446,7 +446,7 @@ def test_forward_outputs_never_require_grad(dev):
             assert not y.requires_grad and y.grad_fn is None
 
 
-@pytest.mark.parametrize("kern,ksplit", [("p8", 3), ("p8", 1), ("p4", 0), ("p8h", 4), ("skinny", 0), ("generic", 0)])
+@pytest.mark.parametrize("kern,ksplit", [("p8", 3), ("p8", 1), ("p4", 0), ("p8h", 4), ("p8q", 0), ("p8q", 3), ("skinny", 0), ("generic", 0)])
 def test_forced_kernel_paths_in_a_child_process(kern, ksplit, dev):
     """Dispatcher branches the shape heuristics never pick by themselves -- notably split-K on the 256-row kernel (pick_kernel hands
     p8 only >= 144 tiles, pick_ksplit splits only < 118) and the opt-in 4-wave kernel p4 -- forced through ASQ_GEMM_KERNEL / ASQ_KSPLIT (read once per process,
