@@ -39,7 +39,7 @@ using namespace asq;
 extern "C" const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K)
 {
     const GemmKernel kern = pick_kernel(nullptr, nullptr, M, N, K);
-    if (plan_tail_peel(kern, M, N, K).n_main > 0) return kern == KERN_P8 ? "p8+tail" : "p4+tail";  // when a workspace is passed
+    if (plan_tail_peel(kern, M, N, K).n_main > 0) return kern == KERN_P8 ? "p8+tail" : "p4+tail";
     switch (kern) {
     case KERN_P8: return "p8";
     case KERN_P8H: return "p8h";
@@ -55,7 +55,7 @@ extern "C" size_t asq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K)
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const GemmKernel kern = pick_kernel(nullptr, nullptr, M, N, K);
     const TailPeel tp = plan_tail_peel(kern, M, N, K);
-    if (tp.n_main > 0) return tp.ws_bytes;  // (a launch with >= 256 tiles never splits K as a whole)
+    if (tp.n_main > 0) return tp.ws_bytes;  // (a launch with >= 256 tiles never splits K as a whole; its peeled remainder may)
     if (kern != KERN_P8 && kern != KERN_P8H && kern != KERN_P8Q) return 0;
     const int s = kern == KERN_P8    ? pick_ksplit(((M + 255) / 256) * ((N + 255) / 256), K, M, N, (size_t)-1)
                   : kern == KERN_P8H ? pick_ksplit_p8h(((M + 127) / 128) * ((N + 255) / 256), K, M, N, (size_t)-1)

@@ -890,33 +890,31 @@ template <class Epi> int launch_skinny(const int8_t *x, const int8_t *w, int64_t
 #undef ASQ_SK
 }
 
-// Tail peel (hybrid of data-parallel tiles and a split-K'd remainder).  A tile grid that is a few tiles over a multiple of 256 pays a whole
-// extra wave for them (1536 x 11008: 258 tiles -> 90 us against 51 us for the 172 tiles of 1024 rows).  When the last wave would be < 3/8 full and <= 24 tiles cover it, the
-// last `c` tile columns (all of the remainder and a little more) become their own launch: 256-row tiles, K split 4-8 ways into int32 slabs + the
-// reduce pass, ~16 us regardless of the shape, and the main launch is left with <= 256 * waves tiles.  Needs the caller's workspace.
+// Tail peel (hybrid of data-parallel tiles and a finer-grained remainder).  A tile grid that is a few tiles over a multiple of 256 pays a whole
+// extra wave for them (1536 x 11008: 258 tiles -> 90 us against 51 us for the 172 tiles of 1024 rows).  When the last wave would be < 3/8 full
+// and <= 24 tiles cover it, the last `c` tile columns (all of the remainder and a little more) become their own launch of 128 x 128 tiles (p8q:
+// four times as many blocks, with its usual K split when the caller's workspace allows one) and the main launch is left with <= 256 * waves tiles.
 struct TailPeel {
     int64_t n_main = 0;  // columns [0, n_main) stay with the main launch; 0 = no peel
-    int ksplit = 1;
-    size_t ws_bytes = 0;
+    size_t ws_bytes = 0; // workspace that lets the remainder split K (optional)
 };
 static inline TailPeel plan_tail_peel(GemmKernel kern, int64_t M, int64_t N, int64_t K)
 {
     TailPeel p;
-    // 256-row kernels only: the remainder launch (slabs + reduce) costs ~18 us whatever the shape; the extra wave of the 128-row kernel
-    // costs about the same at K = 4096 (768 x 11008: 51.4 -> 49.7 us), that of the 256-row kernels 35-45 us
+    // 256-row kernels only: the remainder launch costs ~13-18 us whatever the shape; the extra wave of the 128-row kernel costs about the
+    // same at K = 4096 (768 x 11008: 51.4 -> 49.7 us), that of the 256-row kernels 35-45 us
     if (kern != KERN_P8 && kern != KERN_P4) return p;
     static const bool disabled = getenv("ASQ_NO_TAIL") != nullptr;  // development / A-B aid
-    if (disabled || forced_kernel() >= 0 || forced_ksplit() > 0 || N % 4 != 0 || K < 4096) return p;  // (a short K loop makes the extra wave cheap and the slabs dear)
-    const int64_t rows = 256, tm = (M + rows - 1) / rows, tn = (N + 255) / 256, tiles = tm * tn;
+    if (disabled || forced_kernel() >= 0 || forced_ksplit() > 0 || N % 4 != 0 || K < 4096) return p;  // (a short K loop makes the extra wave cheap)
+    const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, tiles = tm * tn;
     const int64_t full = tiles / 256, r = tiles % 256;
     if (full < 1 || r == 0 || r > 96) return p;
-    const int64_t c = (r + tm - 1) / tm, tm256 = (M + 255) / 256, nt = K / 128;
-    if (c >= tn || tm256 * c > 24) return p;  // measured: 6-24 remainder tiles gain 3-15 %, 36 (1536 x 12288: 66 MB of slabs) lose 2 %
-    int64_t ks = nt / 4 < 8 ? nt / 4 : 8;     // >= 4 K-tiles per split; <= 192 blocks
-    if (ks < 4) return p;
+    const int64_t c = (r + tm - 1) / tm;
+    if (c >= tn || tm * c > 24) return p;  // measured: 6-24 remainder tiles gain 3-19 %, 36 (1536 x 12288) lose 2 %
     p.n_main = (tn - c) * 256;
-    p.ksplit = (int)ks;
-    p.ws_bytes = (size_t)ks * (size_t)M * (size_t)(N - p.n_main) * 4;
+    const int64_t n_rem = N - p.n_main;
+    const int ks = pick_ksplit_p8q(((M + 127) / 128) * ((n_rem + 127) / 128), K, M, n_rem, (size_t)-1);
+    p.ws_bytes = ks > 1 ? (size_t)ks * (size_t)M * (size_t)n_rem * 4 : 0;
     return p;
 }
 
@@ -925,7 +923,7 @@ template <class Epi> struct HasColView<Epi, std::enable_if_t<Epi::kColView>> : s
 
 template <class Epi>
 int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, Epi epi, hipStream_t s, const char *what, void *ws = nullptr,
-                size_t ws_bytes = 0, const int *goffs = nullptr, int ngroups = 0, int peel_role = 0 /* 0 top level, 1 main part, 2+ remainder with that K split */)
+                size_t ws_bytes = 0, const int *goffs = nullptr, int ngroups = 0, int peel_role = 0 /* 0 top level, 1 main part, 2 remainder (128 x 128 tiles) */)
 {
     if (M == 0 || N == 0) return ASQ_OK;
     if (goffs != nullptr) {  // grouped: tiled kernel only; grid = host-side upper bound on the number of tiles
@@ -943,14 +941,14 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
         return asq_after_launch(s, what);
     }
     constexpr bool kInt = Epi::Mma::kIsInt;
-    GemmKernel kern = peel_role >= 2 ? KERN_P8 : pick_kernel(x, w, M, N, K);
+    GemmKernel kern = peel_role == 2 ? KERN_P8Q : pick_kernel(x, w, M, N, K);
     if constexpr (kInt && HasColView<Epi>::value) {
-        if (peel_role == 0 && ws != nullptr && (((uintptr_t)ws) & 15) == 0 && (N * Epi::kOutBytes) % 16 == 0) {
+        if (peel_role == 0 && (N * Epi::kOutBytes) % 16 == 0) {
             const TailPeel tp = plan_tail_peel(kern, M, N, K);
-            if (tp.n_main > 0 && tp.ws_bytes <= ws_bytes) {
-                const int rc = launch_gemm(x, w, M, tp.n_main, K, epi, s, what, ws, ws_bytes, nullptr, 0, 1);
+            if (tp.n_main > 0) {
+                const int rc = launch_gemm(x, w, M, tp.n_main, K, epi, s, what, nullptr, 0, nullptr, 0, 1);
                 if (rc) return rc;
-                return launch_gemm(x, w + tp.n_main * K, M, N - tp.n_main, K, epi.col_view(tp.n_main), s, what, ws, ws_bytes, nullptr, 0, tp.ksplit);
+                return launch_gemm(x, w + tp.n_main * K, M, N - tp.n_main, K, epi.col_view(tp.n_main), s, what, ws, ws_bytes, nullptr, 0, 2);
             }
         }
     }
@@ -972,7 +970,7 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
     if (kern == KERN_P8) {
         const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
         ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
-        const int ksplit = peel_role >= 2 ? peel_role : (kInt && ws != nullptr && (((uintptr_t)ws) & 15) == 0) ? pick_ksplit(tm * tn, K, M, N, ws_bytes) : 1;
+        const int ksplit = (kInt && ws != nullptr && (((uintptr_t)ws) & 15) == 0) ? pick_ksplit(tm * tn, K, M, N, ws_bytes) : 1;
         if constexpr (kInt) if (ksplit > 1) {
             // pass 1: int32 partial slabs; pass 2: reduce + the caller's epilogue
             EpiI32 slab{(int32_t *)ws, N, true};

@@ -70,8 +70,8 @@ int asq_gemm_i8_i32(const int8_t *x, const int8_t *w, int32_t *out,
 /* Optional scratch for the GEMM entry points.  When the M x N tile grid cannot fill the 256 CUs
  * (e.g. OPT-13B fc2 at 256 rows: 20 tiles) the dispatcher splits K across CUs, writes exact int32
  * partial slabs into `workspace` and reduces them in a second launch that applies the epilogue.
- * The same workspace serves the tail peel: a grid a few tiles over a multiple of 256 (1536 x 11008: 258 tiles) runs its last tile columns as
- * a split-K launch of their own instead of paying a second wave for two tiles (-3 ... -15 % of the call).
+ * Independently of the workspace, a grid a few tiles over a multiple of 256 (1536 x 11008: 258 tiles) runs its last tile columns as a launch of
+ * 128 x 128 tiles instead of paying a second wave for two tiles (-3 ... -19 % of the call); with a workspace that remainder may split K too.
  * asq_gemm_workspace_bytes() returns the size that enables this for a shape (0 = never needed).
  * workspace may be NULL / smaller (then fewer or no K splits are used); it must be 16-B aligned and
  * not shared by concurrently running calls. */
@@ -214,7 +214,7 @@ int asq_cast_e5m2(const void *x, int x_dtype, uint8_t *xq, int64_t n, void *stre
 /* ---- introspection for tests / bench: which GEMM kernel the dispatcher picks for a shape (aligned operands):
  * "skinny" (weight streaming), "p8q" (128x128x128 tiles), "p8h" (128x256x128 tiles), "p8" (256x256x128 tiles, 8 waves), "p4" (the same tile,
  * 4 waves: long K) or "generic";
- * "p8+tail" / "p4+tail" when a workspace makes the call a main launch + a split-K'd column remainder.
+ * "p8+tail" / "p4+tail" when the call runs as a main launch + a column remainder of 128 x 128 tiles.
  * Development overrides (read once per process): ASQ_GEMM_KERNEL=generic|skinny|p8q|p8h|p8|p4, ASQ_KSPLIT=n, ASQ_SK_NT=1|2, ASQ_NO_TAIL=1. */
 const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K);
 

@@ -54,8 +54,8 @@ def test_argument_errors_without_gpu():
     assert h.asq_gemm_kernel_name(2048, 4096, 4096) == b"p8h"            # 128 tiles of 256 rows
     assert h.asq_gemm_kernel_name(2048, 5120, 5120) == b"p8"             # 160 tiles: the 256-row kernel is the more efficient one
     assert h.asq_gemm_kernel_name(4, 4096, 4095) == b"generic"
-    # tail peel: 6 x 43 = 258 tiles of 256 rows -> 252 in the main launch + one tile column (6 tiles) split 8 ways along K
-    assert h.asq_gemm_kernel_name(1536, 11008, 4096) == b"p8+tail" and h.asq_gemm_workspace_bytes(1536, 11008, 4096) == 8 * 1536 * 256 * 4
+    # tail peel: 6 x 43 = 258 tiles of 256 rows -> 252 in the main launch + one tile column as 12 x 2 tiles of 128 x 128
+    assert h.asq_gemm_kernel_name(1536, 11008, 4096) == b"p8+tail" and h.asq_gemm_workspace_bytes(1536, 11008, 4096) == 4 * 1536 * 256 * 4   # 24 tiles of 128 x 128, 4 K splits
     assert h.asq_gemm_kernel_name(3072, 11008, 8192) == b"p4+tail"
     assert h.asq_gemm_kernel_name(1536, 12288, 4096) == b"p8" and h.asq_gemm_workspace_bytes(1536, 12288, 4096) == 0   # 36 remainder tiles: the slabs would cost more
     assert h.asq_gemm_kernel_name(2048, 11008, 4096) == b"p8"            # last wave 88 / 256 full: left alone

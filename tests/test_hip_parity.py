@@ -523,37 +523,78 @@ def test_forward_workspace_cache_streams_growth_and_graph_replay(dev):
     assert np.array_equal(t_out(yg), want_g)
 
 
-@pytest.mark.parametrize("shape", [(1536, 11008, 4096), (4352, 4096, 4096), (1536, 11000, 4096), (3072, 11008, 8192)], ids=lambda s: "x".join(map(str, s)))
-def test_tail_peel_launches(shape, dev):
-    """Tile grids a few tiles over a multiple of 256 run as a main launch + a split-K'd column remainder (launch_gemm's tail peel): int32
-    accumulators against the oracle, every epilogue operand on the peeled columns (s_col / bias offsets, per-token rows, int8-out), and
-    bit-equality with the un-peeled launch (no workspace -> no peel)."""
-    from autosmoothquant_amd import ops, _lib as L
+TAIL_SHAPES = [(1536, 11008, 4096), (4352, 4096, 4096), (1536, 11000, 4096), (3072, 11008, 8192)]
+
+
+def _tail_case(shape, dev):
     M, N, K = shape
-    lib = L.lib()
-    assert lib.asq_gemm_kernel_name(M, N, K).endswith(b"+tail") and lib.asq_gemm_workspace_bytes(M, N, K) > 0
     xq = detrng.int8_uniform(901, M, (M, K))
     w = detrng.int8_uniform(902, N, (N, K))
     s_row = (np.abs(detrng.normal(903, 0, (M,))) * 0.01 + 1e-3).astype(np.float32)
     s_col = (np.abs(detrng.normal(903, 1, (N,))) * 0.01 + 1e-3).astype(np.float32)
     bias = detrng.normal(903, 2, (N,)).astype(np.float32)
+    return xq, w, s_row, s_col, bias
+
+
+def _tail_digests(shape, dev):
+    """sha256 of the int32 accumulators and of the fp16 / bf16 / fp32 fused outputs (all operands) of one shape"""
+    from autosmoothquant_amd import ops
+    M, N, K = shape
+    xq, w, s_row, s_col, bias = _tail_case(shape, dev)
+    d = lambda a: torch.from_numpy(a).to(dev)
+    txq, tw = d(xq), d(w)
+    acc = torch.empty((M, N), dtype=torch.int32, device=dev)
+    ops.gemm_i8_i32(txq, tw, acc)
+    out = [_sha(acc.cpu().numpy())]
+    for dt in ("f16", "bf16", "f32"):
+        y = ops.linear_w8a8(txq, tw, TDT[dt], 1.0, d(s_row), d(s_col), d(bias))
+        out.append(_sha(y.view(torch.int16 if dt != "f32" else torch.int32).cpu().numpy()))
+    return out
+
+
+def test_tail_peel_equals_the_plain_launch(dev):
+    """The peeled launches (main + 128 x 128-tile remainder) produce the same bytes as the plain launch of a process started with
+    ASQ_NO_TAIL=1 (the switch is read once per process, hence the child)."""
+    import subprocess
+    import sys
+    code = ("import sys, json, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_hip_parity as T\n"
+            "from autosmoothquant_amd import _lib\n"
+            "assert not any(_lib.lib().asq_gemm_kernel_name(*s).endswith(b'+tail') for s in T.TAIL_SHAPES)\n"
+            "print('DIGESTS ' + json.dumps([T._tail_digests(s, torch.device('cuda:0')) for s in T.TAIL_SHAPES]))\n") % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, ASQ_NO_TAIL="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import json
+    plain = json.loads([l for l in r.stdout.splitlines() if l.startswith("DIGESTS ")][-1][8:])
+    assert plain == [_tail_digests(s, dev) for s in TAIL_SHAPES]
+
+
+@pytest.mark.parametrize("shape", TAIL_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_tail_peel_launches(shape, dev):
+    """Tile grids a few tiles over a multiple of 256 run as a main launch + a column remainder of 128 x 128 tiles (launch_gemm's tail peel): int32
+    accumulators against the oracle on sampled rows over ALL columns, every epilogue operand on the peeled columns (s_col / bias offsets,
+    per-token rows, int8-out), with and without a workspace (the remainder then runs unsplit)."""
+    from autosmoothquant_amd import ops, _lib as L
+    M, N, K = shape
+    lib = L.lib()
+    assert lib.asq_gemm_kernel_name(M, N, K).endswith(b"+tail")
+    xq, w, s_row, s_col, bias = _tail_case(shape, dev)
     d = lambda a: torch.from_numpy(a).to(dev)
     txq, tw, tr, tc, tb = d(xq), d(w), d(s_row), d(s_col), d(bias)
     acc = torch.empty((M, N), dtype=torch.int32, device=dev)
     ops.gemm_i8_i32(txq, tw, acc)
-    # un-peeled reference launches straight through the C-ABI with no workspace
     st = torch.cuda.current_stream().cuda_stream
     acc0 = torch.empty_like(acc)
-    L.check(lib.asq_gemm_i8_i32(txq.data_ptr(), tw.data_ptr(), acc0.data_ptr(), M, N, K, None, 0, st), "plain")
+    L.check(lib.asq_gemm_i8_i32(txq.data_ptr(), tw.data_ptr(), acc0.data_ptr(), M, N, K, None, 0, st), "no workspace")
     assert torch.equal(acc, acc0)
-    # sampled rows against the oracle (all columns, so every tile column incl. the peeled ones is covered)
     rows = np.unique(np.concatenate([np.arange(0, M, 61), [M - 1]]))
     assert np.array_equal(acc.cpu().numpy()[rows], O.igemm(xq[rows], w))
     for dt in ("f16", "bf16", "f32"):
         got = ops.linear_w8a8(txq, tw, TDT[dt], 1.0, tr, tc, tb)
         out0 = torch.empty_like(got)
         L.check(lib.asq_linear_w8a8(txq.data_ptr(), tw.data_ptr(), out0.data_ptr(), {"f32": L.ASQ_F32, "f16": L.ASQ_F16, "bf16": L.ASQ_BF16}[dt], M, N, K, 1.0,
-                                    tr.data_ptr(), tc.data_ptr(), tb.data_ptr(), L.ASQ_EPI_SCALE_FIRST, None, 0, st), "plain")
+                                    tr.data_ptr(), tc.data_ptr(), tb.data_ptr(), L.ASQ_EPI_SCALE_FIRST, None, 0, st), "no workspace")
         assert torch.equal(got, out0), dt
         rows = np.arange(0, M, 131)
         ref = O.dequant_epilogue(acc.cpu().numpy()[rows], s_col, s_row[rows], bias, dt, "scale_first")
