@@ -39,7 +39,7 @@ using namespace asq;
 extern "C" const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K)
 {
     const GemmKernel kern = pick_kernel(nullptr, nullptr, M, N, K);
-    if (plan_tail_peel(kern, M, N, K).n_main > 0) return kern == KERN_P8 ? "p8+tail" : "p4+tail";
+    if (plan_tail_peel(kern, M, N, K).n_main > 0) return kern == KERN_P8 ? "p8+tail" : kern == KERN_P8H ? "p8h+tail" : "p4+tail";
     switch (kern) {
     case KERN_P8: return "p8";
     case KERN_P8H: return "p8h";

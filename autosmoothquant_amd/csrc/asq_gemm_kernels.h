@@ -892,7 +892,7 @@ template <class Epi> int launch_skinny(const int8_t *x, const int8_t *w, int64_t
 
 // Tail peel (hybrid of data-parallel tiles and a finer-grained remainder).  A tile grid that is a few tiles over a multiple of 256 pays a whole
 // extra wave for them (1536 x 11008: 258 tiles -> 90 us against 51 us for the 172 tiles of 1024 rows).  When the last wave would be < 3/8 full
-// and <= 24 tiles cover it, the last `c` tile columns (all of the remainder and a little more) become their own launch of 128 x 128 tiles (p8q:
+// and <= 48 tiles cover it, the last `c` tile columns (all of the remainder and a little more) become their own launch of 128 x 128 tiles (p8q:
 // four times as many blocks, with its usual K split when the caller's workspace allows one) and the main launch is left with <= 256 * waves tiles.
 struct TailPeel {
     int64_t n_main = 0;  // columns [0, n_main) stay with the main launch; 0 = no peel
@@ -901,16 +901,16 @@ struct TailPeel {
 static inline TailPeel plan_tail_peel(GemmKernel kern, int64_t M, int64_t N, int64_t K)
 {
     TailPeel p;
-    // 256-row kernels only: the remainder launch costs ~13-18 us whatever the shape; the extra wave of the 128-row kernel costs about the
-    // same at K = 4096 (768 x 11008: 51.4 -> 49.7 us), that of the 256-row kernels 35-45 us
-    if (kern != KERN_P8 && kern != KERN_P4) return p;
+    // (the remainder launch costs ~13 us at K = 4096; the extra wave it replaces ~20 us for the 128-row kernel, 35-45 us for the 256-row ones)
+    if (kern != KERN_P8 && kern != KERN_P4 && kern != KERN_P8H) return p;
     static const bool disabled = getenv("ASQ_NO_TAIL") != nullptr;  // development / A-B aid
     if (disabled || forced_kernel() >= 0 || forced_ksplit() > 0 || N % 4 != 0 || K < 4096) return p;  // (a short K loop makes the extra wave cheap)
-    const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256, tiles = tm * tn;
+    const int64_t rows = kern == KERN_P8H ? 128 : 256;
+    const int64_t tm = (M + rows - 1) / rows, tn = (N + 255) / 256, tiles = tm * tn;
     const int64_t full = tiles / 256, r = tiles % 256;
     if (full < 1 || r == 0 || r > 96) return p;
     const int64_t c = (r + tm - 1) / tm;
-    if (c >= tn || tm * c > 24) return p;  // measured: 6-24 remainder tiles gain 3-19 %, 36 (1536 x 12288) lose 2 %
+    if (c >= tn || ((M + 255) / 256) * c > 48) return p;  // measured: remainders of 6-36 256 x 256 tiles' worth gain 3-19 %, 88 (2048 x 11008) nothing
     p.n_main = (tn - c) * 256;
     const int64_t n_rem = N - p.n_main;
     const int ks = pick_ksplit_p8q(((M + 127) / 128) * ((n_rem + 127) / 128), K, M, n_rem, (size_t)-1);

@@ -57,7 +57,8 @@ def test_argument_errors_without_gpu():
     # tail peel: 6 x 43 = 258 tiles of 256 rows -> 252 in the main launch + one tile column as 12 x 2 tiles of 128 x 128
     assert h.asq_gemm_kernel_name(1536, 11008, 4096) == b"p8+tail" and h.asq_gemm_workspace_bytes(1536, 11008, 4096) == 4 * 1536 * 256 * 4   # 24 tiles of 128 x 128, 4 K splits
     assert h.asq_gemm_kernel_name(3072, 11008, 8192) == b"p4+tail"
-    assert h.asq_gemm_kernel_name(1536, 12288, 4096) == b"p8" and h.asq_gemm_workspace_bytes(1536, 12288, 4096) == 0   # 36 remainder tiles: the slabs would cost more
+    assert h.asq_gemm_kernel_name(1536, 12288, 4096) == b"p8+tail"       # 288 tiles: 6 tile columns (36 tiles' worth) as 128 x 128 tiles
+    assert h.asq_gemm_kernel_name(768, 11008, 4096) == b"p8h+tail"       # 258 tiles of 128 rows
     assert h.asq_gemm_kernel_name(2048, 11008, 4096) == b"p8"            # last wave 88 / 256 full: left alone
     assert h.asq_gemm_kernel_name(65536, 11008, 4096) == b"p8"           # cfg3: 43 full waves
 
