@@ -77,7 +77,7 @@ def test_fp8_codec_exhaustive_f16(dev):
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
 @pytest.mark.parametrize("shape", [(9, 40, 96), (130, 264, 384), (33, 100, 200), (256, 512, 1024),
                                    (4, 256, 512), (32, 1000, 1152), (64, 48, 128), (100, 520, 384),   # weight-streaming kernel (K % 128 == 0, few rows)
-                                   (640, 768, 256), (2900, 3300, 128)])                               # p8h / p8 tiled kernels
+                                   (640, 768, 256), (2900, 3300, 128), (640, 4100, 256), (384, 4096, 640)])   # p8h / p8 / p8q tiled kernels
 def test_fp8_linear_vs_oracle(dt, shape, dev):
     from autosmoothquant_amd import ops
     M, N, K = shape

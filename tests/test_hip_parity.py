@@ -146,6 +146,8 @@ GEMM_SHAPES = [
     (100, 11008, 4096), (160, 4096, 11008), (256, 512, 6144),
     # >= 144 tiles of 256 x 256: the 256-row kernel (p8); everything tiled above runs p8h
     (3072, 3072, 256), (2900, 3300, 384),
+    # 32..128 tiles of 128 x 256: the 128 x 128 kernel (p8q), ragged M / N, 1..5 K-tiles (every ring phase), with its K split
+    (384, 4096, 128), (400, 4100, 256), (1000, 2052, 384), (450, 7000, 512), (640, 5120, 640), (384, 4096, 2048), (256, 11000, 4096),
 ]
 
 
