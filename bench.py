@@ -141,6 +141,14 @@ def make_moe_workload(device, seed, dtype, skew=False):
         aq, srow = ops.quantize_act(a, "per-token")
         return ops.linear_w8a8_grouped(aq, st["w2"], st["offs"], st["s2"], dtype, srow)
 
+    def grouped_fused():   # N1: SiLU(w1 x) * (w3 x) -> int8 in one pass instead of silu, mul and the per-token quantiser
+        xq, _ = ops.quantize_act(st["x"], "per-tensor-round")
+        h1 = ops.linear_w8a8_grouped(xq, st["w1"], st["offs"], st["s1"], dtype)
+        h3 = ops.linear_w8a8_grouped(xq, st["w3"], st["offs"], st["s3"], dtype)
+        aq, srow = ops.silu_mul_quantize(h1, h3, per_token=True)
+        return ops.linear_w8a8_grouped(aq, st["w2"], st["offs"], st["s2"], dtype, srow)
+    st["grouped_fused"] = grouped_fused
+
     s1h, s3h, s2h = st["s1"].tolist(), st["s3"].tolist(), st["s2"].tolist()
 
     def sequential():   # what the reference's Python expert loop amounts to (models/mixtral.py:142-145)
@@ -459,6 +467,15 @@ def main():
             seq_step()
         torch.cuda.synchronize()
         moe_extra = {"sequential_per_expert_ms": round((time.perf_counter() - t0) / 10 * 1e3, 4), "rows_per_expert": st["counts"]}
+        if "grouped_fused" in st:   # the same step with the N1 SiLU*up -> int8 kernel (differs from torch's silu by +-1 int8 at rounding boundaries)
+            for _ in range(5):
+                st["grouped_fused"]()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                st["grouped_fused"]()
+            torch.cuda.synchronize()
+            moe_extra["grouped_fused_silu_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
     elif layer_mode:
         mods, xs = make_layer_workload(spec, device, seed=1234 if rank == 0 else 99 + rank, dtype=tdt, fuse_norm=args.fuse_norm, fuse_qkv=args.fuse_qkv)
         nlayers = len(mods)
