@@ -605,3 +605,8 @@ def test_tail_peel_launches(shape, dev):
     y = ops.linear_w8a8(txq, tw, torch.float16, 0.0007, None, None, tb)
     want, _ = ops.quantize_act(torch.relu(y), "per-tensor-div", 0.31)
     assert torch.equal(q, want)
+    # the one-call forward (quantise + GEMM inside the C-ABI, its own workspace layout) on the same shape
+    xf = (torch.randn(M, K, device=dev) * 20).half()
+    y1 = ops.linear_w8a8_forward(xf, tw, "per-token", 1.0, 0.0007, None, tb)
+    xq2, sr2 = ops.quantize_act(xf, "per-token")
+    assert torch.equal(y1, ops.linear_w8a8(xq2, tw, torch.float16, 0.0007, sr2, None, tb))
