@@ -413,11 +413,12 @@ def test_full_size_fused_forward_matches_unfused(dev):
 
 @pytest.mark.parametrize("counts", [[300, 0, 17, 256, 1, 511], [40, 40], [0, 0, 5], [700]])
 @pytest.mark.parametrize("per_token", [False, True])
-def test_grouped_launch_equals_per_group_calls(counts, per_token, dev):
+@pytest.mark.parametrize("K", [256, 8192])   # (Mixtral w2 has the long K)
+def test_grouped_launch_equals_per_group_calls(counts, per_token, K, dev):
     """Mixtral-style grouped launch (one kernel over all experts, routing offsets on the device) ==
     one asq_linear_w8a8 call per expert, bit for bit; empty and ragged groups included."""
     from autosmoothquant_amd import ops
-    G, N, K = len(counts), 320, 256
+    G, N = len(counts), 320
     M = sum(counts)
     xq = torch.from_numpy(detrng.int8_uniform(140, M + G, (M, K))).to(dev)
     w = torch.from_numpy(detrng.int8_uniform(141, G, (G, N, K))).to(dev)
