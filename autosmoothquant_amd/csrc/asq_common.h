@@ -54,6 +54,18 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f)
     return (uint16_t)(u >> 16);
 }
 
+// two conversions + the pack in one instruction (gfx950 v_cvt_pk_bf16_f32).  The hardware keeps a NaN's sign and payload bits; c10::BFloat16
+// (and f32_to_bf16_bits above) return the canonical 0x7FC0, so NaN lanes are patched.  Equal to the software rounding on all 2^32 inputs.
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2_bits(float lo, float hi)
+{
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 v2b_ __attribute__((ext_vector_type(2)));
+    uint32_t bits = __builtin_bit_cast(uint32_t, __builtin_convertvector((v2f_){lo, hi}, v2b_));
+    if (lo != lo) bits = (bits & 0xFFFF0000u) | 0x7FC0u;
+    if (hi != hi) bits = (bits & 0x0000FFFFu) | 0x7FC00000u;
+    return bits;
+}
+
 __device__ __forceinline__ float f16_bits_to_f32(uint16_t b)
 {
     return __half2float(__ushort_as_half(b));

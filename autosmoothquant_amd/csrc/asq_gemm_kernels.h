@@ -260,6 +260,11 @@ template <int DT, bool HAS_ROW, bool HAS_COL, bool HAS_BIAS> struct EpiDequant {
             asm("" : "+v"(lo), "+v"(hi));  // opaque: keeps fptrunc(fmul) from becoming one v_fma_mix (a single rounding; see f32_to_f16_bits)
             return (v2u){__builtin_bit_cast(uint32_t, __builtin_convertvector(lo, v2h_)), __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, v2h_))};
         }
+        if constexpr (DT == ASQ_BF16) {  // v_cvt_pk_bf16_f32 (RNE, identical to the software rounding on every non-NaN input: tools/ubench/bf16_cvt_check) + canonical NaN
+            v2f_ lo = two(a[0], a[1], (v2f_){sc[0], sc[1]}, sr, (v2f_){b[0], b[1]}), hi = two(a[2], a[3], (v2f_){sc[2], sc[3]}, sr, (v2f_){b[2], b[3]});
+            asm("" : "+v"(lo), "+v"(hi));
+            return (v2u){f32x2_to_bf16x2_bits(lo[0], lo[1]), f32x2_to_bf16x2_bits(hi[0], hi[1])};
+        }
         const float v0 = one(a[0], sc[0], sr, b[0]), v1 = one(a[1], sc[1], sr, b[1]);
         const float v2 = one(a[2], sc[2], sr, b[2]), v3 = one(a[3], sc[3], sr, b[3]);
         if constexpr (DT == ASQ_F32) {
