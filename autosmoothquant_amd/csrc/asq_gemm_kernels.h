@@ -758,16 +758,19 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
         // from L2 once per 16 (or 32) channels, so it wins while the total work N*K*M stays small; wide-N
         // weights (11008x4096, 14336x4096, 20480x5120) stay ahead longer than square or long-K ones
         const double work = (double)N * (double)K * (double)M;
-        if (M <= 256 && work <= (N > 2 * K ? 5.8e9 : 4.0e9)) return KERN_SKINNY;  // (measured up to 256 rows; beyond that the tiled kernels)
+        const int64_t th = ((M + 127) / 128) * ((N + 255) / 256);  // tiles of 128 x 256
+        if (M <= 256 && work <= (N > 2 * K ? 5.8e9 : 4.0e9) && !(M > 160 && th >= 16))
+            return KERN_SKINNY;  // (measured up to 256 rows; with more than 160 rows the 128 x 128 kernel is 5-10 % ahead once it has >= 32 tiles)
         // 128-row tiles when the 256-row tiling cannot fill 256 CUs (or wastes half a tile row).  Measured
         // (tools/ksplit_sweep.sh): p8h is ~14 % slower per op on a full chip but wins up to 1.45x below ~144 tiles
         const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
         if (t256 < 144) {
             // 128 x 128 tiles (p8q) where the 128 x 256 tiling has at most 128 tiles, i.e. leaves half of the CUs without one: twice the
             // tiles at twice the L2->LDS bytes per MFMA.  Measured (tools/kbench.py, forced vs default, 48 shapes): -3 ... -22 % for 32..128
-            // p8h tiles (512 x 4096 x 4096: 22.8 -> 17.7 us), +15 ... +35 % above 128; with a long K and few tiles p8h's deeper split-K wins.
-            const int64_t th = ((M + 127) / 128) * ((N + 255) / 256);
-            if (th >= 32 && th <= 128 && (K < 8192 || th >= 80)) return KERN_P8Q;
+            // p8h tiles (512 x 4096 x 4096: 22.8 -> 17.7 us), +15 ... +35 % above 128.
+            // (with its cost-model K split p8q also wins 5-13 % at 16..32 tiles and a long K -- 128x4096x11008 20.4 -> 19.0 us; between 40 and 80
+            // tiles at K >= 8192 the two are within 4 % either way and p8h keeps them; OPT's K = 20480 stays with p8h's deeper split)
+            if (th >= 16 && th <= 128 && K < 16384 && !(K >= 8192 && th >= 40 && th < 80)) return KERN_P8Q;
             return KERN_P8H;
         }
         // 256 x 256 tiles, 8 waves (p8) or 4 waves with 128 x 128 per wave (p4: fewer LDS bytes per MFMA, but a one-wave-per-SIMD epilogue
@@ -811,19 +814,26 @@ static inline int pick_ksplit(int64_t tiles, int64_t K, int64_t M, int64_t N, si
     return s < 1 ? 1 : (int)s;
 }
 
-// K splits for the 128 x 128 kernel: fill ~224 CUs, >= 8 K-tiles per split
+// K splits for the 128 x 128 kernel, from a small cost model fitted to measurements (us): a block costs 3 + (K-tiles) x (0.40 + 0.20 x the
+// fraction of the 256 CUs that hold a block -- the L2->LDS path is shared), a split launch adds the reduce pass, 5 + S x M x N x 4 B at
+// 3 TB/s.  512x4096x4096: S = 1 (18.0 us measured; S = 2: 21.3); 512x4096x11008: S = 2 (37.3; S = 1: 40.1); 128x4096x11008: S = 7 (21.9).
 static inline int pick_ksplit_p8q(int64_t tiles, int64_t K, int64_t M, int64_t N, size_t ws_bytes)
 {
     if (N % 4 != 0) return 1;
     const int64_t nt = K / 128;
     const int forced = forced_ksplit();
-    int64_t s;
+    int64_t s = 1;
     if (forced > 0) {
         s = forced > nt ? nt : forced;
     } else {
-        if (tiles >= 160) return 1;
-        s = 224 / tiles;
-        if (s > nt / 8) s = nt / 8;
+        double best = 1e30;
+        const int64_t smax = nt / 4 < 16 ? nt / 4 : 16;
+        for (int64_t c = 1; c <= (smax < 1 ? 1 : smax); ++c) {
+            const double blocks = (double)tiles * (double)c, waves = (double)((tiles * c + 255) / 256), fill = blocks < 256.0 ? blocks / 256.0 : 1.0;
+            double t = waves * (3.0 + (double)((nt + c - 1) / c) * (0.40 + 0.20 * fill));
+            if (c > 1) t += 5.0 + (double)c * (double)M * (double)N * 4.0 / 3.0e6;
+            if (t < best) { best = t; s = c; }
+        }
     }
     while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ws_bytes) --s;
     return s < 1 ? 1 : (int)s;
