@@ -759,7 +759,9 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
         // weights (11008x4096, 14336x4096, 20480x5120) stay ahead longer than square or long-K ones
         const double work = (double)N * (double)K * (double)M;
         const int64_t th = ((M + 127) / 128) * ((N + 255) / 256);  // tiles of 128 x 256
-        if (M <= 256 && work <= (N > 2 * K ? 5.8e9 : 4.0e9) && !(M > 160 && th >= 16))
+        // (against the 128 x 128 kernel the square-ish crossover sits lower once there are more than 64 rows: 96x5120x5120 17.1 -> 14.5 us,
+        // 128x5120x5120 19.5 -> 15.5, while 128x4096x4096 stays with the stream, 11.7 vs 15.0)
+        if (M <= 256 && work <= (N > 2 * K ? 5.8e9 : M > 64 ? 2.4e9 : 4.0e9) && !(M > 160 && th >= 16))
             return KERN_SKINNY;  // (measured up to 256 rows; with more than 160 rows the 128 x 128 kernel is 5-10 % ahead once it has >= 32 tiles)
         // 128-row tiles when the 256-row tiling cannot fill 256 CUs (or wastes half a tile row).  Measured
         // (tools/ksplit_sweep.sh): p8h is ~14 % slower per op on a full chip but wins up to 1.45x below ~144 tiles

@@ -43,8 +43,9 @@ def test_argument_errors_without_gpu():
     assert h.asq_gemm_workspace_bytes(32, 4096, 4096) == 0              # skinny path
     assert h.asq_gemm_kernel_name(4096, 4096, 4096) == b"p8"
     assert h.asq_gemm_kernel_name(64, 14336, 4096) == b"skinny"          # decode batch: weight stream
-    assert h.asq_gemm_kernel_name(160, 4096, 4096) == b"skinny"          # 3 m-blocks x 256 channel tiles still fit the chip
-    assert h.asq_gemm_kernel_name(192, 4096, 4096) == b"p8q"             # more than 160 rows and >= 16 tiles of 128 x 256: the 128 x 128 kernel
+    assert h.asq_gemm_kernel_name(128, 4096, 4096) == b"skinny"          # 2 m-blocks x 256 channel tiles: the weight stream (11.7 vs 15.0 us)
+    assert h.asq_gemm_kernel_name(192, 4096, 4096) == b"p8q"             # more rows on >= 16 tiles of 128 x 256: the 128 x 128 kernel
+    assert h.asq_gemm_kernel_name(128, 5120, 5120) == b"p8q"             # above 64 rows the square-ish crossover is at work 2.4e9
     assert h.asq_gemm_kernel_name(320, 4096, 4096) == b"p8q"             # 48 tiles of 128 x 256 would leave most CUs idle: 128 x 128 tiles
     assert h.asq_gemm_kernel_name(1024, 4096, 4096) == b"p8q"            # 128 tiles of 128 x 256 -> 256 of 128 x 128
     assert h.asq_gemm_kernel_name(1280, 4096, 4096) == b"p8h"            # 160 tiles: the bigger tile's L2 traffic per MFMA wins again
