@@ -418,8 +418,15 @@ template <int DT, bool HAS_BIAS, class MMA_ = MmaFp8> struct EpiFp8 {
         }
         if constexpr (DT == ASQ_F32) {
             return __builtin_bit_cast(v4i, (v4f){v[0], v[1], v[2], v[3]});
+        } else if constexpr (DT == ASQ_F16) {  // two conversions + the pack per instruction, as EpiDequant::pack
+            typedef float v2f_ __attribute__((ext_vector_type(2)));
+            typedef _Float16 v2h_ __attribute__((ext_vector_type(2)));
+            v2f_ lo = {v[0], v[1]}, hi = {v[2], v[3]};
+            asm("" : "+v"(lo), "+v"(hi));
+            return (v2u){__builtin_bit_cast(uint32_t, __builtin_convertvector(lo, v2h_)), __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, v2h_))};
         } else {
-            return (v2u){(uint32_t)E::store(v[0]) | ((uint32_t)E::store(v[1]) << 16), (uint32_t)E::store(v[2]) | ((uint32_t)E::store(v[3]) << 16)};
+            (void)sizeof(E);
+            return (v2u){f32x2_to_bf16x2_bits(v[0], v[1]), f32x2_to_bf16x2_bits(v[2], v[3])};
         }
     }
     void *out;
