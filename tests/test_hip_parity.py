@@ -330,7 +330,8 @@ def test_empty_and_degenerate_inputs(dev):
 
 
 # ---- full-size properties (BASELINE.json sizes; the oracle would take minutes) -----------
-@pytest.mark.parametrize("shape", [(4096, 4096, 4096), (2048, 11008, 4096), (2048, 4096, 11008), (256, 5120, 20480)],
+@pytest.mark.parametrize("shape", [(4096, 4096, 4096), (2048, 11008, 4096), (2048, 4096, 11008), (256, 5120, 20480),
+                                   (1024, 4096, 4096), (128, 4096, 11008), (3072, 11008, 4096)],   # 128 x 128 kernel, its split-K, tail peel
                          ids=lambda s: "x".join(map(str, s)))
 def test_full_size_checksums(shape, dev):
     """sum_n acc[m,n] == x[m,:] . (sum_n w[n,:]) and sum_m acc[m,n] == (sum_m x[m,:]) . w[n,:] in exact
