@@ -288,7 +288,7 @@ def test_int8_out_gemms(dev):
     sat_i8(rne(alpha*acc + beta*c)))."""
     from autosmoothquant_amd._CUDA import I8CUGEMM
     g = I8CUGEMM()
-    for (M, N, K) in [(37, 52, 96), (256, 256, 256)]:
+    for (M, N, K) in [(37, 52, 96), (256, 256, 256), (520, 1000, 384), (300, 520, 1152), (2900, 3300, 128)]:   # generic, skinny, p8q, p8h, p8
         x = detrng.int8_uniform(109, M, (M, K))
         w = detrng.int8_uniform(110, N, (N, K))
         b = detrng.int8_uniform(111, N, (N,))
