@@ -37,6 +37,8 @@ SIGNATURES = {
     "asq_linear_fp8": (_int, [_vp, _vp, _int, _vp, _int, _i64, _i64, _i64, _vp, _int, _f32, _f32, _vp, _vp]),
     "asq_linear_fp8_grouped": (_int, [_vp, _vp, _vp, _int, _vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "asq_cast_e5m2": (_int, [_vp, _int, _vp, _i64, _vp]),
+    "asq_quantize_mxfp8": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _vp]),
+    "asq_linear_mxfp8": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _i64, _vp, _vp]),
 }
 
 

@@ -389,6 +389,44 @@ def quantize_act_fp8(x, mode, static_scale=1.0):
     return xq, float(static_scale)
 
 
+def quantize_mxfp8(x):
+    """MX (OCP Microscaling) e4m3 with real block scales -- opt-in extension, see include/asq_hip.h.  x [M,K] f32/f16/bf16, K % 32 == 0
+    -> (codes float8_e4m3fn [M,K], scales uint8 [M,K/32] as E8M0 bytes)."""
+    _dev(x, "x")
+    if x.dtype not in _DT or x.dim() != 2 or x.shape[1] % 32 != 0:
+        raise ValueError("x must be a 2-D float32/float16/bfloat16 tensor whose last dim is a multiple of 32")
+    M, K = x.shape
+    xq = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((M, K // 32), dtype=torch.uint8, device=x.device)
+    with _on(x.device):
+        L.check(L.lib().asq_quantize_mxfp8(x.data_ptr(), _DT[x.dtype], xq.data_ptr(), sc.data_ptr(), M, K, _stream(x)), "asq_quantize_mxfp8")
+    return xq.view(torch.float8_e4m3fn), sc
+
+
+def linear_mxfp8(xq, x_scales, wq, w_scales, out_dtype, bias=None):
+    """out[M,N] = block-scaled e4m3 product of (xq, x_scales) [M,K] and (wq, w_scales) [N,K] (+ bias) on the scaled matrix-core instruction."""
+    for name, t in (("xq", xq), ("x_scales", x_scales), ("wq", wq), ("w_scales", w_scales)):
+        _dev(t, name)
+    if xq.dim() != 2 or wq.dim() != 2 or xq.shape[1] != wq.shape[1] or xq.shape[1] % 64 != 0 or xq.element_size() != 1 or wq.element_size() != 1:
+        raise ValueError("xq [M,K] and wq [N,K] must be 1-byte e4m3 tensors with equal K, K % 64 == 0")
+    M, K = xq.shape
+    N = wq.shape[0]
+    if tuple(x_scales.shape) != (M, K // 32) or tuple(w_scales.shape) != (N, K // 32) or x_scales.dtype != torch.uint8 or w_scales.dtype != torch.uint8:
+        raise ValueError("scales must be uint8 [rows, K/32]")
+    if bias is not None:
+        _dev(bias, "bias")
+        if bias.dtype != torch.float32 or bias.numel() != N:
+            raise ValueError(f"bias must be float32 with {N} elements")
+    out = torch.empty((M, N), dtype=out_dtype, device=xq.device)
+    if M == 0 or N == 0:
+        return out
+    dev = _same_device(xq, x_scales, wq, w_scales, bias)
+    with _on(dev):
+        L.check(L.lib().asq_linear_mxfp8(xq.data_ptr(), x_scales.data_ptr(), wq.data_ptr(), w_scales.data_ptr(), out.data_ptr(), _DT[out_dtype], M, N, K,
+                                         _ptr(bias), _stream(xq)), "asq_linear_mxfp8")
+    return out
+
+
 def cast_e5m2(x):
     """x [M,K] f32/f16/bf16 -> float8_e5m2 [M,K], plain round-to-nearest-even cast (FP8E5M2Linear, linear.py:612)."""
     _dev(x, "x")

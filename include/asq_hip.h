@@ -211,6 +211,17 @@ int asq_linear_fp8_grouped(const uint8_t *xq, const uint8_t *w, void *out, int o
  * restated from its intent: y = e5m2(x) . e5m2(W)^T + bias.) */
 int asq_cast_e5m2(const void *x, int x_dtype, uint8_t *xq, int64_t n, void *stream);
 
+/* ---- MX (OCP Microscaling, MXFP8 E4M3) with real block scales: an accuracy-checked opt-in beyond the reference (the reference's fp8
+ * classes scale per tensor or per token, layers/nn/linear.py:336-644).  32 consecutive k share one E8M0 scale byte (value 2^(byte - 127), 0xFF = NaN):
+ * scale = 2^(floor(log2 max|x|) - 8), elements = e4m3fn(x / scale) saturating at +-448 (OCP MX v1.0 section 6.3).
+ * asq_quantize_mxfp8: x [M,K] f32/f16/bf16 -> xq [M,K] e4m3 bytes + scales [M,K/32]; K % 32 == 0, x / xq 16-byte aligned.
+ * asq_linear_mxfp8: out[M,N] = sum_blocks (xq . wq) * 2^(x_scale + w_scale - 254) (+ bias f32 [N]) on v_mfma_scale_f32_32x32x64_f8f6f4 with the scale
+ * bytes as matrix-core operands; K % 64 == 0.  Not a tuned kernel and nothing dispatches to it: on SmoothQuant-like activations per-token e4m3
+ * (asq_quantize_act_fp8 + asq_linear_fp8) is the more accurate AND the faster path. */
+int asq_quantize_mxfp8(const void *x, int x_dtype, uint8_t *xq, uint8_t *scales, int64_t M, int64_t K, void *stream);
+int asq_linear_mxfp8(const uint8_t *xq, const uint8_t *x_scales, const uint8_t *wq, const uint8_t *w_scales, void *out, int out_dtype,
+                     int64_t M, int64_t N, int64_t K, const float *bias, void *stream);
+
 /* ---- introspection for tests / bench: which GEMM kernel the dispatcher picks for a shape (aligned operands):
  * "skinny" (weight streaming), "p8q" (128x128x128 tiles), "p8h" (128x256x128 tiles), "p8" (256x256x128 tiles, 8 waves), "p4" (the same tile,
  * 4 waves: long K) or "generic";
