@@ -4,8 +4,8 @@ The reference has no block-scaled mode (its fp8 classes use one scale per tensor
 layers/functional/quantization.py:144-211); SURVEY 8f N4 lists "MX-scaled fp8" as an accuracy-checked extension.  This file restates the
 OCP spec's conversion (section 6.3: shared exponent = floor(log2(max |v|)) - emax_elem, elements = saturating round-to-nearest-even of
 v / 2^shared_exp) and the block-scaled dot product, so the HIP kernels (asq_quantize_mxfp8, asq_linear_mxfp8) can be checked: the quantiser
-bit for bit, the GEMM within the fp32-accumulation tolerance used for the other fp8 linears.  Parity with the reference is not applicable
-(nothing to pin): the anchor is the published spec."""
+bit for bit, the GEMM within the fp32-accumulation tolerance used for the other fp8 linears.  PARITY UNPINNED against the reference (it has no
+counterpart to pin to): the anchor is the published spec, through the hand-derived known answers of tests/test_mx_oracle_cpu.py."""
 import numpy as np
 
 from . import fp8 as F8
