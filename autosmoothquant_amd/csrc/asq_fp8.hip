@@ -326,6 +326,38 @@ __global__ void __launch_bounds__(256) mx_gemm_e4m3(const uint8_t *__restrict__ 
         }
 }
 
+template <int DT, bool HAS_BIAS>
+static int launch_mx_tiled_one(const int8_t *xq, const uint8_t *xs, const int8_t *wq, const uint8_t *ws, void *out, int64_t M, int64_t N, int64_t K, const float *bias,
+                               hipStream_t s)
+{
+    using Epi = EpiFp8<DT, HAS_BIAS, MmaFp8>;
+    const size_t vbytes = DT == ASQ_F32 ? 16 : 8;
+    const bool vec_ok = (N % 4 == 0) && (((uintptr_t)out & (vbytes - 1)) == 0) && ((((uintptr_t)bias) & 15) == 0);
+    Epi epi{out, N, nullptr, bias, nullptr, 1.0f, 1.0f, false, vec_ok};  // unit epilogue scales: the block scales are inside the product
+    auto kfn = gemm_i8_p8q<Epi, true>;
+    hipError_t e = ensure_dynamic_lds((const void *)kfn, P8Q_MX_LDS_BYTES);
+    if (e != hipSuccess) {
+        asq_set_error("asq_linear_mxfp8: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    const int64_t tm = (M + 127) / 128, tn = (N + 127) / 128;
+    ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "asq_linear_mxfp8: too many tiles");
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8Q_MX_LDS_BYTES, s, xq, wq, M, N, K, (int)tm, (int)tn, 1, epi, xs, ws);
+    return asq_after_launch(s, "asq_linear_mxfp8");
+}
+static int launch_mx_tiled(int out_dtype, const int8_t *xq, const uint8_t *xs, const int8_t *wq, const uint8_t *ws, void *out, int64_t M, int64_t N, int64_t K,
+                           const float *bias, hipStream_t s)
+{
+    if (((((uintptr_t)xs) | ((uintptr_t)ws)) & 15) != 0) return ASQ_ERR_ALIGN;
+#define ASQ_MX_CASE(DT) (bias ? launch_mx_tiled_one<DT, true>(xq, xs, wq, ws, out, M, N, K, bias, s) : launch_mx_tiled_one<DT, false>(xq, xs, wq, ws, out, M, N, K, bias, s))
+    switch (out_dtype) {
+    case ASQ_F32: return ASQ_MX_CASE(ASQ_F32);
+    case ASQ_F16: return ASQ_MX_CASE(ASQ_F16);
+    default: return ASQ_MX_CASE(ASQ_BF16);
+    }
+#undef ASQ_MX_CASE
+}
+
 }  // namespace asq
 using namespace asq;
 
@@ -460,9 +492,13 @@ extern "C" int asq_linear_mxfp8(const uint8_t *xq, const uint8_t *x_scales, cons
     ASQ_REQUIRE(K > 0 && K % 64 == 0, ASQ_ERR_DIM, "asq_linear_mxfp8: K = %lld must be a positive multiple of 64", (long long)K);
     ASQ_REQUIRE(((((uintptr_t)xq) | ((uintptr_t)wq)) & 15) == 0 && (((uintptr_t)bias) & 3) == 0, ASQ_ERR_ALIGN, "asq_linear_mxfp8: misaligned operand");
     ASQ_REQUIRE(out_dtype == ASQ_F32 || out_dtype == ASQ_F16 || out_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_linear_mxfp8: bad out_dtype %d", out_dtype);
+    hipStream_t s = (hipStream_t)stream;
+    if (K % 512 == 0 && getenv("ASQ_MX_SIMPLE") == nullptr) {  // the tiled kernel (gemm_i8_p8q with MX = true): scale rows must be 16-byte multiples
+        const int rc = launch_mx_tiled(out_dtype, (const int8_t *)xq, x_scales, (const int8_t *)wq, w_scales, out, M, N, K, bias, s);
+        if (rc != ASQ_ERR_ALIGN) return rc;  // (misaligned scales / output: the plain kernel below)
+    }
     const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
     ASQ_REQUIRE(grid.y < 65536, ASQ_ERR_DIM, "asq_linear_mxfp8: M too large");
-    hipStream_t s = (hipStream_t)stream;
     switch (out_dtype) {
     case ASQ_F32: hipLaunchKernelGGL((mx_gemm_e4m3<ASQ_F32>), grid, dim3(256), 0, s, xq, x_scales, wq, w_scales, out, bias, M, N, K); break;
     case ASQ_F16: hipLaunchKernelGGL((mx_gemm_e4m3<ASQ_F16>), grid, dim3(256), 0, s, xq, x_scales, wq, w_scales, out, bias, M, N, K); break;

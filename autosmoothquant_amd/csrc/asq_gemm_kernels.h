@@ -1054,7 +1054,7 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
                 asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
                 return (int)e;
             }
-            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn * ksplit)), dim3(512), P8Q_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, ksplit, slab);
+            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn * ksplit)), dim3(512), P8Q_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, ksplit, slab, (const uint8_t *)nullptr, (const uint8_t *)nullptr);
             int64_t blocks = (M * (N / 4) + 255) / 256;
             if (blocks > 8192) blocks = 8192;
             hipLaunchKernelGGL((splitk_reduce<Epi>), dim3((unsigned)blocks), dim3(256), 0, s, (const int32_t *)ws, ksplit, M, N, epi);
@@ -1066,7 +1066,7 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
             return (int)e;
         }
-        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8Q_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, epi);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8Q_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, epi, (const uint8_t *)nullptr, (const uint8_t *)nullptr);
     } else if (kern == KERN_SKINNY) {
         const int rc = launch_skinny(x, w, M, N, K, epi, s);
         if (rc) return rc;

@@ -22,10 +22,16 @@ namespace asq {
 
 constexpr int P8Q_STAGE = 2 * P8_UNIT;        // 32 KiB
 constexpr int P8Q_LDS_BYTES = 4 * P8Q_STAGE;  // 128 KiB
+constexpr int P8Q_MX_LDS_BYTES = P8Q_LDS_BYTES + 2 * 4096;  // + two buffers of MX scale bytes (256 rows x 16 B = four K-tiles each)
 
-template <class Epi>
+// MX = true (fp8 only, asq_linear_mxfp8): xs / ws are the operands' E8M0 block scales [rows][K/32]; K % 512 == 0.  Every fourth K-tile waves 0..3
+// fetch the next 16 scale bytes of the tile's 128 + 128 rows with one LDS-DMA each; a lane reads the dword of its row and K-tile next to the
+// fragments and hands byte `hi` (k 0..63 of the tile) / byte 2 + `hi` (k 64..127) to v_mfma_scale_f32_32x32x64_f8f6f4 -- the lane (r, h) of that
+// instruction supplies the scale of the h-th 32-k block of row r.
+template <class Epi, bool MX = false>
 __global__ void __launch_bounds__(512, 2) gemm_i8_p8q(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
-                                                      int tiles_m, int tiles_n, int ksplit, Epi epi_in)
+                                                      int tiles_m, int tiles_n, int ksplit, Epi epi_in, const uint8_t *__restrict__ xs,
+                                                      const uint8_t *__restrict__ ws)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -91,14 +97,39 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8q(const int8_t *__restrict__
         p8_dma16(wbase + k0, voff[1][1], dma_dst + stage * P8Q_STAGE + P8_UNIT + 1024);
     };
 
+    // ---- MX: scale bytes of K-tile group g (tiles 4g .. 4g+3) -> scale buffer g & 1; waves 0,1: the 128 X rows, waves 2,3: the 128 W rows
+    const unsigned sc0 = lds0 + P8Q_LDS_BYTES;
+    [[maybe_unused]] unsigned sc_voff = 0, sx_addr = 0, sw_addr = 0;
+    [[maybe_unused]] const int ngrp = nt_all / 4;
+    if constexpr (MX) {
+        const int kind = wave >> 1, rl = (wave & 1) * 64 + lane;
+        int64_t row = (kind ? n0 : m0) + rl;
+        const int64_t lim = (kind ? N : M) - 1;
+        row = row < lim ? row : lim;
+        sc_voff = (unsigned)(row * (K / 32));
+        sx_addr = sc0 + (wm * 32 + frow) * 16;
+        sw_addr = sc0 + 2048 + (wn * 64 + frow) * 16;  // (+ in * 512)
+    }
+    auto issue_scales = [&](int g) {
+        if constexpr (MX) {
+            if (wave < 4) {
+                const int gc = g < ngrp ? g : ngrp - 1;  // dead prefetch past the end: stay inside the row
+                p8_dma16((const int8_t *)((wave >> 1) ? ws : xs) + 16 * gc, sc_voff, sc0 + (g & 1) * 4096 + (wave >> 1) * 2048 + (wave & 1) * 1024);
+            }
+        }
+    };
+
     // ---- prologue: K-tiles 0, 1, 2 (clamped); fragments of tile 0
+    issue_scales(0);  // (oldest: landed with tile 0)
     issue(0, 0);
     issue(1, 128 < klast ? 128 : klast);
     issue(2, 256 < klast ? 256 : klast);
     P8_WAIT_VM(8);
     __builtin_amdgcn_s_barrier();
     v4i xf[2][4], wf[2][2][4];  // [register set = K-tile parity]
-    auto read_frags = [&](auto stage_tag, auto set_tag) {
+    [[maybe_unused]] unsigned sxr[2] = {0, 0}, swr[2][2] = {{0, 0}, {0, 0}};  // MX: the row's 4 scale bytes of the K-tile, shifted so that byte 0 / 2 are this lane's
+    typedef const __attribute__((address_space(3))) unsigned *p8q_lds_u32;
+    auto read_frags = [&](auto stage_tag, auto set_tag, int tile) {
         constexpr int S = decltype(stage_tag)::value, R = decltype(set_tag)::value;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) xf[R][ks] = *(p8_lds_v4i)(uintptr_t)(xb[S][ks]);
@@ -106,8 +137,14 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8q(const int8_t *__restrict__
         for (int in = 0; in < 2; ++in)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) wf[R][in][ks] = *(p8_lds_v4i)(uintptr_t)(wbp[S][ks] + in * 4096);
+        if constexpr (MX) {
+            const unsigned off = ((tile >> 2) & 1) * 4096 + S * 4;  // scale buffer of the tile's group, dword of the tile (S = tile % 4)
+            sxr[R] = *(p8q_lds_u32)(uintptr_t)(sx_addr + off);
+            swr[R][0] = *(p8q_lds_u32)(uintptr_t)(sw_addr + off);
+            swr[R][1] = *(p8q_lds_u32)(uintptr_t)(sw_addr + 512 + off);
+        }
     };
-    read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
 
     // One barrier per K-tile.  Iteration t: re-fill the slot of tile t-1 with tile t+3 (its fragments were read during iteration t-2 and
     // waited for in iteration t-1, before the barrier every wave has passed to get here); make sure tile t+1 has landed and the
@@ -118,14 +155,27 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8q(const int8_t *__restrict__
         int kn = (t + 3) * 128;  // SALU
         kn = kn < klast ? kn : klast;
         issue(NS, kn);
+        if constexpr (MX && S == 0) issue_scales((t >> 2) + 1);  // after the tile's DMAs: three more K-tiles of DMAs follow before it is needed
         P8_WAIT_VM(8);   // tile t+1 has landed (this wave's part); tiles t+2, t+3 stay in flight
         P8_WAIT_LGKM0();  // fragments of tile t
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        read_frags(std::integral_constant<int, S1>{}, std::integral_constant<int, R ^ 1>{});
+        read_frags(std::integral_constant<int, S1>{}, std::integral_constant<int, R ^ 1>{}, t + 1);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-        if constexpr (MMA::kIsInt) {
+        if constexpr (MX) {
+            const int sx = (int)(sxr[R] >> (8 * hi));
+#pragma unroll
+            for (int in = 0; in < 2; ++in) {
+                const int swv = (int)(swr[R][in] >> (8 * hi));
+                const v8i A0 = {wf[R][in][0][0], wf[R][in][0][1], wf[R][in][0][2], wf[R][in][0][3], wf[R][in][1][0], wf[R][in][1][1], wf[R][in][1][2], wf[R][in][1][3]};
+                const v8i B0 = {xf[R][0][0], xf[R][0][1], xf[R][0][2], xf[R][0][3], xf[R][1][0], xf[R][1][1], xf[R][1][2], xf[R][1][3]};
+                acc[in] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A0, B0, acc[in], 0, 0, 0, swv, 0, sx);
+                const v8i A1 = {wf[R][in][2][0], wf[R][in][2][1], wf[R][in][2][2], wf[R][in][2][3], wf[R][in][3][0], wf[R][in][3][1], wf[R][in][3][2], wf[R][in][3][3]};
+                const v8i B1 = {xf[R][2][0], xf[R][2][1], xf[R][2][2], xf[R][2][3], xf[R][3][0], xf[R][3][1], xf[R][3][2], xf[R][3][3]};
+                acc[in] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A1, B1, acc[in], 0, 0, 2, swv, 2, sx);
+            }
+        } else if constexpr (MMA::kIsInt) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll

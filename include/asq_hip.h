@@ -216,8 +216,9 @@ int asq_cast_e5m2(const void *x, int x_dtype, uint8_t *xq, int64_t n, void *stre
  * scale = 2^(floor(log2 max|x|) - 8), elements = e4m3fn(x / scale) saturating at +-448 (OCP MX v1.0 section 6.3).
  * asq_quantize_mxfp8: x [M,K] f32/f16/bf16 -> xq [M,K] e4m3 bytes + scales [M,K/32]; K % 32 == 0, x / xq 16-byte aligned.
  * asq_linear_mxfp8: out[M,N] = sum_blocks (xq . wq) * 2^(x_scale + w_scale - 254) (+ bias f32 [N]) on v_mfma_scale_f32_32x32x64_f8f6f4 with the scale
- * bytes as matrix-core operands; K % 64 == 0.  Not a tuned kernel and nothing dispatches to it: on SmoothQuant-like activations per-token e4m3
- * (asq_quantize_act_fp8 + asq_linear_fp8) is the more accurate AND the faster path. */
+ * bytes as matrix-core operands; K % 64 == 0 (the 128 x 128 tiled kernel for K % 512 == 0 and 16-byte aligned scales, a plain kernel otherwise).
+ * Nothing dispatches to it: on SmoothQuant-like activations per-token e4m3 (asq_quantize_act_fp8 + asq_linear_fp8) is the more accurate AND the
+ * faster path. */
 int asq_quantize_mxfp8(const void *x, int x_dtype, uint8_t *xq, uint8_t *scales, int64_t M, int64_t K, void *stream);
 int asq_linear_mxfp8(const uint8_t *xq, const uint8_t *x_scales, const uint8_t *wq, const uint8_t *w_scales, void *out, int out_dtype,
                      int64_t M, int64_t N, int64_t K, const float *bias, void *stream);

@@ -44,7 +44,8 @@ def test_mx_quantiser_bit_exact(dt, shape):
 
 
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
-@pytest.mark.parametrize("shape", [(5, 40, 64), (33, 100, 192), (130, 264, 384), (64, 64, 4096), (257, 130, 1024)])
+@pytest.mark.parametrize("shape", [(5, 40, 64), (33, 100, 192), (130, 264, 384), (64, 64, 4096), (257, 130, 1024),    # K % 512 != 0: the plain kernel (first three)
+                                   (300, 260, 512), (129, 1000, 1536), (1000, 520, 2048), (640, 384, 4096)])          # tiled kernel: 1, 3, 4, 8 scale groups, ragged M / N
 def test_mx_linear_vs_oracle(dt, shape):
     from autosmoothquant_amd import ops
     M, N, K = shape

@@ -38,7 +38,7 @@ int main(int argc, char **argv)
         auto kfn = gemm_i8_p8q<decltype(e)>;
         CK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8Q_LDS_BYTES));
         const int tm = (int)((M + 127) / 128), tn = (int)((N + 127) / 128);
-        time([&] { hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8Q_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, e); }, "p8q", tm * tn);
+        time([&] { hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8Q_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, e, (const uint8_t *)nullptr, (const uint8_t *)nullptr); }, "p8q", tm * tn);
     }
     {
         auto kfn = gemm_i8_p8h<decltype(e)>;
