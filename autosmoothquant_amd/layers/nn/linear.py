@@ -462,3 +462,38 @@ class FP8E5M2Linear(_FP8Base):
         if use_bias:
             m.bias = module.bias.detach().clone().to(torch.float32)
         return m
+
+
+class FP8LinearMX(_FP8Base):
+    """Extension beyond the reference: e4m3 weights AND activations with OCP Microscaling block scales (one E8M0 byte per 32
+    consecutive k), the product on the scaled matrix-core instruction (ops.linear_mxfp8).  Opt-in only: on SmoothQuant-like activations
+    FP8LinearDynamic (per-token e4m3) is both more accurate and faster.  Buffers: weight float8_e4m3fn [N, K],
+    weight_scale_mx uint8 [N, K/32], bias f32 [N]; in_features must be a multiple of 64."""
+    _host_scalars = ()
+
+    def __init__(self, in_features, out_features, use_bias=False):
+        if in_features % 64 != 0:
+            raise ValueError("FP8LinearMX needs in_features % 64 == 0 (MX blocks of 32, two per matrix-core instruction)")
+        super().__init__(in_features, out_features, use_bias)
+        self.register_buffer("weight_scale_mx", torch.full((out_features, in_features // 32), 127, dtype=torch.uint8, requires_grad=False))
+
+    @torch.no_grad()
+    def forward(self, x):
+        lead = x.shape[:-1]
+        x2 = self._x2d(x)
+        if x2.numel() == 0:
+            return torch.empty(*lead, self.out_features, dtype=x.dtype, device=x.device)
+        xq, xs = ops.quantize_mxfp8(x2)
+        out = ops.linear_mxfp8(xq, xs, self.weight, self.weight_scale_mx, x.dtype, self._bias_dev(x.device))
+        return out.view(*lead, self.out_features)
+
+    @staticmethod
+    def from_float(module: torch.nn.Linear):
+        """The source module must live on the HIP device: the weight is quantised by the same kernel as the activations (no CPU path)."""
+        use_bias = module.bias is not None
+        m = FP8LinearMX(module.in_features, module.out_features, use_bias=use_bias)
+        wq, ws = ops.quantize_mxfp8(module.weight.detach().contiguous())
+        m.weight, m.weight_scale_mx = wq, ws
+        if use_bias:
+            m.bias = module.bias.detach().clone().to(torch.float32)
+        return m

@@ -57,7 +57,7 @@ class QuantArena:
         self.mods = _quant_modules(root)
         self.entries, off, sig = [], 0, hashlib.sha256()
         for i, m in enumerate(self.mods):
-            for n in ("weight", "bias"):
+            for n in ("weight", "bias", "weight_scale_mx"):
                 t = m._buffers.get(n)
                 if t is None:
                     continue
@@ -168,7 +168,7 @@ def buffers_fingerprint(root):
     the broadcast).  Computed with integer tensor ops on the buffers' own device."""
     acc = 0
     for m in _quant_modules(root):
-        for n in ("weight", "bias") + tuple(m._host_scalars):
+        for n in ("weight", "bias", "weight_scale_mx") + tuple(m._host_scalars):
             t = m._buffers.get(n)
             if t is None:
                 continue

@@ -85,3 +85,25 @@ def test_mx_is_not_more_accurate_than_per_token_here():
     e_tok, e_mx = rel(y_tok), rel(y_mx)
     assert 0.005 < e_tok < 0.05 and 0.005 < e_mx < 0.08, (e_tok, e_mx)
     assert e_mx > 0.9 * e_tok, (e_tok, e_mx)   # MX buys no accuracy on this distribution
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_mx_module_forward(dt):
+    """FP8LinearMX.from_float + forward == the oracle's MX quantisation of both operands and block-scaled product."""
+    from autosmoothquant_amd.layers.nn.linear import FP8LinearMX
+    lin = torch.nn.Linear(1024, 264, bias=True)
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(detrng.normal(720, 0, (264, 1024)).astype(np.float32) * 0.05))
+        lin.bias.copy_(torch.from_numpy(detrng.normal(721, 0, (264,)).astype(np.float32)))
+    m = FP8LinearMX.from_float(lin.to(DEV))
+    assert m.weight.dtype == torch.float8_e4m3fn and tuple(m.weight_scale_mx.shape) == (264, 32)
+    x = O.round_to(detrng.act_like(722, 0, (3, 17, 1024), scale=2.0), dt)
+    y = m(_t(x, dt))
+    assert tuple(y.shape) == (3, 17, 264) and y.dtype == TDT[dt]
+    xq, xs = MX.mx_quantize_e4m3(x.reshape(51, 1024))
+    wq, ws = MX.mx_quantize_e4m3(lin.weight.detach().cpu().numpy())
+    assert np.array_equal(m.weight.view(torch.uint8).cpu().numpy(), wq) and np.array_equal(m.weight_scale_mx.cpu().numpy(), ws)
+    ref = MX.mx_linear(xq, xs, wq, ws, lin.bias.detach().cpu().numpy(), dt).reshape(3, 17, 264)
+    tol = (1e-3 if dt != "bf16" else 8e-3) * max(1.0, float(np.abs(ref).max()))
+    assert np.abs(y.float().cpu().numpy() - ref).max() <= tol
+    assert tuple(m(torch.zeros(0, 1024, device=DEV, dtype=TDT[dt])).shape) == (0, 264)

@@ -24,7 +24,7 @@ def _free_port():
 
 def _make_model(seed):
     from autosmoothquant_amd.layers.nn.linear import (W8A8BFP32OFP32Linear, W8A8BFP32OFP32LinearWithQuantScale,
-                                                      W8A8BFP32OFP32QKVLinear, FP8LinearStatic, FP8LinearDynamic, FP8E5M2Linear)
+                                                      W8A8BFP32OFP32QKVLinear, FP8LinearStatic, FP8LinearDynamic, FP8E5M2Linear, FP8LinearMX)
     g = torch.Generator().manual_seed(seed)
     mods = torch.nn.ModuleDict()
     a = W8A8BFP32OFP32Linear(64, 48, True, "per-tensor")
@@ -49,6 +49,11 @@ def _make_model(seed):
     d.weight_scale, d.input_scale, d.output_scale = torch.tensor(0.01 * (seed + 1)), torch.tensor(0.02 * (seed + 2)), torch.tensor(0.0)
     e.weight_scale = torch.tensor(0.04 * (seed + 3))
     mods["d"], mods["e"], mods["f"] = d, e, f
+    h = FP8LinearMX(64, 16, use_bias=True)   # the MX opt-in: its block-scale bytes are a third device buffer of the arena
+    h.weight = torch.randint(0, 120, h.weight.shape, generator=g, dtype=torch.uint8).view(h._weight_dtype)
+    h.weight_scale_mx = torch.randint(100, 140, h.weight_scale_mx.shape, generator=g, dtype=torch.uint8)
+    h.bias = torch.randn(16, generator=g)
+    mods["h"] = h
     return mods
 
 
@@ -78,6 +83,7 @@ def _worker(rank, world, port, q):
         base = arena.buf.untyped_storage().data_ptr()
         host_ok = host_ok and all(m.weight.untyped_storage().data_ptr() == base for m in mods.values())
         host_ok = host_ok and mods["d"].weight.dtype == torch.float8_e4m3fn and mods["f"].weight.dtype == torch.float8_e5m2
+        host_ok = host_ok and mods["h"].weight_scale_mx.dtype == torch.uint8 and mods["h"].weight_scale_mx.untyped_storage().data_ptr() == base
         host_ok = host_ok and arena.total % (256 * world) == 0
         # each rank computes its shard of a global batch; rank 0 gathers and compares with the 1-process result
         M = 37
@@ -120,8 +126,8 @@ def test_broadcast_and_row_sharding_world2():
     for rank, differs_before, same_after, host_ok, nbytes, fp, parts in res:
         assert differs_before, "test is vacuous if ranks start identical"
         assert same_after and host_ok
-        # int8 weights + fp8 weights + fp32 biases + (6 int8-module + 4 fp8-module) host scalars
-        assert nbytes == (48 * 64 + 64 * 48 + 64 * 64) + (24 * 32 + 40 * 24 + 8 * 40) + 4 * (48 + 64 + 24) + 4 * (6 + 4)
+        # int8 weights + fp8 weights + fp32 biases + (6 int8-module + 4 fp8-module) host scalars + the MX module (weight, block scales, bias)
+        assert nbytes == (48 * 64 + 64 * 48 + 64 * 64) + (24 * 32 + 40 * 24 + 8 * 40) + 4 * (48 + 64 + 24) + 4 * (6 + 4) + (16 * 64 + 16 * 2 + 4 * 16)
         fps.add(fp)
     assert len(fps) == 1
     # replica rows == single-process rows, bit for bit
