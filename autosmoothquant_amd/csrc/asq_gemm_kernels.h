@@ -848,20 +848,27 @@ static inline int pick_ksplit_p8q(int64_t tiles, int64_t K, int64_t M, int64_t N
     return s < 1 ? 1 : (int)s;
 }
 
-// K splits for the 128-row kernel (tiles = its block count at one split).  Measured optimum: fill ~192 CUs,
-// but never leave a split fewer than 12 K-tiles (the int32 slab write + reduce pass must stay small next to the K loop)
+// K splits for the 128-row kernel (tiles = its block count at one split), from the same kind of fitted cost model as pick_ksplit_p8q (us): a block
+// costs 3 + (K-tiles) x (0.45 + 0.33 x the fraction of the 256 CUs that hold a block), a split launch adds 5 + S x M x N x 4 B at 3 TB/s for the
+// reduce pass.  OPT-13B fc2 at 256 rows (40 tiles, 160 K-tiles): S = 6 (39.5 us warm / 46.0 cold; the former "fill ~192 CUs" rule gave S = 4:
+// 41.2 / 51.8); 384x4096x11008: S = 4 (31.4); 256x4096x11008: S = 6 (26.3); 2048x4096x4096 (128 tiles): S = 1.
 static inline int pick_ksplit_p8h(int64_t tiles, int64_t K, int64_t M, int64_t N, size_t ws_bytes)
 {
     if (N % 4 != 0) return 1;
     const int64_t nt = K / 128;
     const int forced = forced_ksplit();
-    int64_t s;
+    int64_t s = 1;
     if (forced > 0) {
         s = forced > nt ? nt : forced;
     } else {
-        if (tiles >= 80) return 1;
-        s = 192 / tiles;
-        if (s > nt / 12) s = nt / 12;
+        double best = 1e30;
+        const int64_t smax = nt / 4 < 16 ? nt / 4 : 16;
+        for (int64_t c = 1; c <= (smax < 1 ? 1 : smax); ++c) {
+            const double blocks = (double)tiles * (double)c, waves = (double)((tiles * c + 255) / 256), fill = blocks < 256.0 ? blocks / 256.0 : 1.0;
+            double t = waves * (3.0 + (double)((nt + c - 1) / c) * (0.45 + 0.33 * fill));
+            if (c > 1) t += 5.0 + (double)c * (double)M * (double)N * 4.0 / 3.0e6;
+            if (t < best) { best = t; s = c; }
+        }
     }
     while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ws_bytes) --s;
     return s < 1 ? 1 : (int)s;

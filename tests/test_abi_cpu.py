@@ -39,7 +39,7 @@ def test_argument_errors_without_gpu():
     assert h.asq_gemm_i8_i32(None, None, None, 0, 4, 4, None, 0, None) == 0            # empty problem is a no-op
     assert h.asq_linear_w8a8_workspace_bytes(3, 7, 5) == 256 + 256
     assert h.asq_gemm_workspace_bytes(4096, 4096, 4096) == 0            # 256 tiles fill the chip: no split-K
-    assert h.asq_gemm_workspace_bytes(256, 5120, 20480) == 4 * 256 * 5120 * 4   # OPT-13B fc2: 40 tiles of 128 rows -> 4 K splits
+    assert h.asq_gemm_workspace_bytes(256, 5120, 20480) == 6 * 256 * 5120 * 4   # OPT-13B fc2: 40 tiles of 128 rows -> 6 K splits (240 blocks)
     assert h.asq_gemm_workspace_bytes(32, 4096, 4096) == 0              # skinny path
     assert h.asq_gemm_kernel_name(4096, 4096, 4096) == b"p8"
     assert h.asq_gemm_kernel_name(64, 14336, 4096) == b"skinny"          # decode batch: weight stream
