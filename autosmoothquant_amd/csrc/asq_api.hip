@@ -27,11 +27,12 @@ extern "C" const char *asq_last_error(void) { return g_err; }
 
 static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// workspace layout: [ xq int8 M*K | pad to 256 | s_row f32 M | pad to 256 | GEMM split-K slabs ]
+// workspace layout: [ GEMM workspace: header (asq_workspace_init) + scratch, padded to 256 | xq int8 M*K | pad to 256 | s_row f32 M | pad to 256 ]
+// The header sits at offset 0 whatever the shape, so one initialised buffer serves every call that fits into it.
 extern "C" size_t asq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K)
 {
     if (M < 0 || K < 0 || N < 0) return 0;
-    return round_up((size_t)M * (size_t)K, 256) + round_up((size_t)M * 4, 256) + asq_gemm_workspace_bytes(M, N, K);
+    return round_up(asq_gemm_workspace_bytes(M, N, K), 256) + round_up((size_t)M * (size_t)K, 256) + round_up((size_t)M * 4, 256);
 }
 
 extern "C" int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t *w, void *out, int64_t M, int64_t N, int64_t K,
@@ -44,11 +45,13 @@ extern "C" int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t 
     ASQ_REQUIRE(workspace != nullptr && workspace_bytes >= need, ASQ_ERR_WORKSPACE,
                 "asq_linear_w8a8_forward: workspace %zu B < required %zu B", workspace_bytes, need);
     ASQ_REQUIRE(((uintptr_t)workspace & 255) == 0, ASQ_ERR_ALIGN, "asq_linear_w8a8_forward: workspace must be 256-B aligned");
-    int8_t *xq = (int8_t *)workspace;
-    float *s_row = (float *)((char *)workspace + round_up((size_t)M * (size_t)K, 256));
+    const size_t gbytes = round_up(asq_gemm_workspace_bytes(M, N, K), 256);
+    const bool with_gemm_ws = gbytes > 0 && workspace_bytes >= gbytes + need;  // a smaller buffer is [ xq | s_row ] only
+    char *base = (char *)workspace + (with_gemm_ws ? gbytes : 0);
+    int8_t *xq = (int8_t *)base;
+    float *s_row = (float *)(base + round_up((size_t)M * (size_t)K, 256));
     int rc = asq_quantize_act(x, x_dtype, act_mode, quant_scale, xq, s_row, M, K, stream);
     if (rc) return rc;
-    char *gws = (char *)workspace + need;
     return asq_linear_w8a8(xq, w, out, x_dtype, M, N, K, s_scalar, act_mode == ASQ_ACT_PER_TOKEN ? s_row : nullptr, s_col, bias,
-                           ASQ_EPI_SCALE_FIRST, workspace_bytes > need ? gws : nullptr, workspace_bytes > need ? workspace_bytes - need : 0, stream);
+                           ASQ_EPI_SCALE_FIRST, with_gemm_ws ? workspace : nullptr, with_gemm_ws ? gbytes : 0, stream);
 }

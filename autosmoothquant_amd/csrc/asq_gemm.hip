@@ -54,14 +54,31 @@ extern "C" size_t asq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K)
 {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const GemmKernel kern = pick_kernel(nullptr, nullptr, M, N, K);
+    size_t scratch = 0;
     const TailPeel tp = plan_tail_peel(kern, M, N, K);
-    if (tp.n_main > 0) return tp.ws_bytes;  // (a launch with >= 256 tiles never splits K as a whole; its peeled remainder may)
-    if (kern != KERN_P8 && kern != KERN_P8H && kern != KERN_P8Q) return 0;
-    const int s = kern == KERN_P8    ? pick_ksplit(((M + 255) / 256) * ((N + 255) / 256), K, M, N, (size_t)-1)
-                  : kern == KERN_P8H ? pick_ksplit_p8h(((M + 127) / 128) * ((N + 255) / 256), K, M, N, (size_t)-1)
-                                     : pick_ksplit_p8q(((M + 127) / 128) * ((N + 127) / 128), K, M, N, (size_t)-1);
-    return s > 1 ? (size_t)s * (size_t)M * (size_t)N * 4 : 0;
+    if (tp.n_main > 0) {
+        scratch = tp.ws_bytes;  // (a launch with >= 256 tiles never splits K as a whole; its peeled remainder may)
+    } else if (kern == KERN_SKINNY) {
+        scratch = plan_wstream(M, N, K).bytes;  // partial slabs of the in-launch reduction (asq_gemm_wstream.h)
+    } else if (kern == KERN_P8 || kern == KERN_P8H || kern == KERN_P8Q) {
+        const int s = kern == KERN_P8    ? pick_ksplit(((M + 255) / 256) * ((N + 255) / 256), K, M, N, (size_t)-1)
+                      : kern == KERN_P8H ? pick_ksplit_p8h(((M + 127) / 128) * ((N + 255) / 256), K, M, N, (size_t)-1)
+                                         : pick_ksplit_p8q(((M + 127) / 128) * ((N + 127) / 128), K, M, N, (size_t)-1);
+        scratch = s > 1 ? (size_t)s * (size_t)M * (size_t)N * 4 : 0;
+    }
+    return scratch ? scratch + WS_HEADER_BYTES : 0;
 }
+
+extern "C" int asq_workspace_init(void *workspace, size_t workspace_bytes, void *stream)
+{
+    ASQ_REQUIRE(workspace != nullptr, ASQ_ERR_NULL, "asq_workspace_init: NULL workspace");
+    ASQ_REQUIRE(workspace_bytes >= (size_t)WS_HEADER_BYTES, ASQ_ERR_WORKSPACE, "asq_workspace_init: workspace %zu B < header %d B", workspace_bytes, WS_HEADER_BYTES);
+    ASQ_REQUIRE((((uintptr_t)workspace) & 255) == 0, ASQ_ERR_ALIGN, "asq_workspace_init: workspace must be 256-B aligned");
+    hipLaunchKernelGGL(ws_init_header, dim3(1), dim3(256), 0, (hipStream_t)stream, (unsigned *)workspace);
+    return asq_after_launch((hipStream_t)stream, "asq_workspace_init");
+}
+
+extern "C" size_t asq_workspace_header_bytes(void) { return (size_t)WS_HEADER_BYTES; }
 
 extern "C" int asq_gemm_i8_i32(const int8_t *x, const int8_t *w, int32_t *out, int64_t M, int64_t N, int64_t K, void *workspace,
                                size_t workspace_bytes, void *stream)

@@ -704,6 +704,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 #include "asq_gemm_p8h.h"
 #include "asq_gemm_p8q.h"
 #include "asq_gemm_skinny.h"
+#include "asq_gemm_wstream.h"
 
 namespace asq {
 
@@ -900,8 +901,72 @@ template <class Epi, int MT, int NT> int launch_skinny_mt(const int8_t *x, const
     return ASQ_OK;
 }
 
-template <class Epi> int launch_skinny(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, const Epi &epi, hipStream_t s)
+// ---- second-generation weight stream (asq_gemm_wstream.h): grid size and workspace
+struct WsPlan {
+    int G = 0, KU = 0, T = 0, maxseg = 0, mt = 0;
+    size_t bytes = 0;  // scratch behind the workspace header
+};
+static inline int ws_env(const char *name)  // development overrides, read once per process
 {
+    const char *e = getenv(name);
+    return e ? atoi(e) : -1;
+}
+static inline WsPlan plan_wstream(int64_t M, int64_t N, int64_t K)
+{
+    WsPlan p;
+    static const int impl = ws_env("ASQ_SK_IMPL");  // 0 = first-generation kernel only, 1 / unset = this one where it applies
+    if (impl == 0 || M < 1 || M > 128 || K % 128 != 0 || K < 128) return p;
+    const int64_t NG = (N + WS_CB - 1) / WS_CB, KU = K / 128, T = NG * KU;
+    if (NG > WS_MAX_GROUPS || T >= (1ll << 22)) return p;  // (T * G < 2^31 with G <= 512)
+    static const int forced_g = ws_env("ASQ_WS_GRID");
+    int64_t G = forced_g > 0 ? forced_g : 256;
+    if (G > 512) G = 512;
+    if (forced_g <= 0) {
+        // at least 4 units (64 KB of W) per block, and at most ~16 contributors per group for the last arriver to sum
+        if (G > T / 4) G = T / 4 < 1 ? 1 : T / 4;
+        if (G > 15 * NG) G = 15 * NG;
+    }
+    if (G > T) G = T;
+    p.G = (int)G;
+    p.KU = (int)KU;
+    p.T = (int)T;
+    const int64_t nun_max = (T + G - 1) / G;
+    p.maxseg = (int)((nun_max + KU - 1) / KU + 1);
+    p.mt = M <= 16 ? 1 : M <= 32 ? 2 : M <= 64 ? 4 : 8;
+    p.bytes = (size_t)G * (size_t)p.maxseg * (size_t)(p.mt * 8192);
+    return p;
+}
+
+template <class Epi, int MT, bool WNT>
+int launch_wstream_mt(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, const WsPlan &p, char *ws, const Epi &epi, hipStream_t s)
+{
+    auto kfn = gemm_i8_wstream<Epi, MT, WNT>;
+    hipError_t e = ensure_dynamic_lds((const void *)kfn, WsCfg<MT>::LDS);
+    if (e != hipSuccess) {
+        asq_set_error("wstream: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)p.G), dim3(512), WsCfg<MT>::LDS, s, x, w, M, N, K, p.KU, p.T, p.maxseg, ws, epi);
+    return ASQ_OK;
+}
+
+// ws_hdr = the caller's workspace (header first), usable scratch behind it = ws_bytes - WS_HEADER_BYTES
+template <class Epi> int launch_skinny(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, const Epi &epi, hipStream_t s, void *ws_hdr = nullptr, size_t ws_bytes = 0)
+{
+    if (ws_hdr != nullptr && ws_bytes > (size_t)WS_HEADER_BYTES && M * K < (1ll << 32)) {
+        const WsPlan p = plan_wstream(M, N, K);
+        if (p.G > 0 && p.bytes <= ws_bytes - WS_HEADER_BYTES) {
+            static const int nt = ws_env("ASQ_WS_NT");
+#define ASQ_WS(MT_) (nt == 1 ? launch_wstream_mt<Epi, MT_, true>(x, w, M, N, K, p, (char *)ws_hdr, epi, s) : launch_wstream_mt<Epi, MT_, false>(x, w, M, N, K, p, (char *)ws_hdr, epi, s))
+            switch (p.mt) {
+            case 1: return ASQ_WS(1);
+            case 2: return ASQ_WS(2);
+            case 4: return ASQ_WS(4);
+            default: return ASQ_WS(8);
+            }
+#undef ASQ_WS
+        }
+    }
     const int mblocks = (int)((M + 63) / 64);                       // m-blocks of <= 64 rows, balanced
     const int mt = (int)(((M + mblocks - 1) / mblocks + 15) / 16);  // 16-row tiles per m-block
     // 32 channels per item halve the X re-reads from L2.  Measured (tools/ubench/skinny_probe, ASQ_SK_NT=1|2, M = 32):
@@ -952,9 +1017,11 @@ static inline TailPeel plan_tail_peel(GemmKernel kern, int64_t M, int64_t N, int
 template <class Epi, class = void> struct HasColView : std::false_type {};
 template <class Epi> struct HasColView<Epi, std::enable_if_t<Epi::kColView>> : std::true_type {};
 
+// A caller's workspace is [ header WS_HEADER_BYTES (asq_workspace_init: magic + tickets of the weight-streaming kernel) | scratch ];
+// `ws` below is the scratch part (split-K slabs), `ws_hdr` the whole thing (null when the caller's buffer is too small to hold a header).
 template <class Epi>
-int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, Epi epi, hipStream_t s, const char *what, void *ws = nullptr,
-                size_t ws_bytes = 0, const int *goffs = nullptr, int ngroups = 0, int peel_role = 0 /* 0 top level, 1 main part, 2 remainder (128 x 128 tiles) */)
+int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, Epi epi, hipStream_t s, const char *what, void *ws_hdr, void *ws,
+                     size_t ws_bytes, const int *goffs = nullptr, int ngroups = 0, int peel_role = 0 /* 0 top level, 1 main part, 2 remainder (128 x 128 tiles) */)
 {
     if (M == 0 || N == 0) return ASQ_OK;
     if (goffs != nullptr) {  // grouped: tiled kernel only; grid = host-side upper bound on the number of tiles
@@ -977,9 +1044,9 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
         if (peel_role == 0 && (N * Epi::kOutBytes) % 16 == 0) {
             const TailPeel tp = plan_tail_peel(kern, M, N, K);
             if (tp.n_main > 0) {
-                const int rc = launch_gemm(x, w, M, tp.n_main, K, epi, s, what, nullptr, 0, nullptr, 0, 1);
+                const int rc = launch_gemm_impl(x, w, M, tp.n_main, K, epi, s, what, nullptr, nullptr, 0, nullptr, 0, 1);
                 if (rc) return rc;
-                return launch_gemm(x, w + tp.n_main * K, M, N - tp.n_main, K, epi.col_view(tp.n_main), s, what, ws, ws_bytes, nullptr, 0, 2);
+                return launch_gemm_impl(x, w + tp.n_main * K, M, N - tp.n_main, K, epi.col_view(tp.n_main), s, what, nullptr, ws, ws_bytes, nullptr, 0, 2);
             }
         }
     }
@@ -1075,7 +1142,7 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
         }
         hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8Q_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, epi, (const uint8_t *)nullptr, (const uint8_t *)nullptr);
     } else if (kern == KERN_SKINNY) {
-        const int rc = launch_skinny(x, w, M, N, K, epi, s);
+        const int rc = launch_skinny(x, w, M, N, K, epi, s, ws_hdr, ws_hdr ? ws_bytes + WS_HEADER_BYTES : 0);
         if (rc) return rc;
     } else {
         const bool fast = (K % 16 == 0) && (((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0);
@@ -1084,6 +1151,15 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
         hipLaunchKernelGGL((gemm_i8_generic<Epi>), grid, dim3(256), 0, s, x, w, M, N, K, fast, epi);
     }
     return asq_after_launch(s, what);
+}
+
+template <class Epi>
+int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, Epi epi, hipStream_t s, const char *what, void *ws = nullptr,
+                size_t ws_bytes = 0, const int *goffs = nullptr, int ngroups = 0)
+{
+    const bool has = ws != nullptr && ws_bytes >= (size_t)WS_HEADER_BYTES && (((uintptr_t)ws) & 15) == 0;
+    return launch_gemm_impl(x, w, M, N, K, epi, s, what, has ? ws : nullptr, has ? (char *)ws + WS_HEADER_BYTES : nullptr, has ? ws_bytes - WS_HEADER_BYTES : 0, goffs,
+                            ngroups, 0);
 }
 
 // per-dtype instantiation units (asq_gemm_inst_*.hip)

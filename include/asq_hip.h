@@ -73,9 +73,22 @@ int asq_gemm_i8_i32(const int8_t *x, const int8_t *w, int32_t *out,
  * Independently of the workspace, a grid a few tiles over a multiple of 256 (1536 x 11008: 258 tiles) runs its last tile columns as a launch of
  * 128 x 128 tiles instead of paying a second wave for two tiles (-3 ... -19 % of the call); with a workspace that remainder may split K too.
  * asq_gemm_workspace_bytes() returns the size that enables this for a shape (0 = never needed).
- * workspace may be NULL / smaller (then fewer or no K splits are used); it must be 16-B aligned and
- * not shared by concurrently running calls. */
+ * workspace may be NULL / smaller (then fewer or no K splits are used); it must be 256-B aligned, initialised once with
+ * asq_workspace_init() and not shared by concurrently running calls (contract below). */
 size_t asq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+
+/* Workspace contract.  A workspace is [ header: asq_workspace_header_bytes() = 8 KiB | scratch ].  The header holds a magic word and the
+ * arrival tickets of the weight-streaming kernel's in-launch reduction (few rows against a large weight: decode, cfg1, OPT fc2 at 32 rows per GPU --
+ * csrc/asq_gemm_wstream.h); split-K slabs of the tiled kernels live behind it.
+ *   - asq_workspace_init() must run ONCE on a buffer (on the stream it will be used on, or synchronised) before the first GEMM call that receives it;
+ *     every launch leaves the tickets at zero, also under hipGraph replay, so there is nothing to reset between calls or shapes;
+ *   - a buffer is used by one launch at a time (one stream): concurrent launches on one workspace corrupt each other's tickets;
+ *   - sizes returned by asq_gemm_workspace_bytes / asq_linear_w8a8_workspace_bytes include the header; the header is always at offset 0;
+ *   - a launch that finds no magic word, or a ticket above its contributor count, executes s_trap (the stream reports a launch failure)
+ *     instead of returning wrong sums.  Passing NULL / a buffer smaller than the header selects the first-generation kernels, which need none.
+ * 256-B aligned. */
+int asq_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
+size_t asq_workspace_header_bytes(void);
 
 /* ---- K3/K4/K5: I8CUGEMM::linear_a8_w8_o8 / linear_a8_w8_o8_ / linear_a8_w8_b8_o8_
  * (bindings.cpp:86-142 -> cublasINT8MMWrapper.cc:360-672)
