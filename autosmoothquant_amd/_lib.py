@@ -21,6 +21,8 @@ SIGNATURES = {
     "asq_version": (_int, []),
     "asq_last_error": (ctypes.c_char_p, []),
     "asq_gemm_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "asq_workspace_init": (_int, [_vp, _sz, _vp]),
+    "asq_workspace_header_bytes": (_sz, []),
     "asq_gemm_i8_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _sz, _vp]),
     "asq_gemm_i8_i8": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _f32, _f32, _vp, _sz, _vp]),
     "asq_quantize_act": (_int, [_vp, _int, _int, _f32, _vp, _vp, _i64, _i64, _vp]),

@@ -72,7 +72,7 @@ extern "C" size_t asq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K)
 extern "C" int asq_workspace_init(void *workspace, size_t workspace_bytes, void *stream)
 {
     ASQ_REQUIRE(workspace != nullptr, ASQ_ERR_NULL, "asq_workspace_init: NULL workspace");
-    ASQ_REQUIRE(workspace_bytes >= (size_t)WS_HEADER_BYTES, ASQ_ERR_WORKSPACE, "asq_workspace_init: workspace %zu B < header %d B", workspace_bytes, WS_HEADER_BYTES);
+    ASQ_REQUIRE(workspace_bytes >= (size_t)WS_HEADER_BYTES, ASQ_ERR_WORKSPACE, "asq_workspace_init: workspace %zu B < header %d B (asq_workspace_header_bytes)", workspace_bytes, WS_HEADER_BYTES);
     ASQ_REQUIRE((((uintptr_t)workspace) & 255) == 0, ASQ_ERR_ALIGN, "asq_workspace_init: workspace must be 256-B aligned");
     hipLaunchKernelGGL(ws_init_header, dim3(1), dim3(256), 0, (hipStream_t)stream, (unsigned *)workspace);
     return asq_after_launch((hipStream_t)stream, "asq_workspace_init");

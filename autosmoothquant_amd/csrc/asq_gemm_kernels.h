@@ -914,8 +914,13 @@ static inline int ws_env(const char *name)  // development overrides, read once 
 static inline WsPlan plan_wstream(int64_t M, int64_t N, int64_t K)
 {
     WsPlan p;
-    static const int impl = ws_env("ASQ_SK_IMPL");  // 0 = first-generation kernel only, 1 / unset = this one where it applies
-    if (impl == 0 || M < 1 || M > 128 || K % 128 != 0 || K < 128) return p;
+    if (M < 1 || M > 128 || K % 128 != 0 || K < 128) return p;
+    // Used where its in-launch reduction (~4 us) costs less than gemm_i8_skinny's LDS starvation: long-K weights at >= 16 rows.  Measured, cold
+    // weights, us (tools/ubench/wstream_probe, profiles/r3_skinny_experiments.md): 5120x20480 (OPT-13B fc2) 16 rows 26.5 -> 24.0, 32 rows 31.3 -> 25.9;
+    // 4096x14336 (Mixtral w2) 64 rows 22.5 -> 20.0; everything else +3 ... +90 % (4096x4096 at 32 rows: 6.5 -> 12.0): the region is narrow on purpose.
+    static const int impl = ws_env("ASQ_SK_IMPL");  // development A/B: 0 = never, 1 = wherever it can run
+    const bool region = (K >= 4 * N && M >= 16 && N * K >= (64ll << 20)) || (K >= 3 * N && M > 32 && N * K >= (48ll << 20));
+    if (impl == 0 || !(region || impl == 1)) return p;
     const int64_t NG = (N + WS_CB - 1) / WS_CB, KU = K / 128, T = NG * KU;
     if (NG > WS_MAX_GROUPS || T >= (1ll << 22)) return p;  // (T * G < 2^31 with G <= 512)
     static const int forced_g = ws_env("ASQ_WS_GRID");
@@ -953,10 +958,19 @@ int launch_wstream_mt(const int8_t *x, const int8_t *w, int64_t M, int64_t N, in
 // ws_hdr = the caller's workspace (header first), usable scratch behind it = ws_bytes - WS_HEADER_BYTES
 template <class Epi> int launch_skinny(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, const Epi &epi, hipStream_t s, void *ws_hdr = nullptr, size_t ws_bytes = 0)
 {
-    if (ws_hdr != nullptr && ws_bytes > (size_t)WS_HEADER_BYTES && M * K < (1ll << 32)) {
-        const WsPlan p = plan_wstream(M, N, K);
+    const int mblocks = (int)((M + 63) / 64);                       // m-blocks of <= 64 rows, balanced
+    const int mt = (int)(((M + mblocks - 1) / mblocks + 15) / 16);  // 16-row tiles per m-block
+    static int nt_forced = -1;
+    if (nt_forced < 0) { const char *e = getenv("ASQ_SK_NT"); nt_forced = e ? atoi(e) : 0; }
+    const int64_t items2 = ((N + 31) / 32) * mblocks;
+    const bool wide = nt_forced ? nt_forced == 2 : (items2 >= 448 || (K >= 16384 && items2 >= 128));
+    if constexpr (Epi::Mma::kIsInt) if (ws_hdr != nullptr && ws_bytes > (size_t)WS_HEADER_BYTES && M * K < (1ll << 32)) {
+        const WsPlan p = plan_wstream(M, N, K);  // the stream-K kernel inside its measured region (plan_wstream)
         if (p.G > 0 && p.bytes <= ws_bytes - WS_HEADER_BYTES) {
-            static const int nt = ws_env("ASQ_WS_NT");
+            // streaming (nt) cache policy for the weight lines of the big streams: 5120x20480 (105 MB) 27.2 -> 25.9 us at 32 rows, 25.8 -> 24.0 at 16;
+            // 4096x14336 (59 MB) 20.0 -> 21.9 at 64 rows, so only above 80 MB
+            static const int nt_env = ws_env("ASQ_WS_NT");
+            const int nt = nt_env >= 0 ? nt_env : (N * K >= (80ll << 20) ? 1 : 0);
 #define ASQ_WS(MT_) (nt == 1 ? launch_wstream_mt<Epi, MT_, true>(x, w, M, N, K, p, (char *)ws_hdr, epi, s) : launch_wstream_mt<Epi, MT_, false>(x, w, M, N, K, p, (char *)ws_hdr, epi, s))
             switch (p.mt) {
             case 1: return ASQ_WS(1);
@@ -967,15 +981,9 @@ template <class Epi> int launch_skinny(const int8_t *x, const int8_t *w, int64_t
 #undef ASQ_WS
         }
     }
-    const int mblocks = (int)((M + 63) / 64);                       // m-blocks of <= 64 rows, balanced
-    const int mt = (int)(((M + mblocks - 1) / mblocks + 15) / 16);  // 16-row tiles per m-block
     // 32 channels per item halve the X re-reads from L2.  Measured (tools/ubench/skinny_probe, ASQ_SK_NT=1|2, M = 32):
     // 14336x4096 16.8 -> 15.5 us, 20480x5120 29.5 -> 26.3, 5120x20480 40.9 -> 31.7; but 8192x8192 18.0 -> 20.6 and
     // 4096x11008 13.1 -> 15.5 (too few items), 11008x4096 unchanged: only with plenty of items, or a long K
-    static int nt_forced = -1;
-    if (nt_forced < 0) { const char *e = getenv("ASQ_SK_NT"); nt_forced = e ? atoi(e) : 0; }
-    const int64_t items2 = ((N + 31) / 32) * mblocks;
-    const bool wide = nt_forced ? nt_forced == 2 : (items2 >= 448 || (K >= 16384 && items2 >= 128));
 #define ASQ_SK(MT_) (wide ? launch_skinny_mt<Epi, MT_, 2>(x, w, M, N, K, mblocks, epi, s) : launch_skinny_mt<Epi, MT_, 1>(x, w, M, N, K, mblocks, epi, s))
     switch (mt) {
     case 1: return ASQ_SK(1);

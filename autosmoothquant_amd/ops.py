@@ -54,47 +54,56 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def _gemm_ws(M, N, K, dev):
-    """split-K scratch for shapes whose tile grid cannot fill the chip (None when not needed);
-    comes from torch's stream-ordered caching allocator, so concurrent streams never share it"""
-    n = L.lib().asq_gemm_workspace_bytes(M, N, K)
-    return (torch.empty((n,), dtype=torch.uint8, device=dev), n) if n else (None, 0)
-
-
-_WS_CACHE_MAX = 8 << 20   # decode-sized calls only: the quantised activation of a 65536-row call is 256 MiB and not worth pinning
+_WS_PERSIST_MAX = 64 << 20   # beyond that (split-K slabs of large-M calls) a fresh buffer per call; decode-sized calls never get there
 _ws_tls = threading.local()
 
 
-def _forward_ws(lib, M, N, K, dev, stream):
-    """Workspace of asq_linear_w8a8_forward (int8 activation + row scales + split-K slabs).  Decode-sized calls are host-bound
-    (two launches ~7 us): their workspace is kept per (thread, device, stream) instead of going through
-    torch.empty + a size query on every call (-2 us).  Same-stream launches are ordered, so consecutive calls may share it;
-    another stream or thread gets its own.  A buffer that is outgrown is retired, not freed: a captured hipGraph may still
-    replay launches that point at it."""
-    if M * K > _WS_CACHE_MAX:
-        n = lib.asq_linear_w8a8_workspace_bytes(M, N, K)
-        return torch.empty((n,), dtype=torch.uint8, device=dev), n
+def _workspace(lib, size_fn, M, N, K, dev, stream):
+    """Caller-owned scratch of the GEMM entry points, kept per (thread, device, stream).
+
+    The C-ABI's workspace contract (include/asq_hip.h): a workspace starts with a header (magic word + the arrival tickets of the weight-streaming
+    kernel's in-launch reduction) that asq_workspace_init() writes ONCE; every launch leaves it clean, one launch at a time may use a buffer.  Hence:
+    the buffer is persistent (not torch.empty per call: a fresh allocation has no header), initialised on the stream it is used on when it is
+    created, and never shared across streams or threads.  Same-stream launches are ordered, so consecutive calls of any shape share it.  A buffer
+    that is outgrown is retired, not freed: a captured hipGraph may still replay launches that point at it.  Returns (tensor | None, nbytes)."""
     cache = _ws_tls.__dict__.setdefault("c", {})
-    key = (dev.index, stream, M, N, K)
+    key = (dev.index, stream, size_fn, M, N, K)
     hit = cache.get(key)
     if hit is not None:
         return hit
-    n = lib.asq_linear_w8a8_workspace_bytes(M, N, K)
-    slot = cache.get((dev.index, stream))
-    if slot is None or slot.numel() < n:
-        if n > _WS_CACHE_MAX:
-            return torch.empty((n,), dtype=torch.uint8, device=dev), n
-        if slot is not None:
-            _ws_tls.__dict__.setdefault("retired", []).append(slot)
-        slot = torch.empty((max(2 * n, 1 << 20),), dtype=torch.uint8, device=dev)
-        cache[(dev.index, stream)] = slot
-        for k in [k for k in cache if len(k) == 5 and k[:2] == key[:2]]:   # shape entries of this stream point at the old slot
+    n = getattr(lib, size_fn)(M, N, K)
+    if n == 0:
+        res = (None, 0)
+    elif n > _WS_PERSIST_MAX:
+        buf = torch.empty((n,), dtype=torch.uint8, device=dev)
+        L.check(lib.asq_workspace_init(buf.data_ptr(), n, stream), "asq_workspace_init")
+        return buf, n          # (not cached: one buffer per call, header written ahead of the launch on the same stream)
+    else:
+        slot = cache.get((dev.index, stream))
+        if slot is None or slot.numel() < n:
+            if slot is not None:
+                _ws_tls.__dict__.setdefault("retired", []).append(slot)
+            slot = torch.empty((max(2 * n, 1 << 20),), dtype=torch.uint8, device=dev)
+            L.check(lib.asq_workspace_init(slot.data_ptr(), slot.numel(), stream), "asq_workspace_init")
+            cache[(dev.index, stream)] = slot
+            for k in [k for k in cache if len(k) == 6 and k[:2] == key[:2]]:   # shape entries of this stream point at the old slot
+                del cache[k]
+        res = (slot, n)
+    if len(cache) > 512:
+        for k in [k for k in cache if len(k) == 6]:
             del cache[k]
-    if len(cache) > 256:
-        for k in [k for k in cache if len(k) == 5]:
-            del cache[k]
-    cache[key] = (slot, n)
-    return cache[key]
+    cache[key] = res
+    return res
+
+
+def _gemm_ws(M, N, K, dev, stream):
+    """scratch of a GEMM-only call (None when the shape never needs any)"""
+    return _workspace(L.lib(), "asq_gemm_workspace_bytes", M, N, K, dev, stream)
+
+
+def _forward_ws(lib, M, N, K, dev, stream):
+    """workspace of asq_linear_w8a8_forward (GEMM scratch + int8 activation + row scales)"""
+    return _workspace(lib, "asq_linear_w8a8_workspace_bytes", M, N, K, dev, stream)
 
 
 def _same_device(*ts):
@@ -118,7 +127,7 @@ def gemm_i8_i32(x, w, out):
         raise ValueError(f"shape mismatch: input {tuple(x.shape)}, weight {tuple(w.shape)}, out {tuple(out.shape)}")
     dev = _same_device(x, w, out)
     with _on(dev):
-        ws, n = _gemm_ws(x.shape[0], w.shape[0], x.shape[1], dev)
+        ws, n = _gemm_ws(x.shape[0], w.shape[0], x.shape[1], dev, _stream(x))
         L.check(L.lib().asq_gemm_i8_i32(x.data_ptr(), w.data_ptr(), out.data_ptr(), x.shape[0], w.shape[0], x.shape[1], _ptr(ws), n,
                                         _stream(x)), "asq_gemm_i8_i32")
     return out
@@ -133,7 +142,7 @@ def gemm_i8_i8(x, w, out, alpha, beta=0.0):
         raise ValueError(f"shape mismatch: input {tuple(x.shape)}, weight {tuple(w.shape)}, out {tuple(out.shape)}")
     dev = _same_device(x, w, out)
     with _on(dev):
-        ws, n = _gemm_ws(x.shape[0], w.shape[0], x.shape[1], dev)
+        ws, n = _gemm_ws(x.shape[0], w.shape[0], x.shape[1], dev, _stream(x))
         L.check(L.lib().asq_gemm_i8_i8(x.data_ptr(), w.data_ptr(), out.data_ptr(), x.shape[0], w.shape[0], x.shape[1],
                                        float(alpha), float(beta), _ptr(ws), n, _stream(x)), "asq_gemm_i8_i8")
     return out
@@ -271,7 +280,7 @@ def linear_w8a8(xq, w, out_dtype, s_scalar=1.0, s_row=None, s_col=None, bias=Non
         _bump_version(out)
     dev = _same_device(xq, w, out, s_row, s_col, bias)
     with _on(dev):
-        ws, n = _gemm_ws(M, N, K, dev)
+        ws, n = _gemm_ws(M, N, K, dev, _stream(xq))
         L.check(L.lib().asq_linear_w8a8(xq.data_ptr(), w.data_ptr(), out.data_ptr(), _DT[out_dtype], M, N, K, float(s_scalar),
                                         _ptr(s_row), _ptr(s_col), _ptr(bias),
                                         L.ASQ_EPI_SCALE_FIRST if order == "scale_first" else L.ASQ_EPI_ACC_FIRST, _ptr(ws), n, _stream(xq)),
@@ -298,7 +307,7 @@ def linear_w8a8_q8(xq, w, mid_dtype, s_scalar=1.0, s_row=None, s_col=None, bias=
     out = torch.empty((M, N), dtype=torch.int8, device=xq.device)
     dev = _same_device(xq, w, s_row, s_col, bias)
     with _on(dev):
-        ws, n = _gemm_ws(M, N, K, dev)
+        ws, n = _gemm_ws(M, N, K, dev, _stream(xq))
         L.check(L.lib().asq_linear_w8a8_q8(xq.data_ptr(), w.data_ptr(), out.data_ptr(), _DT[mid_dtype], M, N, K, float(s_scalar), _ptr(s_row), _ptr(s_col),
                                            _ptr(bias), L.ASQ_EPI_SCALE_FIRST if order == "scale_first" else L.ASQ_EPI_ACC_FIRST, 1 if act == "relu" else 0,
                                            _ACT[qmode], float(quant_scale), _ptr(ws), n, _stream(xq)), "asq_linear_w8a8_q8")

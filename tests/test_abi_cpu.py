@@ -39,8 +39,13 @@ def test_argument_errors_without_gpu():
     assert h.asq_gemm_i8_i32(None, None, None, 0, 4, 4, None, 0, None) == 0            # empty problem is a no-op
     assert h.asq_linear_w8a8_workspace_bytes(3, 7, 5) == 256 + 256
     assert h.asq_gemm_workspace_bytes(4096, 4096, 4096) == 0            # 256 tiles fill the chip: no split-K
-    assert h.asq_gemm_workspace_bytes(256, 5120, 20480) == 6 * 256 * 5120 * 4   # OPT-13B fc2: 40 tiles of 128 rows -> 6 K splits (240 blocks)
-    assert h.asq_gemm_workspace_bytes(32, 4096, 4096) == 0              # skinny path
+    hdr = h.asq_workspace_header_bytes()                                # every non-empty workspace starts with the header asq_workspace_init() writes
+    assert hdr == 8192
+    assert h.asq_gemm_workspace_bytes(256, 5120, 20480) == hdr + 6 * 256 * 5120 * 4   # OPT-13B fc2: 40 tiles of 128 rows -> 6 K splits (240 blocks)
+    assert h.asq_gemm_workspace_bytes(32, 4096, 4096) == 0              # first-generation weight stream: no scratch
+    assert h.asq_gemm_workspace_bytes(32, 5120, 20480) == hdr + 256 * 2 * 2 * 8192    # cfg4's per-GPU shape: stream-K, 256 blocks x 2 segments x 16 KB partial tiles
+    assert h.asq_gemm_workspace_bytes(1, 5120, 20480) == 0              # ... but not at one row (the reduction costs more than it saves)
+    assert h.asq_workspace_init(None, 1 << 20, None) == -1 and h.asq_workspace_init(256, 100, None) == -5
     assert h.asq_gemm_kernel_name(4096, 4096, 4096) == b"p8"
     assert h.asq_gemm_kernel_name(64, 14336, 4096) == b"skinny"          # decode batch: weight stream
     assert h.asq_gemm_kernel_name(128, 4096, 4096) == b"skinny"          # 2 m-blocks x 256 channel tiles: the weight stream (11.7 vs 15.0 us)
@@ -58,7 +63,7 @@ def test_argument_errors_without_gpu():
     assert h.asq_gemm_kernel_name(2048, 5120, 5120) == b"p8"             # 160 tiles: the 256-row kernel is the more efficient one
     assert h.asq_gemm_kernel_name(4, 4096, 4095) == b"generic"
     # tail peel: 6 x 43 = 258 tiles of 256 rows -> 252 in the main launch + one tile column as 12 x 2 tiles of 128 x 128
-    assert h.asq_gemm_kernel_name(1536, 11008, 4096) == b"p8+tail" and h.asq_gemm_workspace_bytes(1536, 11008, 4096) == 4 * 1536 * 256 * 4   # 24 tiles of 128 x 128, 4 K splits
+    assert h.asq_gemm_kernel_name(1536, 11008, 4096) == b"p8+tail" and h.asq_gemm_workspace_bytes(1536, 11008, 4096) == hdr + 4 * 1536 * 256 * 4   # 24 tiles of 128 x 128, 4 K splits
     assert h.asq_gemm_kernel_name(3072, 11008, 8192) == b"p4+tail"
     assert h.asq_gemm_kernel_name(1536, 12288, 4096) == b"p8+tail"       # 288 tiles: 6 tile columns (36 tiles' worth) as 128 x 128 tiles
     assert h.asq_gemm_kernel_name(768, 11008, 4096) == b"p8h+tail"       # 258 tiles of 128 rows

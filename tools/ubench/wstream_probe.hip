@@ -40,7 +40,8 @@ int main(int argc, char** argv)
     RC(asq_workspace_init(ws, wsb, nullptr));
     CK(hipDeviceSynchronize());
     std::vector<int32_t> a(128L * 20480), b(128L * 20480);
-    std::vector<uint32_t> hdr(2048);
+    const size_t hdrw = asq_workspace_header_bytes() / 4;
+    std::vector<uint32_t> hdr(hdrw);
 
     if (!strcmp(mode, "check") || !strcmp(mode, "both")) {
         // ragged shapes first (N not a multiple of 128 / 16, M not a multiple of 16), then the grid
@@ -76,9 +77,9 @@ int main(int argc, char** argv)
             long badh = 0;
             for (size_t i = 0; i < n; ++i) badh += ha[i] != hb[i];
             CK(hipFree(srow)); CK(hipFree(bias));
-            CK(hipMemcpy(hdr.data(), ws, 8192, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hdr.data(), ws, hdrw * 4, hipMemcpyDeviceToHost));
             long dirty = 0;
-            for (int i = 4; i < 2048; ++i) dirty += hdr[i] != 0;
+            for (size_t i = 4; i < hdrw; ++i) dirty += hdr[i] != 0;  // accumulator tiles back at zero
             if (bad || badh || dirty) printf("MISMATCH M=%ld N=%ld K=%ld: i32 %ld  f16 %ld  dirty tickets %ld\n", sh.M, sh.N, sh.K, bad, badh, dirty);
             bad_total += bad + badh + dirty;
         }
