@@ -43,6 +43,16 @@ int main(int argc, char** argv)
     const size_t hdrw = asq_workspace_header_bytes() / 4;
     std::vector<uint32_t> hdr(hdrw);
 
+    if (!strcmp(mode, "one")) {  // wstream_probe one M N K [nows]: 40 launches of one shape over rotating weights (for rocprofv3 passes)
+        const long M = atol(argv[2]), N = atol(argv[3]), K = atol(argv[4]);
+        const bool nows = argc > 5 && !strcmp(argv[5], "nows");
+        int nb = (int)(300e6 / ((double)N * K)) + 1; if (nb > NB) nb = NB;
+        for (int i = 0; i < 40; ++i) RC(asq_linear_w8a8(x, w[i % nb], out, ASQ_F16, M, N, K, 1e-4f, nullptr, nullptr, nullptr, 0, nows ? nullptr : ws, nows ? 0 : wsb, nullptr));
+        CK(hipDeviceSynchronize());
+        printf("one: M=%ld N=%ld K=%ld %s, 40 launches over %d weight buffers, kernel class %s, workspace need %zu\n", M, N, K, nows ? "no workspace" : "workspace", nb,
+               asq_gemm_kernel_name(M, N, K), asq_gemm_workspace_bytes(M, N, K));
+        return 0;
+    }
     if (!strcmp(mode, "check") || !strcmp(mode, "both")) {
         // ragged shapes first (N not a multiple of 128 / 16, M not a multiple of 16), then the grid
         std::vector<S> cs = {{3, 200, 256}, {17, 1000, 384}, {33, 130, 128}, {70, 4100, 1024}, {128, 16, 4096}, {5, 129, 128 * 7}};
