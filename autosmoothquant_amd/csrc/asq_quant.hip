@@ -366,7 +366,9 @@ template <int DT> __device__ __forceinline__ v4i vec_pack(const float (&f)[ElemT
 // -- here the previous GEMM's epilogue has already dequantised): h = dt(x + residual) is written to `hout` (the
 // new residual stream) and normalised + quantised in the same pass.
 template <int DT, int NV, bool LAYERNORM, bool PER_TOKEN, bool ADD>
-__global__ void __launch_bounds__(256) norm_quant_cached(const void *__restrict__ xv, const void *__restrict__ resv, void *__restrict__ hout,
+// (xv, resv and hout carry NO __restrict__: the API allows h_out to alias residual or x -- the residual stream updated in place -- and an aliased
+// restrict pointer is undefined behaviour even though every thread loads a vector before it stores the same one)
+__global__ void __launch_bounds__(256) norm_quant_cached(const void *xv, const void *resv, void *hout,
                                                          const void *__restrict__ wv, const void *__restrict__ bv, float eps,
                                                          int8_t *__restrict__ xq, float *__restrict__ s_row, int K)
 {

@@ -60,6 +60,22 @@ def _rope(x, theta=10000.0):
     return out
 
 
+SHARED_INPUT_MIN_ELEMS = 1 << 20   # below this the single fused C-ABI call per module is cheaper than a separate quantiser launch (host-bound regime)
+
+
+def shared_input(x, *mods):
+    """One explicit activation quantisation for modules that read the SAME tensor (q/k/v, gate/up): the reference quantises it inside each
+    forward (layers/nn/linear.py:88-96), three HBM passes over one hidden state.  Returns a QuantizedActivation when `x` is a float tensor
+    large enough to be bandwidth-bound and every module has the same input contract (`input_signature()`), else `x` unchanged.  No caching, no
+    identity or version heuristics: the caller states that the modules share the input by calling this."""
+    if not isinstance(x, torch.Tensor) or x.numel() < SHARED_INPUT_MIN_ELEMS or len(mods) < 2:
+        return x
+    sigs = {m.input_signature() if hasattr(m, "input_signature") else None for m in mods}
+    if len(sigs) != 1 or None in sigs:
+        return x
+    return mods[0].quantize_input(x)
+
+
 class LlamaLayer(torch.nn.Module):
     """Float decoder layer (pre-norm, MHA/GQA with RoPE, SiLU-gated MLP)."""
 
@@ -91,7 +107,8 @@ class LlamaLayer(torch.nn.Module):
             nq, nkv = self.heads * self.hd, self.kv_heads * self.hd
             q, k, v = self.qkv_proj(x).split([nq, nkv, nkv], dim=-1)
         else:
-            q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+            xi = shared_input(x, self.q_proj, self.k_proj, self.v_proj)
+            q, k, v = self.q_proj(xi), self.k_proj(xi), self.v_proj(xi)
         q = q.view(B, S, self.heads, self.hd).transpose(1, 2)
         k = k.view(B, S, self.kv_heads, self.hd).transpose(1, 2)
         v = v.view(B, S, self.kv_heads, self.hd).transpose(1, 2)
@@ -120,11 +137,12 @@ class LlamaLayer(torch.nn.Module):
             x = norm(h)
         if record is not None:
             record["mlp_in"] = x
+        xi = shared_input(x, self.gate_proj, self.up_proj)
         if getattr(self, "fuse_act", False) or alt:  # SiLU * up quantised in one pass; the fp product never reaches HBM
             from .layers.nn.fused import silu_mul_q
-            d = self.down_proj(silu_mul_q(self.gate_proj(x), self.up_proj(x), self.down_proj))
+            d = self.down_proj(silu_mul_q(self.gate_proj(xi), self.up_proj(xi), self.down_proj))
             return DeferredResidual(h, d) if getattr(self, "defer_residual", False) else h + d
-        g = F.silu(self.gate_proj(x)) * self.up_proj(x)
+        g = F.silu(self.gate_proj(xi)) * self.up_proj(xi)
         if record is not None:
             record["down_in"] = g
         return h + self.down_proj(g)
@@ -158,8 +176,16 @@ def qkv_from_parts(q_proj, k_proj, v_proj):
     float weight (per-segment absmax scales, reference linear.py:226-232)."""
     from .layers.nn.linear import W8A8BFP32OFP32QKVLinear
     sizes = [q_proj.out_features, k_proj.out_features, v_proj.out_features]
-    m = W8A8BFP32OFP32QKVLinear(sizes, q_proj.in_features, sum(sizes), False, q_proj.act_quant)
+    parts = (q_proj, k_proj, v_proj)
+    has_bias = [bool(p.use_bias) for p in parts]
+    if any(has_bias) and not all(has_bias):
+        raise ValueError("qkv_from_parts: either all of q/k/v carry a bias or none (a missing one would silently become zeros)")
+    if len({p.act_quant for p in parts}) != 1 or len({p.in_features for p in parts}) != 1:
+        raise ValueError("qkv_from_parts: q/k/v must share act_quant and in_features")
+    m = W8A8BFP32OFP32QKVLinear(sizes, q_proj.in_features, sum(sizes), all(has_bias), q_proj.act_quant)
     m.weight = torch.cat([q_proj.weight, k_proj.weight, v_proj.weight], dim=0)
+    if all(has_bias):   # OPT's biased projections: the fused module's bias is the three biases, concatenated (reference linear.py:236-238)
+        m.bias = torch.cat([p.bias.detach().to(torch.float32) for p in parts])
     for name, part in zip(m._host_scalars, (q_proj, k_proj, v_proj)):
         setattr(m, name, part._buffers["dequant_scale"].detach().clone())
     return m.to(q_proj.weight.device)
@@ -272,10 +298,11 @@ class BaichuanLayer(torch.nn.Module):
         x = self.post_attention_layernorm(h)
         if record is not None:
             record["mlp_in"] = x
-        g = self.gate_proj(x)
+        xi = shared_input(x, self.gate_proj, self.up_proj)
+        g = self.gate_proj(xi)
         if self.int8:
             g = g.to(torch.float16)        # models/baichuan.py:227
-        g = F.silu(g) * self.up_proj(x)
+        g = F.silu(g) * self.up_proj(xi)
         if record is not None:
             record["down_in"] = g
         return h + self.down_proj(g).to(h.dtype)

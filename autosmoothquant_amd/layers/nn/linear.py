@@ -117,6 +117,19 @@ class _W8A8Base(torch.nn.Module):
     def _epilogue_scales(self, device):
         return self._scalar("dequant_scale"), None
 
+    def input_signature(self):
+        """What this module's prologue computes from its input: (quantiser mode, scale).  Modules with equal signatures produce the same int8
+        activation from the same tensor, so one `quantize_input` serves them all."""
+        mode, qs = self._input_mode()
+        return (mode, float(qs))
+
+    def quantize_input(self, x):
+        """The module's own prologue as a separate, explicit step (one asq_quantize_act launch): the QuantizedActivation it returns is accepted by
+        this module and by every module with the same `input_signature()`.  Bit-identical to what forward(x) computes internally."""
+        mode, qs = self._input_mode()
+        xq, s_row = ops.quantize_act(self._flatten(x), mode, qs)
+        return QuantizedActivation(xq, s_row, x.dtype, x.shape[:-1])
+
     def forward_q(self, x, consumer, act=None):
         """This linear, an optional activation (act = "relu": OPT's fc1 -> ReLU -> fc2, reference models/opt.py:127-128) and the
         per-tensor prologue of `consumer` (the next W8A8 linear) in ONE GEMM launch with an int8-out epilogue
@@ -152,15 +165,11 @@ def _prequantized_forward(mod, qa, s_scalar, s_col):
 
 
 def _module_forward(mod, x, mode, qs, s_scalar, s_col):
-    """quantise -> GEMM + epilogue for a floating input.  Large activations go through the shared quantiser (one quantisation per
-    tensor: q/k/v and gate/up reuse it, ops.quantize_act_shared); small ones through the single fused C-ABI call."""
+    """quantise -> GEMM + epilogue for a floating input: every forward quantises its own input, as the reference does
+    (layers/nn/linear.py:88-96).  Callers that KNOW several modules read one tensor (q/k/v, gate/up) quantise it once,
+    explicitly: `qa = mod.quantize_input(x)` and pass `qa` to each (harness.shared_input)."""
     lead = x.shape[:-1]
-    x2 = mod._flatten(x)
-    if ops.act_cache_enabled and x2.numel() >= ops.ACT_CACHE_MIN_ELEMS:
-        xq, s_row = ops.quantize_act_shared(x, x2, mode, qs)
-        out = ops.linear_w8a8(xq, mod.weight, x.dtype, s_scalar, s_row, s_col, mod._bias_on(x.device))
-    else:
-        out = ops.linear_w8a8_forward(x2, mod.weight, mode, qs, s_scalar, s_col, mod._bias_on(x.device))
+    out = ops.linear_w8a8_forward(mod._flatten(x), mod.weight, mode, qs, s_scalar, s_col, mod._bias_on(x.device))
     return out.view(*lead, mod.out_features)
 
 

@@ -163,40 +163,13 @@ def quantize_act(x, mode, quant_scale=1.0):
     return xq, s_row
 
 
-# ---- one quantisation per activation TENSOR, not per consuming module --------------------------------------------
-# The reference's q/k/v (and gate/up) modules each quantise the very same hidden state (layers/nn/linear.py:88-96 runs inside every
-# forward).  The quantised result is a pure function of (tensor contents, mode, quant_scale), so the last one is kept and handed to
-# the next module that is called with the SAME tensor object, unchanged (same ._version), on the same stream: identical bits, one
-# HBM pass instead of three.  Only a weak reference to the input is held; the int8 copy (1 B/element) lives until the next miss.
-import threading
-import weakref
-
-_ACT_CACHE = threading.local()
-ACT_CACHE_MIN_ELEMS = 1 << 20      # below this the single-call fused path is cheaper than two C-ABI calls (host-bound regime)
-import os as _os
-act_cache_enabled = _os.environ.get("ASQ_ACT_CACHE", "1") != "0"     # ASQ_ACT_CACHE=0: every module quantises its own input, like the reference
-
-
-def quantize_act_shared(x_obj, x2d, mode, quant_scale=1.0):
-    """quantize_act(x2d, ...) memoised on the identity / version / stream of `x_obj` (the tensor the module was called with)."""
-    key = (x_obj._version, mode, float(quant_scale), x_obj.dtype, tuple(x_obj.shape), x_obj.data_ptr(), _stream(x2d))
-    ent = getattr(_ACT_CACHE, "ent", None)
-    if ent is not None and ent[0]() is x_obj and ent[1] == key:
-        return ent[2], ent[3]
-    xq, s_row = quantize_act(x2d, mode, quant_scale)
-    try:
-        _ACT_CACHE.ent = (weakref.ref(x_obj), key, xq, s_row)
-    except TypeError:
-        _ACT_CACHE.ent = None
-    return xq, s_row
-
-
 def _bump_version(t):
-    """A raw C-ABI write into a caller-provided tensor must be visible to torch's version counter (the cache above relies on it)."""
+    """A raw C-ABI write into a caller-provided tensor is made visible to torch's version counter (autograd's saved-tensor checks and
+    any caller that keys on ._version).  Inference tensors have no counter: nothing to do."""
     try:
         torch.autograd.graph.increment_version(t)
     except Exception:
-        _ACT_CACHE.ent = None
+        pass
 
 
 def norm_quantize(x, weight, bias=None, eps=1e-5, per_token=False):

@@ -119,8 +119,10 @@ def broadcast_arena(arena, src=0, group=None):
     chunk = arena.total // world
     views = [arena.buf[r * chunk:(r + 1) * chunk] for r in range(world)]
     mine = views[rank]
-    # 1. scatter: chunk r -> rank r (the source keeps its own); G-1 links of the source in parallel
-    dist.scatter(mine, scatter_list=views if rank == src else None, src=src, group=group)
+    # `src` is a GLOBAL rank (torch.distributed's convention for scatter / broadcast); `rank` and the chunk index are group ranks
+    src_in_group = src if group is None else dist.get_group_rank(group, src)
+    # 1. scatter: chunk r -> group rank r (the source keeps its own); G-1 links of the source in parallel
+    dist.scatter(mine, scatter_list=views if rank == src_in_group else None, src=src, group=group)
     # 2. all-gather of the chunks into every arena (input staged: in-place aliasing is backend-specific)
     dist.all_gather_into_tensor(arena.buf, mine.clone(), group=group)
 
@@ -134,19 +136,22 @@ def broadcast_quantized(root, src=0, group=None, device=None, timing=None):
     import time
     world = dist.get_world_size(group)
     arena = QuantArena(root, world)
-    if not arena.mods:
-        return 0
-    dev = device if device is not None else arena.mods[0].weight.device
+    dev = device if device is not None else (arena.mods[0].weight.device if arena.mods else torch.device("cpu"))
 
     def tick():
         if torch.device(dev).type == "cuda":
             torch.cuda.synchronize(dev)
         return time.perf_counter()
+    # the signature collective runs on EVERY rank first -- also on one that found no quantised module (its empty arena hashes to a constant): a
+    # rank that returned early here would leave the others blocked in the all-reduce instead of raising the mismatch
     if not all_ranks_equal(arena.signature, group=group, device=dev):
         raise RuntimeError("broadcast_quantized: ranks hold different module structures (class / buffer names / shapes); "
                            "every rank must build the same quantised model skeleton before the broadcast")
+    if not arena.mods:
+        return 0
     t0 = tick()
-    arena.pack(dev, copy=dist.get_rank(group) == src)
+    src_in_group = src if group is None else dist.get_group_rank(group, src)
+    arena.pack(dev, copy=dist.get_rank(group) == src_in_group)
     t1 = tick()
     dist.barrier(group=group)
     t1b = tick()

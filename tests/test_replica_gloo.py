@@ -136,3 +136,46 @@ def test_broadcast_and_row_sharding_world2():
     ref = _oracle_forward(ref_mods, xg)
     got = np.concatenate([p[2] for p in sorted(res[0][6], key=lambda t: t[0])], axis=0)
     assert np.array_equal(got, ref)
+
+
+def _worker_edge(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from autosmoothquant_amd import replica
+        # A. one rank found no quantised module: every rank must RAISE the structure mismatch (round 2: that rank returned early and the
+        #    others hung in the signature all-reduce)
+        mods = _make_model(seed=rank) if rank != 2 else torch.nn.ModuleDict()
+        try:
+            replica.broadcast_quantized(mods, src=0)
+            raised = False
+        except RuntimeError as e:
+            raised = "different module structures" in str(e)
+        # B. a sub-group whose source is not its first member: `src` is a global rank, chunk indices are group ranks
+        sub = dist.new_group([1, 2])
+        same = None
+        if rank in (1, 2):
+            m2 = _make_model(seed=10 + rank)
+            want = replica.buffers_fingerprint(_make_model(seed=12))
+            replica.broadcast_quantized(m2, src=2, group=sub)
+            same = replica.buffers_fingerprint(m2) == want and float(m2["a"].dequant_scale) == pytest.approx(0.001 * 13)
+        q.put((rank, raised, same))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_broadcast_mismatch_raises_everywhere_and_subgroup_source_world3():
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_edge, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), "every rank must raise the structure mismatch (no hang, no silent return)"
+    assert res[1][2] is True and res[2][2] is True and res[0][2] is None
