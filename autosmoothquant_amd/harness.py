@@ -79,10 +79,13 @@ def shared_input(x, *mods):
 class LlamaLayer(torch.nn.Module):
     """Float decoder layer (pre-norm, MHA/GQA with RoPE, SiLU-gated MLP)."""
 
-    def __init__(self, hidden=4096, inter=11008, heads=32, kv_heads=None, eps=1e-5):
+    rope_theta = 10000.0   # config.json "rope_theta" (HF LlamaConfig default); checkpoint.load_reference_checkpoint sets it per model
+
+    def __init__(self, hidden=4096, inter=11008, heads=32, kv_heads=None, eps=1e-5, rope_theta=10000.0):
         super().__init__()
         kv_heads = kv_heads or heads
         self.hidden, self.heads, self.kv_heads, self.hd = hidden, heads, kv_heads, hidden // heads
+        self.rope_theta = float(rope_theta)
         L = torch.nn.Linear
         self.input_layernorm, self.post_attention_layernorm = RMSNorm(hidden, eps), RMSNorm(hidden, eps)
         self.q_proj, self.k_proj, self.v_proj = L(hidden, heads * self.hd, bias=False), L(hidden, kv_heads * self.hd, bias=False), L(hidden, kv_heads * self.hd, bias=False)
@@ -112,7 +115,7 @@ class LlamaLayer(torch.nn.Module):
         q = q.view(B, S, self.heads, self.hd).transpose(1, 2)
         k = k.view(B, S, self.kv_heads, self.hd).transpose(1, 2)
         v = v.view(B, S, self.kv_heads, self.hd).transpose(1, 2)
-        q, k = _rope(q), _rope(k)
+        q, k = _rope(q, self.rope_theta), _rope(k, self.rope_theta)
         if self.kv_heads != self.heads:
             r = self.heads // self.kv_heads
             k, v = k.repeat_interleave(r, dim=1), v.repeat_interleave(r, dim=1)
@@ -205,7 +208,7 @@ def to_w8a8(layer, scales, quant_config=None, fuse_norm=False, fuse_qkv=False, b
     dev = layer.q_proj.weight.device
     q = LlamaLayer.__new__(LlamaLayer)
     torch.nn.Module.__init__(q)
-    q.hidden, q.heads, q.kv_heads, q.hd = layer.hidden, layer.heads, layer.kv_heads, layer.hd
+    q.hidden, q.heads, q.kv_heads, q.hd, q.rope_theta = layer.hidden, layer.heads, layer.kv_heads, layer.hd, layer.rope_theta
 
     def conv(lin, cls, scale, aq):
         src = torch.nn.Linear(lin.in_features, lin.out_features, bias=False)
@@ -340,3 +343,213 @@ def to_w8a8_baichuan(layer, scales, quant_config=None):
     q.input_layernorm = norm(layer.input_layernorm, scales["attn_in"], cfg["qkv"] == "per-tensor")
     q.post_attention_layernorm = norm(layer.post_attention_layernorm, scales["mlp_in"], cfg["fc1"] == "per-tensor")
     return q
+
+
+# ---------------------------------------------------------------------------------------------
+# OPT-architecture layer (reference models/opt.py): LayerNorm with weight AND bias folded (:20-29), biased q/k/v/out_proj
+# (:78-81), fc1 -> ReLU -> fc2 (:127-128).  The reference borrows OPTDecoderLayer.forward from HF (:131); restated here:
+# pre-LN (do_layer_norm_before, every size but 350m) or post-LN, q scaled by head_dim^-0.5 BEFORE the score product, causal mask.
+# ---------------------------------------------------------------------------------------------
+class OptLayer(torch.nn.Module):
+    def __init__(self, hidden=5120, ffn=20480, heads=40, eps=1e-5, bias=True, do_layer_norm_before=True):
+        super().__init__()
+        self.hidden, self.heads, self.hd, self.pre_ln = hidden, heads, hidden // heads, do_layer_norm_before
+        L = torch.nn.Linear
+        self.q_proj, self.k_proj, self.v_proj, self.out_proj = (L(hidden, hidden, bias=bias) for _ in range(4))
+        self.fc1, self.fc2 = L(hidden, ffn, bias=bias), L(ffn, hidden, bias=bias)
+        self.self_attn_layer_norm, self.final_layer_norm = torch.nn.LayerNorm(hidden, eps), torch.nn.LayerNorm(hidden, eps)
+
+    def forward(self, h, record=None):
+        B, S, _ = h.shape
+        res = h
+        x = self.self_attn_layer_norm(h) if self.pre_ln else h   # a QuantizedActivation when the norm is a LayerNormQ (N1)
+        if record is not None:
+            record["attn_in"] = x
+        xi = shared_input(x, self.q_proj, self.k_proj, self.v_proj)
+        q = self.q_proj(xi) * (self.hd ** -0.5)                  # OPTAttention: query_states = q_proj(x) * scaling
+        k, v = self.k_proj(xi), self.v_proj(xi)
+        q, k, v = (t.view(B, S, self.heads, self.hd).transpose(1, 2) for t in (q, k, v))
+        a = F.scaled_dot_product_attention(q, k, v, is_causal=True, scale=1.0).transpose(1, 2).reshape(B, S, self.hidden)
+        if record is not None:
+            record["o_in"] = a
+        h = res + self.out_proj(a)
+        if not self.pre_ln:
+            h = self.self_attn_layer_norm(h)
+        res = h
+        x = self.final_layer_norm(h) if self.pre_ln else h
+        if record is not None:
+            record["fc1_in"] = x
+        if record is None and hasattr(self.fc1, "forward_q") and getattr(self.fc2, "act_quant", None) == "per-tensor":
+            y = self.fc2(self.fc1.forward_q(x, self.fc2, act="relu"))   # fc1 + ReLU + fc2's prologue in ONE launch (asq_linear_w8a8_q8): bit-identical
+        else:
+            g = F.relu(self.fc1(x))
+            if record is not None:
+                record["fc2_in"] = g
+            y = self.fc2(g)
+        h = res + y
+        return h if self.pre_ln else self.final_layer_norm(h)
+
+
+@torch.no_grad()
+def to_w8a8_opt(layer, scales, quant_config=None, fuse_norm=False):
+    """Quantised copy composed like Int8OPTDecoderLayer.from_float (models/opt.py:133-164): q/k/v, fc1 -> W8A8BFP32OFP32Linear(cfg qkv / fc1),
+    out_proj, fc2 -> W8A8BFP32OFP32LinearWithQuantScale(cfg out / fc2), biases kept, LayerNorm weight AND bias divided by the input scale iff the
+    consumers are per-tensor.  scales: attn_in, o_in, fc1_in, fc2_in.  fuse_norm: the two LayerNorms become LayerNormQ (emit int8 directly, N1)."""
+    cfg = {"qkv": "per-tensor", "out": "per-token", "fc1": "per-tensor", "fc2": "per-token"}
+    cfg.update(quant_config or {})
+    dev = layer.q_proj.weight.device
+    q = OptLayer.__new__(OptLayer)
+    torch.nn.Module.__init__(q)
+    q.hidden, q.heads, q.hd, q.pre_ln = layer.hidden, layer.heads, layer.hd, layer.pre_ln
+
+    def conv(lin, cls, scale, aq):
+        src = torch.nn.Linear(lin.in_features, lin.out_features, bias=lin.bias is not None)
+        src.weight = torch.nn.Parameter(lin.weight.detach().float().clone())  # from_float rounds an fp32 source in place
+        if lin.bias is not None:
+            src.bias = torch.nn.Parameter(lin.bias.detach().float().clone())
+        return cls.from_float(src, scale, save_device=dev, act_quant=aq).to(dev)
+
+    for n in ("q_proj", "k_proj", "v_proj"):
+        setattr(q, n, conv(getattr(layer, n), W8A8BFP32OFP32Linear, scales["attn_in"], cfg["qkv"]))
+    q.out_proj = conv(layer.out_proj, W8A8BFP32OFP32LinearWithQuantScale, scales["o_in"], cfg["out"])
+    q.fc1 = conv(layer.fc1, W8A8BFP32OFP32Linear, scales["fc1_in"], cfg["fc1"])
+    q.fc2 = conv(layer.fc2, W8A8BFP32OFP32LinearWithQuantScale, scales["fc2_in"], cfg["fc2"])
+
+    def norm(n, scale, aq):
+        if fuse_norm:
+            from .layers.nn.fused import LayerNormQ
+            return LayerNormQ.from_float(n, scale, per_token=aq == "per-token")
+        m = torch.nn.LayerNorm(n.normalized_shape[0], n.eps).to(dev, n.weight.dtype)
+        s = scale if aq == "per-tensor" else 1.0
+        m.weight, m.bias = torch.nn.Parameter(n.weight.detach() / s), torch.nn.Parameter(n.bias.detach() / s)
+        return m
+    q.self_attn_layer_norm = norm(layer.self_attn_layer_norm, scales["attn_in"], cfg["qkv"])
+    q.final_layer_norm = norm(layer.final_layer_norm, scales["fc1_in"], cfg["fc1"])
+    return q
+
+
+# ---------------------------------------------------------------------------------------------
+# Mixtral-architecture layer (reference models/mixtral.py): LLaMA-style attention (GQA, RoPE with the config's rope_theta) + a sparse MoE block:
+# float router `gate` (:137, "we do not apply quant to gate"), experts w1 / w3 = W8A8BFP32OFP32Linear(fc1), w2 = ...WithQuantScale(fc2) (:99-101).
+# The reference borrows MixtralSparseMoeBlock.forward (:145): softmax in fp32 -> top-k -> renormalise -> a Python loop of per-expert module
+# calls -> index_add.  Here the routed rows are sorted by expert once and each projection of ALL experts is ONE grouped launch
+# (asq_linear_w8a8_grouped, bit-identical to the per-expert calls) whenever w2 is per-token; per-tensor w2 (one calibrated scale PER expert)
+# falls back to the per-expert loop.
+# ---------------------------------------------------------------------------------------------
+class ExpertMLP(torch.nn.Module):
+    """MixtralBlockSparseTop2MLP: w2(silu(w1 x) * w3 x).  Float linears when built with sizes; `ExpertMLP()` is an empty shell the quantised
+    modules are attached to (to_w8a8_mixtral, checkpoint loader)."""
+
+    def __init__(self, hidden=None, inter=None):
+        super().__init__()
+        if hidden is not None:
+            L = torch.nn.Linear
+            self.w1, self.w2, self.w3 = L(hidden, inter, bias=False), L(inter, hidden, bias=False), L(hidden, inter, bias=False)
+
+    def forward(self, x):
+        return self.w2(F.silu(self.w1(x)) * self.w3(x))
+
+
+class MixtralLayer(LlamaLayer):
+    def __init__(self, hidden=4096, inter=14336, heads=32, kv_heads=8, experts=8, top_k=2, eps=1e-5, rope_theta=1e6):
+        torch.nn.Module.__init__(self)
+        self.hidden, self.heads, self.kv_heads, self.hd, self.rope_theta = hidden, heads, kv_heads, hidden // heads, float(rope_theta)
+        self.top_k = top_k
+        L = torch.nn.Linear
+        self.input_layernorm, self.post_attention_layernorm = RMSNorm(hidden, eps), RMSNorm(hidden, eps)
+        self.q_proj, self.k_proj, self.v_proj = L(hidden, heads * self.hd, bias=False), L(hidden, kv_heads * self.hd, bias=False), L(hidden, kv_heads * self.hd, bias=False)
+        self.o_proj = L(heads * self.hd, hidden, bias=False)
+        self.gate = L(hidden, experts, bias=False)
+        self.experts = torch.nn.ModuleList([ExpertMLP(hidden, inter) for _ in range(experts)])
+
+    def route(self, x2):
+        w = F.softmax(self.gate(x2), dim=1, dtype=torch.float)
+        w, sel = torch.topk(w, self.top_k, dim=-1)
+        w = (w / w.sum(dim=-1, keepdim=True)).to(x2.dtype)
+        flat = sel.reshape(-1)
+        order = torch.sort(flat, stable=True).indices          # routed (token, slot) pairs sorted by expert, token order kept inside an expert
+        counts = torch.bincount(flat, minlength=len(self.experts))
+        return order // self.top_k, w.reshape(-1)[order], counts
+
+    @torch.no_grad()
+    def stack_experts(self):
+        """[E, N, K] stacks of the experts' int8 weights for the grouped launches; the per-expert modules' `weight` buffers become views of
+        the stacks (one copy of every weight in memory), their scalar scales go into device vectors."""
+        ex = self.experts
+        if not hasattr(ex[0].w1, "input_signature"):
+            return self
+        for name in ("w1", "w3", "w2"):
+            mods = [getattr(e, name) for e in ex]
+            st = torch.stack([m.weight for m in mods]).contiguous()
+            for i, m in enumerate(mods):
+                m._buffers["weight"] = st[i]
+            setattr(self, f"_{name}_stack", st)
+            setattr(self, f"_{name}_scale", torch.tensor([float(m._buffers["dequant_scale"]) for m in mods], dtype=torch.float32, device=st.device))
+        return self
+
+    def moe(self, x):
+        B, S, H = x.shape
+        x2 = x.reshape(-1, H)
+        tok, wts, counts = self.route(x2)
+        xs = x2[tok]
+        ex = self.experts
+        grouped = hasattr(self, "_w1_stack") and ex[0].w2.act_quant == "per-token" and xs.is_cuda
+        if grouped:
+            from . import ops
+            offs = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int32)
+            mode, qs = ex[0].w1._input_mode()
+            xq, srow = ops.quantize_act(xs.contiguous(), mode, qs)
+            h1 = ops.linear_w8a8_grouped(xq, self._w1_stack, offs, self._w1_scale, x.dtype, srow)
+            h3 = ops.linear_w8a8_grouped(xq, self._w3_stack, offs, self._w3_scale, x.dtype, srow)
+            aq, arow = ops.quantize_act(F.silu(h1) * h3, "per-token")
+            y = ops.linear_w8a8_grouped(aq, self._w2_stack, offs, self._w2_scale, x.dtype, arow)
+        else:   # the reference's loop (also the float layer's path)
+            y, o = torch.empty_like(xs), 0
+            for e, c in zip(ex, counts.tolist()):
+                if c:
+                    y[o:o + c] = e(xs[o:o + c])
+                o += c
+        out = torch.zeros_like(x2)
+        out.index_add_(0, tok, y * wts[:, None])
+        return out.view(B, S, H)
+
+    def mlp(self, h, record=None):
+        if isinstance(h, DeferredResidual):
+            h = h.materialize()
+        x = self.post_attention_layernorm(h)
+        if record is not None:
+            record["mlp_in"] = x
+        return h + self.moe(x)
+
+
+@torch.no_grad()
+def to_w8a8_mixtral(layer, scales, quant_config=None):
+    """Quantised copy composed like Int8MixtralDecoderLayer.from_float (models/mixtral.py:166-200): attention as LLaMA, every expert's w1 / w3 with
+    the shared moe input scale, w2 with ITS OWN down input scale (`scales["down_in"]`: a list, one per expert), the router left in floating point,
+    RMSNorm weights divided by the input scale iff per-tensor."""
+    cfg = {"qkv": "per-tensor", "out": "per-token", "fc1": "per-tensor", "fc2": "per-token"}
+    cfg.update(quant_config or {})
+    dev = layer.q_proj.weight.device
+    q = MixtralLayer.__new__(MixtralLayer)
+    torch.nn.Module.__init__(q)
+    q.hidden, q.heads, q.kv_heads, q.hd, q.rope_theta, q.top_k = layer.hidden, layer.heads, layer.kv_heads, layer.hd, layer.rope_theta, layer.top_k
+
+    def conv(lin, cls, scale, aq):
+        src = torch.nn.Linear(lin.in_features, lin.out_features, bias=False)
+        src.weight = torch.nn.Parameter(lin.weight.detach().float().clone())
+        return cls.from_float(src, scale, save_device=dev, act_quant=aq).to(dev)
+
+    for n in ("q_proj", "k_proj", "v_proj"):
+        setattr(q, n, conv(getattr(layer, n), W8A8BFP32OFP32Linear, scales["attn_in"], cfg["qkv"]))
+    q.o_proj = conv(layer.o_proj, W8A8BFP32OFP32LinearWithQuantScale, scales["o_in"], cfg["out"])
+    q.gate = layer.gate
+    q.experts = torch.nn.ModuleList()
+    for e, ds in zip(layer.experts, scales["down_in"]):
+        m = ExpertMLP()
+        m.w1 = conv(e.w1, W8A8BFP32OFP32Linear, scales["mlp_in"], cfg["fc1"])
+        m.w3 = conv(e.w3, W8A8BFP32OFP32Linear, scales["mlp_in"], cfg["fc1"])
+        m.w2 = conv(e.w2, W8A8BFP32OFP32LinearWithQuantScale, ds, cfg["fc2"])
+        q.experts.append(m)
+    q.input_layernorm = layer.input_layernorm.folded(scales["attn_in"]) if cfg["qkv"] == "per-tensor" else layer.input_layernorm
+    q.post_attention_layernorm = layer.post_attention_layernorm.folded(scales["mlp_in"]) if cfg["fc1"] == "per-tensor" else layer.post_attention_layernorm
+    return q.stack_experts()

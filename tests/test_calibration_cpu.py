@@ -98,3 +98,52 @@ def test_parse_quant_config(tmp_path):
     p.write_text(json.dumps({"qkv": "per-channel"}))
     with pytest.raises(ValueError):
         parse_quant_config(str(p))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# N3 pinned to the REFERENCE: tests/golden/g9_calib.npz holds what quantize/calibration.py's own get_act_scales and
+# get_static_decoder_layer_scales returned on the toy HF models of tests/calib_toy.py (tests/golden/make_golden_calib.py); the collectors
+# of this package, fed the same token ids in the same order, must return the same numbers.
+# ---------------------------------------------------------------------------------------------------------------------------------------
+import os
+
+G9 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g9_calib.npz")
+
+
+def check_against_reference_fixture(tag, device="cpu", rtol=0.0):
+    import calib_toy
+    z = np.load(G9)
+    model = (calib_toy.build_llama() if tag == "llama" else calib_toy.build_opt()).to(device)
+    mtype = "llama" if tag == "llama" else "transformers"
+    names = [str(n) for n in z[f"{tag}_names"]]
+    ids_act = [torch.from_numpy(z[f"{tag}_ids_act_{j}"]).to(device) for j in range(6)]
+    ids_static = [torch.from_numpy(z[f"{tag}_ids_static_{j}"]).to(device) for j in range(5)]
+    act = get_act_scales(model, ids_act)
+    assert sorted(act) == names                                  # every nn.Linear, the reference's module names (incl. lm_head)
+    for n in names:
+        want = z[f"{tag}_act::{n}"]
+        assert act[n].dtype == torch.float32 and act[n].device.type == "cpu" and act[n].shape == want.shape
+        np.testing.assert_allclose(act[n].numpy(), want, rtol=rtol, atol=0.0, err_msg=n)
+    scales, act_dict = get_static_decoder_layer_scales(model, ids_static, 2, mtype)
+    io = np.array([[act_dict[n]["input"], act_dict[n]["output"]] for n in names])
+    np.testing.assert_allclose(io, z[f"{tag}_io"], rtol=rtol, atol=0.0)
+    keys = [str(k) for k in z[f"{tag}_scale_keys"]]
+    assert sorted(scales[0]) == keys and len(scales) == 2
+    np.testing.assert_allclose(np.array([[s[k] for k in keys] for s in scales]), z[f"{tag}_scales"], rtol=rtol, atol=0.0)
+
+
+@pytest.mark.parametrize("tag", ["llama", "opt"])
+def test_collectors_equal_the_reference_collectors(tag):
+    check_against_reference_fixture(tag)      # same torch CPU kernels on the same inputs: exact
+
+
+def test_reference_dataset_fixture_matches_the_toy_corpus():
+    import calib_toy
+    lines = [json.loads(l)["text"] for l in open(os.path.join(os.path.dirname(G9), "calib_dataset.jsonl"))]
+    assert lines == calib_toy.DATASET
+    # the reference shuffles (seed 42) and truncates: the recorded ids are a permutation of the tokenised corpus prefixes
+    z = np.load(G9)
+    tok = calib_toy.ToyTokenizer()
+    want = sorted(tuple(tok(t, max_length=24, truncation=True).input_ids[0].tolist()) for t in calib_toy.DATASET)
+    got = [tuple(z[f"llama_ids_act_{j}"][0].tolist()) for j in range(6)]
+    assert all(g in want for g in got) and len(set(got)) == 6

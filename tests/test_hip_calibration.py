@@ -47,3 +47,11 @@ def test_calibrate_smooth_quantise_run_on_device():
             h = q(h)
     err = float((h - ref).norm() / ref.norm())
     assert torch.isfinite(h).all() and err < 6e-2, err
+
+
+@pytest.mark.parametrize("tag", ["llama", "opt"])
+def test_device_collectors_reproduce_the_reference_fixture(tag):
+    """The collectors running on HIP tensors against what the REFERENCE's quantize/calibration.py returned on the same toy model and token ids
+    (tests/golden/g9_calib.npz): the device's fp32 GEMMs sum in another order than the recording's CPU run, hence a relative tolerance."""
+    from test_calibration_cpu import check_against_reference_fixture
+    check_against_reference_fixture(tag, device=DEV, rtol=2e-4)
