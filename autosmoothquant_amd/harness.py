@@ -493,7 +493,8 @@ class MixtralLayer(LlamaLayer):
         tok, wts, counts = self.route(x2)
         xs = x2[tok]
         ex = self.experts
-        grouped = hasattr(self, "_w1_stack") and ex[0].w2.act_quant == "per-token" and xs.is_cuda
+        grouped = (hasattr(self, "_w1_stack") and ex[0].w2.act_quant == "per-token" and xs.is_cuda
+                   and H % 128 == 0 and self._w2_stack.shape[-1] % 128 == 0)   # (the grouped launch runs on the tiled kernel: K % 128 == 0)
         if grouped:
             from . import ops
             offs = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int32)

@@ -187,7 +187,7 @@ def moe_forward(h, gate, experts, top_k):
 
 def make_mixtral():
     from transformers.models.mixtral.modeling_mixtral import MixtralConfig, MixtralAttention, MixtralRMSNorm, MixtralRotaryEmbedding
-    H, INTER, HEADS, KVH, L, E, TOPK, V, B, S = 128, 192, 4, 2, 2, 4, 2, 40, 2, 20
+    H, INTER, HEADS, KVH, L, E, TOPK, V, B, S = 128, 256, 4, 2, 2, 4, 2, 40, 2, 20
     cfg = MixtralConfig(hidden_size=H, intermediate_size=INTER, num_attention_heads=HEADS, num_key_value_heads=KVH, num_hidden_layers=L, vocab_size=V,
                         num_local_experts=E, num_experts_per_tok=TOPK, max_position_embeddings=64, rope_theta=1e6, sliding_window=None, rms_norm_eps=1e-5)
     cfg._attn_implementation = "eager"

@@ -178,7 +178,7 @@ def test_loads_the_mixtral_directory():
                 _same_buffers(getattr(ex, n), raw, p + f"block_sparse_moe.experts.{e}.{n}")
             # after stack_experts the module buffers are views of ONE [E, N, K] stack per projection
             assert ex.w1.weight.untyped_storage().data_ptr() == lay._w1_stack.untyped_storage().data_ptr()
-        assert tuple(lay._w2_stack.shape) == (4, 128, 192) and lay._w2_scale.dtype == torch.float32
+        assert tuple(lay._w2_stack.shape) == (4, 128, 256) and lay._w2_scale.dtype == torch.float32
 
 
 def test_loads_the_fp8_llama_directory_and_honours_rope_config(tmp_path):
