@@ -76,6 +76,44 @@ def shared_input(x, *mods):
     return mods[0].quantize_input(x)
 
 
+# ---- independent linears of one input on side streams (measured, OFF by default) ----------------------------------------------------------
+# q/k/v (gate/up) read one activation and write three (two) outputs: nothing orders them but the stream.  On one stream every GEMM ends with a
+# tail (the last tiles draining) and the next one starts with a ramp -- 5-6 us launch to launch at 4096^3 (profiles/r2_clock_power_evidence.md).
+# Forking the 2nd / 3rd module onto side streams and joining afterwards was VERDICT r2's lever 2(c); measured (profiles/r3_gemm_levers.md): the
+# default step goes from 0.2445 to 0.2868 ms (-15 %): three 256-block GEMMs that each want every CU's whole LDS interleave block by block and
+# the fork / join events cost more than the two gaps.  Kept behind ASQ_SIDE_STREAMS=1 for the A/B; results are identical either way.
+import os as _os
+
+SIDE_STREAM_MIN_ROWS = 1024     # below this the GEMMs are short and the fork / join events cost more than the gaps they hide
+side_streams_enabled = _os.environ.get("ASQ_SIDE_STREAMS", "0") == "1"
+_SIDE = {}
+
+
+def concurrent_linears(mods, xi):
+    """[m(xi) for m in mods] with modules 2.. running on side streams (fork after `xi` is ready on the current stream, join before returning)."""
+    t = xi.xq if hasattr(xi, "xq") else xi
+    if (not side_streams_enabled or len(mods) < 2 or not isinstance(t, torch.Tensor) or not t.is_cuda
+            or t.numel() // t.shape[-1] < SIDE_STREAM_MIN_ROWS):
+        return [m(xi) for m in mods]
+    cur = torch.cuda.current_stream(t.device)
+    pool = _SIDE.setdefault((t.device.index, cur.cuda_stream), [])
+    while len(pool) < len(mods) - 1:
+        pool.append(torch.cuda.Stream(device=t.device))
+    fork = torch.cuda.Event()
+    fork.record(cur)
+    outs = [None] * len(mods)
+    for i, m in enumerate(mods[1:], 1):
+        s = pool[i - 1]
+        s.wait_event(fork)
+        with torch.cuda.stream(s):
+            outs[i] = m(xi)
+        outs[i].record_stream(cur)     # allocated on the side stream's pool, consumed (and later freed) on the current stream's timeline
+    outs[0] = mods[0](xi)
+    for s in pool[:len(mods) - 1]:
+        cur.wait_stream(s)
+    return outs
+
+
 class LlamaLayer(torch.nn.Module):
     """Float decoder layer (pre-norm, MHA/GQA with RoPE, SiLU-gated MLP)."""
 
@@ -111,7 +149,7 @@ class LlamaLayer(torch.nn.Module):
             q, k, v = self.qkv_proj(x).split([nq, nkv, nkv], dim=-1)
         else:
             xi = shared_input(x, self.q_proj, self.k_proj, self.v_proj)
-            q, k, v = self.q_proj(xi), self.k_proj(xi), self.v_proj(xi)
+            q, k, v = concurrent_linears([self.q_proj, self.k_proj, self.v_proj], xi)
         q = q.view(B, S, self.heads, self.hd).transpose(1, 2)
         k = k.view(B, S, self.kv_heads, self.hd).transpose(1, 2)
         v = v.view(B, S, self.kv_heads, self.hd).transpose(1, 2)
@@ -141,11 +179,12 @@ class LlamaLayer(torch.nn.Module):
         if record is not None:
             record["mlp_in"] = x
         xi = shared_input(x, self.gate_proj, self.up_proj)
+        gate, up = concurrent_linears([self.gate_proj, self.up_proj], xi)
         if getattr(self, "fuse_act", False) or alt:  # SiLU * up quantised in one pass; the fp product never reaches HBM
             from .layers.nn.fused import silu_mul_q
-            d = self.down_proj(silu_mul_q(self.gate_proj(xi), self.up_proj(xi), self.down_proj))
+            d = self.down_proj(silu_mul_q(gate, up, self.down_proj))
             return DeferredResidual(h, d) if getattr(self, "defer_residual", False) else h + d
-        g = F.silu(self.gate_proj(xi)) * self.up_proj(xi)
+        g = F.silu(gate) * up
         if record is not None:
             record["down_in"] = g
         return h + self.down_proj(g)

@@ -292,12 +292,15 @@ def run_step(mods, spec, xs):
     """One pass over the step's linears.  Linears that read the same activation tensor (q/k/v: one hidden state) get ONE explicit
     quantisation (harness.shared_input -> mod.quantize_input, the caller states the sharing; no cache, no identity heuristics) and one
     GEMM launch each; the others run their whole forward (quantise + GEMM) in one C-ABI call."""
-    from autosmoothquant_amd.harness import shared_input
+    from autosmoothquant_amd.harness import shared_input, concurrent_linears
     groups = {}
     for label, kind, K, N, aq, bias in spec:
         groups.setdefault((K, aq, kind), []).append(label)
-    qa = {key: shared_input(xs[key], *[mods[l] for l in labels]) for key, labels in groups.items()}
-    return [mods[label](qa[(K, aq, kind)]) for label, kind, K, N, aq, bias in spec]
+    outs = {}
+    for key, labels in groups.items():   # (harness.concurrent_linears: side streams only with ASQ_SIDE_STREAMS=1, measured slower)
+        ms = [mods[l] for l in labels]
+        outs.update(zip(labels, concurrent_linears(ms, shared_input(xs[key], *ms))))
+    return [outs[label] for label, kind, K, N, aq, bias in spec]
 
 
 def measure_dominant_kernel(mod, x, iters=10, batch=20, warm=200):
