@@ -486,7 +486,10 @@ int launch_norm_quant(const void *x, const void *w, const void *b, float eps, in
 // reading 3 x and writing s_in + 1).  exp() is exp_det above: bit-identical to oracle/n1.py; against
 // torch's silu (a different exp) the int8 result can differ by +-1 at rounding boundaries.
 // ---------------------------------------------------------------------------------
-template <int DT, int NV, bool PER_TOKEN>
+// FAST (opt-in, ASQ_SILU_FAST flag): silu from the hardware transcendentals -- g * v_rcp_f32(1 + v_exp_f32(-g * log2 e)), ~1 ulp each -- instead of the
+// bit-reproducible exp_det + IEEE division (30 of the 42 VALU instructions per element).  The int8 result then differs from the exact kernel / oracle/n1.py by
+// at most +-1 (bf16: +-2 on < 1e-4 of the elements), where silu(g) * up lies within an fp16 / bf16 ulp of a rounding boundary (tests/test_hip_n1.py).
+template <int DT, int NV, bool PER_TOKEN, bool FAST = false>
 __global__ void __launch_bounds__(256) silu_mul_quant_cached(const void *__restrict__ gv, const void *__restrict__ uv, float quant_scale,
                                                              int8_t *__restrict__ xq, float *__restrict__ s_row, int K)
 {
@@ -514,8 +517,15 @@ __global__ void __launch_bounds__(256) silu_mul_quant_cached(const void *__restr
             if constexpr (!H) vec_unpack<DT>(uw, u);
 #pragma unroll
             for (int j = 0; j < VEC; j += 2) {  // two elements per packed instruction
-                const v2f den = exp_det2<false>((v2f){-g[j], -g[j + 1]}) + 1.0f;
-                const float q0 = __fdiv_rn(g[j], den[0]), q1 = __fdiv_rn(g[j + 1], den[1]);
+                float q0, q1;
+                if constexpr (FAST) {
+                    q0 = g[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g[j] * -1.4426950408889634f));
+                    q1 = g[j + 1] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g[j + 1] * -1.4426950408889634f));
+                } else {
+                    const v2f den = exp_det2<false>((v2f){-g[j], -g[j + 1]}) + 1.0f;
+                    q0 = __fdiv_rn(g[j], den[0]);
+                    q1 = __fdiv_rn(g[j + 1], den[1]);
+                }
                 if constexpr (H) {
                     const v2h sl = {(_Float16)q0, (_Float16)q1};
                     const uint32_t pr = __builtin_bit_cast(uint32_t, sl * __builtin_bit_cast(v2h, (uint32_t)uw[j / 2]));
@@ -577,13 +587,13 @@ __global__ void __launch_bounds__(256) silu_mul_quant_cached(const void *__restr
     }
 }
 
-template <int DT, bool PT>
+template <int DT, bool PT, bool FAST = false>
 int launch_silu_mul_quant(const void *g, const void *u, float qs, int8_t *xq, float *s_row, int64_t M, int64_t K, hipStream_t s)
 {
     constexpr int VEC = ElemT<DT>::VEC;
     const int64_t nvec = K / VEC;
     dim3 grid((unsigned)M), block(256);
-#define ASQ_SM(NV) hipLaunchKernelGGL((silu_mul_quant_cached<DT, NV, PT>), grid, block, 0, s, g, u, qs, xq, s_row, (int)K)
+#define ASQ_SM(NV) hipLaunchKernelGGL((silu_mul_quant_cached<DT, NV, PT, FAST>), grid, block, 0, s, g, u, qs, xq, s_row, (int)K)
     if (nvec <= 256 * 2) ASQ_SM(2);
     else if (nvec <= 256 * 4) ASQ_SM(4);
     else if (nvec <= 256 * 6) ASQ_SM(6);
@@ -669,13 +679,19 @@ extern "C" int asq_silu_mul_quantize(const void *gate, const void *up, int x_dty
     ASQ_REQUIRE(M >= 0 && K > 0 && M < (1ll << 31), ASQ_ERR_DIM, "asq_silu_mul_quantize: bad dims");
     ASQ_REQUIRE(x_dtype == ASQ_F32 || x_dtype == ASQ_F16 || x_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_silu_mul_quantize: bad x_dtype %d", x_dtype);
     if (M == 0) return ASQ_OK;
-    ASQ_REQUIRE(gate && up && xq && (!per_token || s_row), ASQ_ERR_NULL, "asq_silu_mul_quantize: NULL pointer");
+    ASQ_REQUIRE(gate && up && xq && (!(per_token & 1) || s_row), ASQ_ERR_NULL, "asq_silu_mul_quantize: NULL pointer");
     const int vec = x_dtype == ASQ_F32 ? 4 : 8;
     ASQ_REQUIRE(K % vec == 0 && K / vec <= 256 * 8, ASQ_ERR_DIM, "asq_silu_mul_quantize: K must be a multiple of %d and <= %d", vec, 256 * 8 * vec);
     ASQ_REQUIRE(((((uintptr_t)gate | (uintptr_t)up) & 15) == 0) && (((uintptr_t)xq & (vec - 1)) == 0), ASQ_ERR_ALIGN,
                 "asq_silu_mul_quantize: gate / up must be 16-B aligned");
     hipStream_t s = (hipStream_t)stream;
-#define ASQ_SMD(DT_) (per_token ? launch_silu_mul_quant<DT_, true>(gate, up, quant_scale, xq, s_row, M, K, s) : launch_silu_mul_quant<DT_, false>(gate, up, quant_scale, xq, s_row, M, K, s))
+    const bool fast = (per_token & ASQ_SILU_FAST) != 0;
+    per_token &= 1;
+#define ASQ_SMD(DT_)                                                                                                                              \
+    (fast ? (per_token ? launch_silu_mul_quant<DT_, true, true>(gate, up, quant_scale, xq, s_row, M, K, s)                                        \
+                       : launch_silu_mul_quant<DT_, false, true>(gate, up, quant_scale, xq, s_row, M, K, s))                                     \
+          : (per_token ? launch_silu_mul_quant<DT_, true>(gate, up, quant_scale, xq, s_row, M, K, s)                                              \
+                       : launch_silu_mul_quant<DT_, false>(gate, up, quant_scale, xq, s_row, M, K, s)))
     switch (x_dtype) {
     case ASQ_F32: return ASQ_SMD(ASQ_F32);
     case ASQ_F16: return ASQ_SMD(ASQ_F16);

@@ -105,14 +105,15 @@ class LayerNormQ(_NormQ):
 
 
 @torch.no_grad()
-def silu_mul_q(gate, up, consumer):
+def silu_mul_q(gate, up, consumer, fast=False):
     """silu(gate) * up quantised for `consumer` (a W8A8BFP32OFP32LinearWithQuantScale such as down_proj / w2):
-    per-token, or per-tensor with the consumer's calibrated quant_scale.  Returns a QuantizedActivation."""
+    per-token, or per-tensor with the consumer's calibrated quant_scale.  Returns a QuantizedActivation.  fast: ops.silu_mul_quantize's opt-in
+    hardware-transcendental variant."""
     lead = gate.shape[:-1]
     g2, u2 = gate.reshape(-1, gate.shape[-1]), up.reshape(-1, up.shape[-1])
     g2 = g2 if g2.is_contiguous() else g2.contiguous()
     u2 = u2 if u2.is_contiguous() else u2.contiguous()
     per_token = consumer.act_quant == "per-token"
     qs = 1.0 if per_token else float(consumer.quant_scale)
-    xq, s_row = ops.silu_mul_quantize(g2, u2, per_token, qs)
+    xq, s_row = ops.silu_mul_quantize(g2, u2, per_token, qs, fast)
     return QuantizedActivation(xq, s_row, gate.dtype, lead)

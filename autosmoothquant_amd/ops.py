@@ -218,8 +218,9 @@ def add_norm_quantize(x, residual, weight, bias=None, eps=1e-5, per_token=False,
     return h, xq, s_row
 
 
-def silu_mul_quantize(gate, up, per_token=True, quant_scale=1.0):
-    """int8(quantise(silu(gate) * up)) in one pass; returns (xq int8 [M,K], s_row f32 [M] or None)."""
+def silu_mul_quantize(gate, up, per_token=True, quant_scale=1.0, fast=False):
+    """int8(quantise(silu(gate) * up)) in one pass; returns (xq int8 [M,K], s_row f32 [M] or None).  fast=True (opt-in): silu from the hardware
+    transcendentals instead of the bit-reproducible sequence (ASQ_SILU_FAST: at most +-1 int8 against the exact kernel, ~1.3x the throughput)."""
     _dev(gate, "gate"), _dev(up, "up")
     if gate.dtype not in _DT or gate.dim() != 2 or up.dtype != gate.dtype or up.shape != gate.shape:
         raise ValueError("gate and up must be 2-D float tensors of equal shape and dtype")
@@ -227,7 +228,7 @@ def silu_mul_quantize(gate, up, per_token=True, quant_scale=1.0):
     xq = torch.empty((M, K), dtype=torch.int8, device=gate.device)
     s_row = torch.empty((M,), dtype=torch.float32, device=gate.device) if per_token else None
     with _on(gate.device):
-        L.check(L.lib().asq_silu_mul_quantize(gate.data_ptr(), up.data_ptr(), _DT[gate.dtype], 1 if per_token else 0, float(quant_scale),
+        L.check(L.lib().asq_silu_mul_quantize(gate.data_ptr(), up.data_ptr(), _DT[gate.dtype], (1 if per_token else 0) | (2 if fast else 0), float(quant_scale),
                                               xq.data_ptr(), _ptr(s_row), M, K, _stream(gate)), "asq_silu_mul_quantize")
     return xq, s_row
 

@@ -264,9 +264,11 @@ def time_cfg3(layers, x, world, sync_all, steps=2, warmup=1):
     lin_ops = 2.0 * tokens * (4 * 4096 * 4096 + 3 * 4096 * 11008) * len(layers)
     out = {"workload": f"{CFG3}: {WORKLOADS[CFG3][0]}", "tokens_per_step_per_gpu": tokens, "layers": len(layers), "steps": steps, "warmup": warmup,
            "linear_ops_per_step_per_gpu": lin_ops, "roofline_floor_s_at_5033_TOPS": lin_ops / 5033e12}
-    for tag, fused in (("reference_composition", False), ("fused_n1", True)):
+    # fused_n1_fast_silu: the same with the opt-in hardware-transcendental SiLU*up quantiser (ASQ_SILU_FAST: +-1 int8 at rounding boundaries)
+    for tag, fused, fast in (("reference_composition", False, False), ("fused_n1", True, False), ("fused_n1_fast_silu", True, True)):
         for l in layers:
             l.use_fused = fused
+            l.fast_silu = fast
             l.defer_residual = fused    # residual adds move into asq_add_norm_quantize (N1, reference csrc/kernels/fused.cu:5-25)
         for _ in range(warmup):
             run_layers(layers, x)
@@ -284,7 +286,7 @@ def time_cfg3(layers, x, world, sync_all, steps=2, warmup=1):
                     "linear_TOPS": round(lin_ops * world * steps / el / 1e12, 1),
                     "linear_frac_of_peak_per_gpu": round(lin_ops * steps / el / 1e12 / PEAK_INT8_TOPS, 4)}
     for l in layers:
-        l.use_fused = l.defer_residual = False
+        l.use_fused = l.defer_residual = l.fast_silu = False
     return out
 
 
@@ -638,6 +640,9 @@ def main():
         if cfg3:
             # the metric's "tokens/sec, LLaMA-7B W8A8 fwd" half: whole 32-layer forward incl. the torch attention / norm glue
             out["cfg3"] = cfg3
+            # BASELINE configs[2] at the top level of the line: the reference's module composition and the N1-fused path (bit-exact kernels) side by side
+            out["cfg3_tokens_per_s"] = cfg3["reference_composition"]["tokens_per_s"]
+            out["cfg3_fused_n1_tokens_per_s"] = cfg3["fused_n1"]["tokens_per_s"]
             out["step_tokens_per_s"] = out["tokens_per_s"]
             out["tokens_per_s"] = cfg3["reference_composition"]["tokens_per_s"]
             out["config"]["workload"] += f"  +  {cfg3['workload']} (block 'cfg3': tokens_per_s = its whole-forward rate in the reference's module composition)"

@@ -119,6 +119,31 @@ def test_silu_mul_quantize_every_16bit_gate(dt, per_token):
             assert np.array_equal(s.cpu().numpy(), rs.reshape(-1), equal_nan=True)
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("per_token", [True, False])
+def test_silu_mul_quantize_fast_variant_is_within_one_of_the_oracle(dt, per_token):
+    """The opt-in ASQ_SILU_FAST kernel (hardware v_exp_f32 / v_rcp_f32 instead of the bit-reproducible sequence): never more than +-1 int8 away from the
+    oracle-exact result (+-2 for a handful of bf16 elements), and only on a small fraction of the elements (where silu(g) * up sits within an ulp of a rounding boundary); the per-token
+    scale within one ulp of the activation dtype."""
+    from autosmoothquant_amd import ops
+    for si, (M, K) in enumerate([(9, 704), (33, 11008), (70, 2048)]):
+        if dt == "f32" and K > 8192:
+            continue
+        rng = np.random.default_rng(600 + si)
+        g = O.round_to(rng.standard_normal((M, K)).astype(np.float32) * 4, dt)
+        u = O.round_to(rng.standard_normal((M, K)).astype(np.float32) * 4, dt)
+        g[0, :6] = O.round_to(np.array([0.0, -0.0, 30.0, -30.0, 88.0, -100.0], np.float32), dt)
+        xq, s = ops.silu_mul_quantize(_t(g, dt), _t(u, dt), per_token, 0.21, fast=True)
+        rq, rs = n1.silu_mul_quant_kernel_order(g, u, dt, per_token, 0.21)
+        d = np.abs(xq.cpu().numpy().astype(np.int32) - rq.astype(np.int32))
+        # f16 / f32: +-1.  bf16: silu and the product are each rounded to 8 significant bits, so a 1-ulp silu can move the bf16 quotient by two of its
+        # 0.5-wide steps near |x / s| = 64..127: +-2 there, +-1 everywhere else
+        assert d.max() <= (2 if dt == "bf16" else 1), (dt, M, K, int(d.max()))
+        assert (d > 1).mean() <= 1e-4 and (d != 0).mean() <= (2e-2 if per_token else 5e-3), (dt, M, K, float((d != 0).mean()))
+        if per_token:
+            np.testing.assert_allclose(s.cpu().numpy(), rs.reshape(-1), rtol={"f16": 1e-3, "bf16": 8e-3, "f32": 1e-6}[dt])
+
+
 @pytest.mark.parametrize("c", [c for c in goldenio.load_g8() if c["kind"] in ("lnq", "rmsq")], ids=lambda c: c["id"])
 def test_reference_fixtures_through_hip(c):
     """The reference's own LayerNormQ / folded-RMSNorm+round inputs through the HIP kernel: equal to the oracle exactly and to the
