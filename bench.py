@@ -59,6 +59,8 @@ WORKLOADS = {
                         "routed to 8 experts, ONE grouped launch per projection (BASELINE configs[4])", 8192, "moe"),
     "opt13b_fc2": ("OPT-13B fc2 W8A8BFP32OFP32LinearWithQuantScale 20480->5120 +bias, per-token, 256 rows per GPU", 256,
                    [("fc2", "quantscale", 20480, 5120, "per-token", True)]),
+    "opt13b_fc2_m32": ("OPT-13B fc2 20480->5120 +bias, per-token, 32 rows per GPU (BASELINE configs[3]: batch 256 sharded over 8 GPUs)", 32,
+                       [("fc2", "quantscale", 20480, 5120, "per-token", True)]),
 }
 
 
@@ -416,8 +418,12 @@ def cpu_baseline(spec, M_sample, dtype_tag, budget_s=8.0, mods=None, xs=None):
         return {"backend": backend, "threads": threads, "reps": len(ts), "TOPS_median": round(ops_pass / med / 1e12, 5), "TOPS_mean": round(ops_pass * len(ts) / sum(ts) / 1e12, 5),
                 "tokens_per_s": round(M_sample / med, 1), "s_total": round(sum(ts), 2)}
 
-    primary = leg("torch", ncpu, budget_s)
-    secondary = [leg("torch", 1, budget_s / 3), leg("c", ncpu, budget_s / 3)]
+    # every leg runs on every box (no auto-pick); `value` is the best of them, named in `sample`.  On a 256-thread host the all-threads oneDNN GEMM of
+    # a 256-row sample is oversubscribed (0.07 TOPS against 0.67 on ONE thread), hence the quarter-of-the-threads leg
+    legs = [leg("torch", ncpu, budget_s / 2), leg("torch", max(1, ncpu // 4), budget_s / 4), leg("torch", 1, budget_s / 4), leg("c", ncpu, budget_s / 4)]
+    ok = [l for l in legs if "TOPS_median" in l]
+    primary = max(ok, key=lambda l: l["TOPS_median"]) if ok else legs[0]
+    secondary = [l for l in legs if l is not primary]
     O.set_igemm_backend("numpy")
     cpu_model = "unknown"
     try:
@@ -427,9 +433,10 @@ def cpu_baseline(spec, M_sample, dtype_tag, budget_s=8.0, mods=None, xs=None):
                 break
     except Exception:
         pass
-    return {"value": primary.get("TOPS_median"), "unit": "TOPS", "cores": ncpu, "kind": "port",
+    return {"value": primary.get("TOPS_median"), "unit": "TOPS", "cores": primary.get("threads"), "kind": "port",
             "tokens_per_s": primary.get("tokens_per_s"),
-            "sample": f"oracle/w8a8.py module forwards (exact int GEMM = torch._int_mm, {ncpu} host threads, median of {primary.get('reps')} passes) on the first {M_sample} rows of the "
+            "sample": f"oracle/w8a8.py module forwards (exact int GEMM backend {primary.get('backend')!r}, {primary.get('threads')} of {ncpu} host threads: the fastest of the fixed legs, "
+                      f"median of {primary.get('reps')} passes) on the first {M_sample} rows of the "
                       f"{'step' + chr(39) + 's own quantised weights and activations' if real else 'same shapes (synthetic operands)'}, {len(spec)} linears, {primary.get('s_total')} s",
             "primary": primary, "secondary": secondary, "cpu_model": cpu_model, "os_cpu_count": ncpu, "torch": torch.__version__}
 
@@ -542,11 +549,17 @@ def main():
     if args.graph:
         # hipGraph capture of one whole step on a side stream (torch.cuda.CUDAGraph = hipGraph on ROCm); the C-ABI
         # launches on torch's current stream, so its kernels are captured like any torch op
-        for _ in range(3):
-            step()
+        # Warm-up ON the capture stream (torch's own recipe): the per-stream workspace and its one-time asq_workspace_init launch then exist before the
+        # capture begins (created inside it, the init launch would be recorded and replayed with every step: harmless, one launch too many)
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, stream=cap):
             graph_out = step()
         eager_step, step = step, graph.replay
     if args.settle_ms > 0:   # sustained-load clock first (not part of the W warmup / K timed steps)
