@@ -71,6 +71,36 @@ def test_argument_errors_without_gpu():
     assert h.asq_gemm_kernel_name(65536, 11008, 4096) == b"p8"           # cfg3: 43 full waves
 
 
+def test_dispatcher_on_the_model_shapes():
+    """Which kernel class every linear of the BASELINE configs gets at the row counts that matter (VERDICT r2 hygiene 12): the dispatcher is a measured
+    table, so a change that moves one of these is a deliberate re-measurement, not an accident.  (rows, N, K) -> class; '+ws' = needs a workspace."""
+    from autosmoothquant_amd import _lib
+    h = _lib.lib()
+    hdr = h.asq_workspace_header_bytes()
+    llama = {"qkvo": (4096, 4096), "gate_up": (11008, 4096), "down": (4096, 11008), "qkv_fused": (12288, 4096)}
+    opt = {"qkvo": (5120, 5120), "fc1": (20480, 5120), "fc2": (5120, 20480)}
+    mixtral = {"w1_w3": (14336, 4096), "w2": (4096, 14336), "kv": (1024, 4096)}
+    want = {
+        # decode / cfg1 / cfg4 per GPU: the weight stream
+        (1, "llama"): "skinny", (4, "llama"): "skinny", (32, "llama"): "skinny",
+        (1, "opt"): "skinny", (32, "opt"): "skinny", (1, "mixtral"): "skinny", (32, "mixtral"): "skinny",
+        # prefill chunks / cfg3: the 256 x 256 tile (4 waves once K >= 8192)
+        (4096, "llama"): {"qkvo": "p8", "gate_up": "p8", "down": "p4", "qkv_fused": "p8"},
+        (65536, "llama"): {"qkvo": "p8", "gate_up": "p8", "down": "p4", "qkv_fused": "p8"},
+    }
+    for (rows, fam), cls in want.items():
+        for name, (N, K) in {"llama": llama, "opt": opt, "mixtral": mixtral}[fam].items():
+            got = h.asq_gemm_kernel_name(rows, N, K).decode()
+            exp = cls if isinstance(cls, str) else cls[name]
+            assert got == exp, (rows, fam, name, got, exp)
+    # the stream-K variant of the weight stream (asq_gemm_wstream.h) is chosen by its workspace need: long-K weights at >= 16 rows only
+    streamk = {(r, N, K): h.asq_gemm_workspace_bytes(r, N, K) > hdr for r in (1, 8, 16, 32, 64) for (N, K) in (opt["fc2"], mixtral["w2"], llama["down"], llama["qkvo"], llama["gate_up"])
+               if h.asq_gemm_kernel_name(r, N, K) == b"skinny"}
+    assert {k for k, v in streamk.items() if v} == {(16, 5120, 20480), (32, 5120, 20480), (64, 4096, 14336)}
+    # cfg4 at 256 rows on one GPU and mid-size prefill: the 128-row tiles with a K split
+    assert h.asq_gemm_kernel_name(256, 5120, 20480) == b"p8h" and h.asq_gemm_kernel_name(512, 4096, 4096) == b"p8q"
+
+
 def test_ops_refuse_cpu_tensors_loudly():
     from autosmoothquant_amd import ops
     from autosmoothquant_amd._CUDA import I8CUGEMM
