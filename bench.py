@@ -582,6 +582,36 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the same step with q / k / v as ONE GEMM over the three modules' stacked int8 rows (the reference's own W8A8BFP32OFP32QKVLinear class,
+    # harness.qkv_from_parts: bit-identical outputs, two launch-to-launch gaps fewer).  Reported beside the main value, never instead of it.
+    fused_qkv = None
+    if not (layer_mode or moe_mode) and not args.graph and all(l in mods for l in ("q", "k", "v")):
+        from autosmoothquant_amd.harness import qkv_from_parts
+        qkv = qkv_from_parts(mods["q"], mods["k"], mods["v"])
+        xk = next(key for key in xs if key[0] == mods["q"].in_features and key[2] == "linear")
+        rest = [(label, kind, K, N, aq, bias) for (label, kind, K, N, aq, bias) in spec if label not in ("q", "k", "v")]
+        sizes = [mods[l].out_features for l in ("q", "k", "v")]
+        y3 = qkv(xs[xk]).split(sizes, dim=-1)
+        assert all(torch.equal(a, mods[l](xs[xk])) for a, l in zip(y3, ("q", "k", "v"))), "fused QKV launch != the three modules"
+
+        def fstep():
+            return [qkv(xs[xk])] + [mods[label](xs[(K, aq, kind)]) for label, kind, K, N, aq, bias in rest]
+        for _ in range(max(args.warmup, 20)):
+            fstep()
+        sync_all()
+        tf = time.perf_counter()
+        for _ in range(args.steps):
+            fstep()
+        sync_all()
+        ef = time.perf_counter() - tf
+        if world > 1:
+            t = torch.tensor([ef], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ef = float(t.item())
+        fused_qkv = {"ms_per_step": round(ef / args.steps * 1e3, 4), "TOPS": round(sum(2.0 * M * N * K for (_, _, K, N, _, _) in spec) * world * args.steps / ef / 1e12, 1),
+                     "composition": "q/k/v as one W8A8BFP32OFP32QKVLinear over the same int8 rows (outputs bit-identical, asserted)"}
+        del qkv
+
     cfg3 = time_cfg3(cfg3_layers, cfg3_x, world, sync_all) if cfg3_layers is not None else None
     del cfg3_layers, cfg3_x
 
@@ -659,6 +689,8 @@ def main():
             out["step_tokens_per_s"] = out["tokens_per_s"]
             out["tokens_per_s"] = cfg3["reference_composition"]["tokens_per_s"]
             out["config"]["workload"] += f"  +  {cfg3['workload']} (block 'cfg3': tokens_per_s = its whole-forward rate in the reference's module composition)"
+        if fused_qkv:
+            out["step_fused_qkv"] = fused_qkv
         if bcast:
             out["weight_broadcast"] = bcast
         if moe_extra:
