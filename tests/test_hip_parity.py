@@ -485,6 +485,95 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_stream_k_weight_stream_in_its_dispatch_region(dev):
+    """gemm_i8_wstream (stream-K over 128-channel groups, in-launch ticket reduction; asq_gemm_wstream.h) at the shapes the dispatcher gives it --
+    cfg4's per-GPU shape 32 x 5120 x 20480 (+ 16 rows) and Mixtral's w2 at 64 rows: exact int32 against the first-generation kernel (same call
+    without a workspace; itself pinned to the oracle at these sizes by the checksum tests), exact fp16 epilogue with row scales and bias, three
+    launches in a row and a hipGraph replay (the tickets must return to zero each time), header clean afterwards."""
+    from autosmoothquant_amd import ops, _lib as L
+    lib = L.lib()
+    hdr = lib.asq_workspace_header_bytes()
+    st = torch.cuda.current_stream().cuda_stream
+    for (M, N, K) in [(32, 5120, 20480), (16, 5120, 20480), (17, 5120, 20480), (64, 4096, 14336)]:
+        n = lib.asq_gemm_workspace_bytes(M, N, K)
+        assert n > hdr, (M, N, K)                                            # the stream-K kernel is what this shape gets
+        x = torch.from_numpy(detrng.int8_uniform(170, M, (M, K))).to(dev)
+        w = torch.from_numpy(detrng.int8_uniform(171, N % 997, (N, K))).to(dev)
+        ref = torch.empty((M, N), dtype=torch.int32, device=dev)
+        L.check(lib.asq_gemm_i8_i32(x.data_ptr(), w.data_ptr(), ref.data_ptr(), M, N, K, None, 0, st), "first generation")
+        ws = torch.full((n,), 0xA5, dtype=torch.uint8, device=dev)           # garbage first: the header comes from asq_workspace_init alone
+        L.check(lib.asq_workspace_init(ws.data_ptr(), n, st), "init")
+        for rep in range(3):
+            out = torch.full((M, N), -1, dtype=torch.int32, device=dev)
+            L.check(lib.asq_gemm_i8_i32(x.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, ws.data_ptr(), n, st), "stream-K")
+            assert torch.equal(out, ref), (M, N, K, rep)
+        assert int(ws[16:hdr].view(torch.int32).abs().max()) == 0            # tickets back at zero
+        s_row = (torch.rand(M, device=dev) * 0.01 + 1e-3)
+        bias = torch.randn(N, device=dev)
+        y0 = torch.empty((M, N), dtype=torch.float16, device=dev)
+        y1 = torch.empty_like(y0)
+        a = (x.data_ptr(), w.data_ptr())
+        L.check(lib.asq_linear_w8a8(*a, y0.data_ptr(), L.ASQ_F16, M, N, K, 2e-3, s_row.data_ptr(), None, bias.data_ptr(), 0, None, 0, st), "f16 first generation")
+        L.check(lib.asq_linear_w8a8(*a, y1.data_ptr(), L.ASQ_F16, M, N, K, 2e-3, s_row.data_ptr(), None, bias.data_ptr(), 0, ws.data_ptr(), n, st), "f16 stream-K")
+        assert torch.equal(y0, y1), (M, N, K)
+    # the module path (ops keeps an initialised workspace per stream) and a captured graph replayed three times
+    M, N, K = 32, 5120, 20480
+    xf = (torch.randn(M, K, device=dev) * 20).half()
+    w = torch.from_numpy(detrng.int8_uniform(172, 7, (N, K))).to(dev)
+    bias = torch.randn(N, device=dev)
+    want = ops.linear_w8a8_forward(xf, w, "per-token", 1.0, 1e-3, None, bias)
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        ops.linear_w8a8_forward(xf, w, "per-token", 1.0, 1e-3, None, bias)
+    torch.cuda.current_stream().wait_stream(cap)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cap):
+        got = ops.linear_w8a8_forward(xf, w, "per-token", 1.0, 1e-3, None, bias)
+    for _ in range(3):
+        got.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+
+
+def test_stream_k_everywhere_and_the_workspace_contract_in_child_processes(dev):
+    """ASQ_SK_IMPL=1 sends EVERY few-row shape the kernel can run to it (ragged N, rows not a multiple of 16, one K unit, blocks spanning several
+    groups, fewer units than CUs): exact against the oracle.  And the contract's loud failure: a workspace that never went through
+    asq_workspace_init makes the launch trap (the process dies with a HIP error) instead of returning wrong sums."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import detrng
+from oracle import w8a8 as O
+from autosmoothquant_amd import _lib as L
+lib = L.lib(); dev = torch.device("cuda:0"); st = torch.cuda.current_stream().cuda_stream
+mode = sys.argv[1]
+shapes = [(3, 200, 256), (17, 1000, 384), (33, 130, 128), (70, 4100, 1024), (128, 16, 4096), (5, 129, 896), (32, 4096, 4096), (1, 11008, 4096), (100, 512, 2048)]
+for (M, N, K) in shapes:
+    n = lib.asq_gemm_workspace_bytes(M, N, K)
+    assert n > lib.asq_workspace_header_bytes(), (M, N, K, n)
+    x, w = detrng.int8_uniform(180, M, (M, K)), detrng.int8_uniform(181, N, (N, K))
+    xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    ws = torch.full((n,), 0x5A, dtype=torch.uint8, device=dev)
+    if mode == "ok":
+        L.check(lib.asq_workspace_init(ws.data_ptr(), n, st), "init")
+    for rep in range(2):
+        out = torch.empty((M, N), dtype=torch.int32, device=dev)
+        L.check(lib.asq_gemm_i8_i32(xd.data_ptr(), wd.data_ptr(), out.data_ptr(), M, N, K, ws.data_ptr(), n, st), "stream-K")
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), O.igemm(x, w)), (M, N, K, rep)
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, ASQ_SK_IMPL="1")
+    r = subprocess.run([sys.executable, "-c", code, "ok"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-c", code, "uninitialised"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "ok" not in r.stdout, "a launch on an uninitialised workspace must fail loudly"
+
+
 def test_forward_workspace_cache_streams_growth_and_graph_replay(dev):
     """Decode-sized module calls reuse one workspace per (thread, device, stream): results stay exact when the shapes
     grow (the slot is re-allocated), when two streams run interleaved, and when a hipGraph captured against an outgrown
