@@ -28,11 +28,17 @@ extern "C" const char *asq_last_error(void) { return g_err; }
 static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // workspace layout: [ GEMM workspace: header (asq_workspace_init) + scratch, padded to 256 | xq int8 M*K | pad to 256 | s_row f32 M | pad to 256 ]
-// The header sits at offset 0 whatever the shape, so one initialised buffer serves every call that fits into it.
+// The header sits at offset 0 whatever the shape -- also for shapes whose GEMM needs no scratch -- so one initialised buffer serves every call
+// that fits into it and no call writes activations over the header another call's kernel will read.
+static inline size_t forward_gemm_part(int64_t M, int64_t N, int64_t K)
+{
+    const size_t g = asq_gemm_workspace_bytes(M, N, K);
+    return round_up(g > asq_workspace_header_bytes() ? g : asq_workspace_header_bytes(), 256);
+}
 extern "C" size_t asq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K)
 {
     if (M < 0 || K < 0 || N < 0) return 0;
-    return round_up(asq_gemm_workspace_bytes(M, N, K), 256) + round_up((size_t)M * (size_t)K, 256) + round_up((size_t)M * 4, 256);
+    return forward_gemm_part(M, N, K) + round_up((size_t)M * (size_t)K, 256) + round_up((size_t)M * 4, 256);
 }
 
 extern "C" int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t *w, void *out, int64_t M, int64_t N, int64_t K,
@@ -45,9 +51,10 @@ extern "C" int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t 
     ASQ_REQUIRE(workspace != nullptr && workspace_bytes >= need, ASQ_ERR_WORKSPACE,
                 "asq_linear_w8a8_forward: workspace %zu B < required %zu B", workspace_bytes, need);
     ASQ_REQUIRE(((uintptr_t)workspace & 255) == 0, ASQ_ERR_ALIGN, "asq_linear_w8a8_forward: workspace must be 256-B aligned");
-    const size_t gbytes = round_up(asq_gemm_workspace_bytes(M, N, K), 256);
-    const bool with_gemm_ws = gbytes > 0 && workspace_bytes >= gbytes + need;  // a smaller buffer is [ xq | s_row ] only
-    char *base = (char *)workspace + (with_gemm_ws ? gbytes : 0);
+    const size_t gbytes = forward_gemm_part(M, N, K);
+    const bool full = workspace_bytes >= gbytes + need;  // a smaller buffer is [ xq | s_row ] only: no header, no GEMM scratch
+    const bool with_gemm_ws = full && asq_gemm_workspace_bytes(M, N, K) > 0;
+    char *base = (char *)workspace + (full ? gbytes : 0);
     int8_t *xq = (int8_t *)base;
     float *s_row = (float *)(base + round_up((size_t)M * (size_t)K, 256));
     int rc = asq_quantize_act(x, x_dtype, act_mode, quant_scale, xq, s_row, M, K, stream);

@@ -65,16 +65,24 @@ def _workspace(lib, size_fn, M, N, K, dev, stream):
     kernel's in-launch reduction) that asq_workspace_init() writes ONCE; every launch leaves it clean, one launch at a time may use a buffer.  Hence:
     the buffer is persistent (not torch.empty per call: a fresh allocation has no header), initialised on the stream it is used on when it is
     created, and never shared across streams or threads.  Same-stream launches are ordered, so consecutive calls of any shape share it.  A buffer
-    that is outgrown is retired, not freed: a captured hipGraph may still replay launches that point at it.  Returns (tensor | None, nbytes)."""
+    that is outgrown is retired, not freed: a captured hipGraph may still replay launches that point at it.  While the stream is being CAPTURED
+    nothing is created in the cache (an asq_workspace_init recorded into a graph has not run: the next eager call on that stream handle would
+    find a header-less buffer and trap): a capture without a warmed-up buffer gets a graph-owned one whose init is part of the graph.
+    Returns (tensor | None, nbytes)."""
     cache = _ws_tls.__dict__.setdefault("c", {})
     key = (dev.index, stream, size_fn, M, N, K)
     hit = cache.get(key)
     if hit is not None:
         return hit
     n = getattr(lib, size_fn)(M, N, K)
+    capturing = n != 0 and torch.cuda.is_current_stream_capturing()
+    if capturing:
+        slot = cache.get((dev.index, stream))
+        if slot is not None and slot.numel() >= n:
+            return slot, n
     if n == 0:
         res = (None, 0)
-    elif n > _WS_PERSIST_MAX:
+    elif n > _WS_PERSIST_MAX or capturing:
         buf = torch.empty((n,), dtype=torch.uint8, device=dev)
         L.check(lib.asq_workspace_init(buf.data_ptr(), n, stream), "asq_workspace_init")
         return buf, n          # (not cached: one buffer per call, header written ahead of the launch on the same stream)

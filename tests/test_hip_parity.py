@@ -521,6 +521,8 @@ def test_stream_k_weight_stream_in_its_dispatch_region(dev):
     xf = (torch.randn(M, K, device=dev) * 20).half()
     w = torch.from_numpy(detrng.int8_uniform(172, 7, (N, K))).to(dev)
     bias = torch.randn(N, device=dev)
+    # a shape whose GEMM needs no scratch goes first on the same stream: its int8 activations must not land on the shared buffer's header
+    ops.linear_w8a8_forward(xf[:, :4096].contiguous(), w[:4096, :4096].contiguous(), "per-token", 1.0, 1e-3, None, None)
     want = ops.linear_w8a8_forward(xf, w, "per-token", 1.0, 1e-3, None, bias)
     cap = torch.cuda.Stream()
     cap.wait_stream(torch.cuda.current_stream())
@@ -535,6 +537,21 @@ def test_stream_k_weight_stream_in_its_dispatch_region(dev):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(got, want)
+    # a capture WITHOUT a warm-up on its stream: the graph owns its workspace (init recorded with it); the eager call that follows on the same
+    # stream handle must not inherit a buffer whose header was only recorded, never written
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s2):
+        got2 = ops.linear_w8a8_forward(xf, w, "per-token", 1.0, 1e-3, None, bias)
+    with torch.cuda.stream(s2):
+        eager = ops.linear_w8a8_forward(xf, w, "per-token", 1.0, 1e-3, None, bias)
+    torch.cuda.synchronize()
+    assert torch.equal(eager, want)
+    for _ in range(2):
+        g2.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got2, want)
 
 
 def test_stream_k_everywhere_and_the_workspace_contract_in_child_processes(dev):
