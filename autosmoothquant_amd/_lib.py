@@ -32,6 +32,8 @@ SIGNATURES = {
     "asq_linear_w8a8": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _int, _vp, _sz, _vp]),
     "asq_linear_w8a8_q8": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _int, _int, _int, _f32, _vp, _sz, _vp]),
     "asq_linear_w8a8_grouped": (_int, [_vp, _vp, _vp, _int, _vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "asq_grouped_workspace_bytes": (_sz, [_i64, _i64, _i64, _int]),
+    "asq_linear_w8a8_grouped_ws": (_int, [_vp, _vp, _vp, _int, _vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "asq_linear_w8a8_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "asq_linear_w8a8_forward": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _int, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "asq_gemm_kernel_name": (ctypes.c_char_p, [_i64, _i64, _i64]),

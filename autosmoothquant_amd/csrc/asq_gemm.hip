@@ -140,8 +140,21 @@ extern "C" int asq_linear_w8a8_q8(const int8_t *xq, const int8_t *w, int8_t *out
     }
 }
 
+extern "C" size_t asq_grouped_workspace_bytes(int64_t M, int64_t N, int64_t K, int ngroups)
+{
+    if (M <= 0 || N <= 0 || K < 128 * 2 * P8_TAIL_MIN_KTILES || ngroups <= 0 || ngroups > P8_GROUPED_SCAN_MAX) return 0;
+    return (size_t)WS_HEADER_BYTES + P8_GROUPED_WS_BYTES;
+}
+
 extern "C" int asq_linear_w8a8_grouped(const int8_t *xq, const int8_t *w, void *out, int out_dtype, const int32_t *group_offsets, int ngroups,
                                        int64_t M, int64_t N, int64_t K, const float *s_group, const float *s_row, const float *bias, void *stream)
+{
+    return asq_linear_w8a8_grouped_ws(xq, w, out, out_dtype, group_offsets, ngroups, M, N, K, s_group, s_row, bias, nullptr, 0, stream);
+}
+
+extern "C" int asq_linear_w8a8_grouped_ws(const int8_t *xq, const int8_t *w, void *out, int out_dtype, const int32_t *group_offsets, int ngroups,
+                                          int64_t M, int64_t N, int64_t K, const float *s_group, const float *s_row, const float *bias,
+                                          void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = check_gemm_args("asq_linear_w8a8_grouped", xq, w, out, M, N, K);
     if (rc) return rc;
@@ -153,7 +166,8 @@ extern "C" int asq_linear_w8a8_grouped(const int8_t *xq, const int8_t *w, void *
                 ASQ_ERR_ALIGN, "asq_linear_w8a8_grouped: misaligned pointer");
     const size_t vbytes = out_dtype == ASQ_F32 ? 16 : 8;
     const bool vec_ok = (N % 4 == 0) && (((uintptr_t)out & (vbytes - 1)) == 0) && ((((uintptr_t)bias) & 15) == 0);
-    DequantArgs a{xq, w, out, M, N, K, 1.0f, s_row, nullptr, bias, ASQ_EPI_SCALE_FIRST, vec_ok, nullptr, 0};
+    ASQ_REQUIRE(workspace == nullptr || (((uintptr_t)workspace) & 255) == 0, ASQ_ERR_ALIGN, "asq_linear_w8a8_grouped: workspace must be 256-B aligned");
+    DequantArgs a{xq, w, out, M, N, K, 1.0f, s_row, nullptr, bias, ASQ_EPI_SCALE_FIRST, vec_ok, workspace, workspace ? workspace_bytes : 0};
     a.s_group = s_group;
     a.goffs = group_offsets;
     a.ngroups = ngroups;

@@ -697,6 +697,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return base + slot;
 }
 
+// workspace header (asq_workspace_init): magic word + arrival tickets of the in-launch reductions (asq_gemm_wstream.h; grouped tail split of asq_gemm_p8.h)
+constexpr int WS_HEADER_BYTES = 8192;
+constexpr unsigned long long WS_MAGIC = 0x4153515753763031ull;  // "ASQWSv01"
+constexpr int WS_MAX_GROUPS = (WS_HEADER_BYTES - 16) / 4;
+
 }  // namespace asq
 
 #include "asq_gemm_p8.h"
@@ -1022,6 +1027,16 @@ static inline TailPeel plan_tail_peel(GemmKernel kern, int64_t M, int64_t N, int
     return p;
 }
 
+// ASQ_GROUPED_SPLIT=0: grouped launches never split the K loop of their tail tiles (A/B switch; the default is on when a workspace is passed)
+static inline bool grouped_tail_split_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("ASQ_GROUPED_SPLIT");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 template <class Epi, class = void> struct HasColView : std::false_type {};
 template <class Epi> struct HasColView<Epi, std::enable_if_t<Epi::kColView>> : std::true_type {};
 
@@ -1035,7 +1050,14 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
     if (goffs != nullptr) {  // grouped: tiled kernel only; grid = host-side upper bound on the number of tiles
         const bool ok = (((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0) && K % 128 == 0 && K >= 128 && K <= (1 << 24);
         ASQ_REQUIRE(ok, ASQ_ERR_DIM, "%s: grouped launch needs K %% 128 == 0 and 16-B aligned operands", what);
-        const int64_t tn = (N + 255) / 256, tiles = (M / 256 + ngroups) * tn;
+        const int64_t tn = (N + 255) / 256;
+        int64_t tiles = (M / 256 + ngroups) * tn;   // upper bound on sum ceil(m_g / 256) * tn
+        char *gws = nullptr;
+        if (ngroups <= P8_GROUPED_SCAN_MAX) {       // balanced scheduler: blocks b = 8 * slot + xcd, up to one extra round of K pieces per XCD
+            tiles = 8 * ((tiles + 7) / 8 + P8_CUS_PER_XCD);
+            if constexpr (Epi::Mma::kIsInt)
+                if (ws_hdr != nullptr && ws_bytes >= P8_GROUPED_WS_BYTES && grouped_tail_split_enabled()) gws = (char *)ws_hdr;
+        }
         ASQ_REQUIRE(tiles < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
         auto kfn = gemm_i8_p8<Epi>;
         hipError_t e = ensure_dynamic_lds((const void *)kfn, P8_LDS_BYTES);
@@ -1043,7 +1065,7 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
             return (int)e;
         }
-        hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, 0, (int)tn, 1, goffs, ngroups, epi);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, 0, (int)tn, 1, goffs, ngroups, gws, epi);
         return asq_after_launch(s, what);
     }
     constexpr bool kInt = Epi::Mma::kIsInt;
@@ -1086,7 +1108,7 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
                 asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
                 return (int)e;
             }
-            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn * ksplit)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, ksplit, (const int *)nullptr, 0, slab);
+            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn * ksplit)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, ksplit, (const int *)nullptr, 0, (char *)nullptr, slab);
             int64_t blocks = (M * (N / 4) + 255) / 256;
             if (blocks > 8192) blocks = 8192;
             hipLaunchKernelGGL((splitk_reduce<Epi>), dim3((unsigned)blocks), dim3(256), 0, s, (const int32_t *)ws, ksplit, M, N, epi);
@@ -1098,7 +1120,7 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
             return (int)e;
         }
-        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, (const int *)nullptr, 0, epi);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, (const int *)nullptr, 0, (char *)nullptr, epi);
     } else if (kern == KERN_P8H) {
         const int64_t tm = (M + 127) / 128, tn = (N + 255) / 256;
         ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);

@@ -46,6 +46,15 @@ namespace asq {
 constexpr int P8_UNIT = 128 * 128;        // 16 KiB
 constexpr int P8_STAGE = 4 * P8_UNIT;     // one K-tile: 64 KiB
 constexpr int P8_LDS_BYTES = 2 * P8_STAGE;
+// grouped launches (the scheduler at the top of gemm_i8_p8)
+constexpr int P8_GROUPED_SCAN_MAX = 64;     // groups a block may scan twice (tile total, then its own tile)
+constexpr int P8_CUS_PER_XCD = 32;          // MI355X: 256 CUs in 8 XCDs; one 128-KiB-LDS block per CU
+constexpr int P8_TAIL_SPLIT_MAX = 8;        // K pieces of a tail tile
+#ifndef P8_FIX_BATCH
+#define P8_FIX_BATCH 16                     // 16-B loads per lane in flight while the last piece sums the others' images
+#endif
+constexpr int P8_TAIL_MIN_KTILES = 8;       // ... each at least this many 128-byte K tiles
+constexpr size_t P8_GROUPED_WS_BYTES = (size_t)8 * P8_CUS_PER_XCD * 256 * 256 * 4;  // 256 register images of 256 KiB
 
 #define P8_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define P8_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -127,7 +136,7 @@ __device__ __forceinline__ void p8_dma16(const int8_t *sbase, unsigned voff, uns
 template <class Epi, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N,
                                                      int64_t K, int tiles_m, int tiles_n, int ksplit, const int *__restrict__ goffs, int ngroups,
-                                                     Epi epi_in)
+                                                     char *gws, Epi epi_in)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -140,14 +149,54 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
     // split-K (ksplit > 1, int32 slabs only): logical id = split * ntiles + tile, so the blocks an XCD
     // receives share one K range and neighbouring tiles (operand panels stay L2-local)
     // Grouped mode (goffs != null; Mixtral-style experts): x rows are sorted by group, goffs[0..ngroups]
-    // are the row offsets (device int32), w is [ngroups][N][K].  The grid is the host-side upper bound
-    // floor(M/256) + ngroups tile rows; each block finds its (group, tile) by a scalar scan, surplus blocks exit.
+    // are the row offsets (device int32), w is [ngroups][N][K].  The grid is a host-side upper bound; each block finds its
+    // (group, tile) by a scalar scan, surplus blocks exit.
+    //   ngroups <= P8_GROUPED_SCAN_MAX: the block first sums the tile count T of the launch and the remap runs over T, not over the
+    //   grid: every XCD (blocks b = 8*slot + xcd) gets T/8 consecutive tiles, instead of the last XCDs holding the grid's surplus blocks
+    //   and idling.  With a workspace (gws) the tiles an XCD would run in its last, less than half full round (32 CUs, one block each)
+    //   are split along K into S = 32/tail pieces that fill the round; the pieces leave their accumulators in the workspace as register
+    //   images and the last one to arrive (ticket in the workspace header, as in asq_gemm_wstream.h) adds them in split order and runs
+    //   the epilogue: exact for int32.
     constexpr int GM = 4;
-    int split = 0, id, grp = 0;
+    int split = 0, id, grp = 0, ksp = ksplit;
+    int tsplit = 0, tsplits = 1, tpart0 = 0, ttail = 0, tticket = 0;  // K split of a tail tile inside a grouped launch
     int64_t m_base = 0;
     const int64_t M_all = M;
     if (goffs != nullptr) {
-        int gid = xcd_remap(blockIdx.x, gridDim.x), e = 0, r0 = 0, r1 = 0, tm_e = 0;
+        int gid, e = 0, r0 = 0, r1 = 0, tm_e = 0;
+        if (ngroups <= P8_GROUPED_SCAN_MAX) {
+            int T = 0;
+            for (int g = 0; g < ngroups; ++g) T += ((goffs[g + 1] - goffs[g] + 255) >> 8) * tiles_n;
+            const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+            const int q = T >> 3, r = T & 7;
+            const int c = q + (xcd < r ? 1 : 0), base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+            const int tail = c & (P8_CUS_PER_XCD - 1);
+            int S = 1;
+            if (gws != nullptr && tail > 0 && tail <= P8_CUS_PER_XCD / 2) {
+                S = P8_CUS_PER_XCD / tail;
+                S = S < P8_TAIL_SPLIT_MAX ? S : P8_TAIL_SPLIT_MAX;
+                const int by_k = (int)(K / 128) / P8_TAIL_MIN_KTILES;
+                S = S < by_k ? S : by_k;
+                if (S < 2) S = 1;
+            }
+            const int body = S > 1 ? c - tail : c;
+            if (slot < body) {
+                gid = base + slot;
+            } else {
+                const int t = slot - body;
+                if (S == 1 || t >= tail * S) return;  // surplus block (uniform for the whole block, before any barrier)
+                const int ti = t % tail;
+                gid = base + body + ti;
+                tsplit = t / tail;
+                tsplits = S;
+                ksp = S;
+                ttail = tail;
+                tpart0 = xcd * P8_CUS_PER_XCD + ti;   // partial (tile ti, split s) lives at tpart0 + s * tail
+                tticket = xcd * (P8_CUS_PER_XCD / 2) + ti;
+            }
+        } else {
+            gid = xcd_remap(blockIdx.x, gridDim.x);
+        }
         for (; e < ngroups; ++e) {
             r0 = goffs[e];
             r1 = goffs[e + 1];
@@ -163,13 +212,16 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
         M = r1;  // rows >= r1 belong to the next group: clamp loads, mask stores
         w += (int64_t)e * N * K;
         grp = e;
+        if (tsplits > 1) split = tsplit;
     } else {
         const int nwg = tiles_m * tiles_n;
         const int lid = xcd_remap(blockIdx.x, nwg * ksplit);
         split = lid / nwg;
         id = lid - split * nwg;
     }
-    const Epi epi = epi_in.rebased(grp, split, M_all, N);
+    unsigned long long ws_magic = 0;
+    if (tsplits > 1) ws_magic = *(const volatile unsigned long long *)gws;  // checked at the ticket (asq_workspace_init wrote it)
+    const Epi epi = epi_in.rebased(grp, tsplits > 1 ? 0 : split, M_all, N);
     const int per_group = GM * tiles_n;
     const int group = id / per_group, in_group = id - group * per_group;
     const int first_m = group * GM;
@@ -180,7 +232,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
     // ---- DMA sources: uniform tile base (SGPR pair, + k advanced per K-tile) + 32-bit lane offset.
     // This wave fills row-groups 2*wave, 2*wave+1 (8 rows each) of every unit.
     const int nt_all = (int)(K / 128);
-    const int kt0 = (int)((int64_t)nt_all * split / ksplit), kt1 = (int)((int64_t)nt_all * (split + 1) / ksplit);
+    const int kt0 = (int)((int64_t)nt_all * split / ksp), kt1 = (int)((int64_t)nt_all * (split + 1) / ksp);
     const int8_t *const xbase = uniform_ptr(x + m0 * K + (int64_t)kt0 * 128);  // wave-uniform, SGPR pair
     const int8_t *const wbase = uniform_ptr(w + n0 * K + (int64_t)kt0 * 128);
     const int64_t mrem = M - m0 - 1, nrem = N - n0 - 1;  // last valid local row
@@ -411,6 +463,59 @@ if constexpr (MMA::kIsInt) {
     P8_BLK(2);
     P8_WAIT_VM(0);          // drain the dead prefetches before LDS is released
     if (wm == 0) P8_BAR();  // balance the stagger barrier
+
+    if (tsplits > 1) {  // block-uniform: a K piece of a tail tile of a grouped launch (see the top of the kernel)
+        typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+        typedef decltype(acc[0][0][0][0]) elem_ref;
+        typedef std::remove_cv_t<std::remove_reference_t<elem_ref>> elem_t;
+        typedef elem_t v4e_ __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(gws + WS_HEADER_BYTES, 0, 0x7FFFFFFF, 0x00020000);
+        constexpr int PART = 256 * 256 * 4;   // one register image: 32 x (512 lanes x 16 B)
+        const int my = (tpart0 + tsplit * ttail) * PART + tid * 16;
+        // (offset in the VGPR, soffset 0 and a wait state after the stores: see the note on buffer stores in asq_gemm_wstream.h)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const acc_t &A = acc[i >> 4][(i >> 3) & 1][(i >> 2) & 1];
+            const int j = (i & 3) * 4;
+            const v4e_ v = {A[j], A[j + 1], A[j + 2], A[j + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, v), rsrc, my + i * 8192, 0, 16 /* sc1: write-through */);
+        }
+        asm volatile("s_nop 1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's image is in memory before the block takes its ticket
+        unsigned *const flag = (unsigned *)lds;  // (the ring is dead)
+        if (tid == 0) {
+            unsigned *const tk = (unsigned *)gws + 4 + tticket;
+            const unsigned old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old >= (unsigned)tsplits || ws_magic != WS_MAGIC) __builtin_trap();  // header not initialised / workspace shared by concurrent launches
+            if (old == (unsigned)tsplits - 1) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next launch / replay
+            *flag = old == (unsigned)tsplits - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool last = *flag != 0;
+        __syncthreads();  // (the staged epilogue reuses this LDS)
+        if (!last) return;
+        for (int sp = 0; sp < tsplits; ++sp) {
+            if (sp == tsplit) continue;
+            const int src = (tpart0 + sp * ttail) * PART + tid * 16;
+#pragma unroll
+            for (int i0 = 0; i0 < 32; i0 += P8_FIX_BATCH) {   // (64 VGPRs of loads in flight beside the 128 accumulators)
+                v4u_ v[P8_FIX_BATCH];
+#pragma unroll
+                for (int u = 0; u < P8_FIX_BATCH; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, src + (i0 + u) * 8192, 0, 16 /* sc1 */);
+#pragma unroll
+                for (int u = 0; u < P8_FIX_BATCH; ++u) {
+                    const int i = i0 + u;
+                    acc_t &A = acc[i >> 4][(i >> 3) & 1][(i >> 2) & 1];
+                    const int j = (i & 3) * 4;
+                    const v4e_ a = __builtin_bit_cast(v4e_, v[u]);
+                    A[j] += a[0];
+                    A[j + 1] += a[1];
+                    A[j + 2] += a[2];
+                    A[j + 3] += a[3];
+                }
+            }
+        }
+    }
 
     // accumulator tile (in = n-half, im = 2*m-half + j) -> rows m0 + wm*128 + 32*im, cols n0 + wn*64 + 32*in
     auto get = [&](int in, int im) -> const acc_t & { return acc[im >> 1][in][im & 1]; };

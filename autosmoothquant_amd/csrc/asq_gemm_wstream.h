@@ -34,9 +34,7 @@
 
 namespace asq {
 
-constexpr int WS_HEADER_BYTES = 8192;
-constexpr unsigned long long WS_MAGIC = 0x4153515753763031ull;  // "ASQWSv01"
-constexpr int WS_MAX_GROUPS = (WS_HEADER_BYTES - 16) / 4;
+// (WS_HEADER_BYTES, WS_MAGIC, WS_MAX_GROUPS: asq_gemm_kernels.h, shared with the grouped launch of asq_gemm_p8.h)
 constexpr int WS_CB = 128;  // channels per group = 8 waves x 16
 
 template <int MT> struct WsCfg {

@@ -104,6 +104,25 @@ def _workspace(lib, size_fn, M, N, K, dev, stream):
     return res
 
 
+def _grouped_ws(lib, M, N, K, G, dev, stream):
+    """workspace of a grouped launch (asq_grouped_workspace_bytes: header + 64 MiB of K-piece images, one size for every shape that uses it):
+    one persistent, initialised buffer per (thread, device, stream), separate from the GEMM slot; under stream capture without a warmed-up
+    buffer the launch simply runs without one (same results, no tail split)."""
+    n = lib.asq_grouped_workspace_bytes(M, N, K, G)
+    if n == 0:
+        return None, 0
+    cache = _ws_tls.__dict__.setdefault("c", {})
+    key = (dev.index, stream, "grouped")
+    buf = cache.get(key)
+    if buf is None or buf.numel() < n:
+        if torch.cuda.is_current_stream_capturing():
+            return None, 0
+        buf = torch.empty((n,), dtype=torch.uint8, device=dev)
+        L.check(lib.asq_workspace_init(buf.data_ptr(), n, stream), "asq_workspace_init")
+        cache[key] = buf
+    return buf, n
+
+
 def _gemm_ws(M, N, K, dev, stream):
     """scratch of a GEMM-only call (None when the shape never needs any)"""
     return _workspace(L.lib(), "asq_gemm_workspace_bytes", M, N, K, dev, stream)
@@ -316,8 +335,10 @@ def linear_w8a8_grouped(xq, w, group_offsets, s_group, out_dtype, s_row=None, bi
     out = torch.empty((M, N), dtype=out_dtype, device=xq.device)
     dev = _same_device(xq, w, group_offsets, s_group, s_row, bias)
     with _on(dev):
-        L.check(L.lib().asq_linear_w8a8_grouped(xq.data_ptr(), w.data_ptr(), out.data_ptr(), _DT[out_dtype], group_offsets.data_ptr(), G, M, N, K,
-                                                s_group.data_ptr(), _ptr(s_row), _ptr(bias), _stream(xq)), "asq_linear_w8a8_grouped")
+        lib, st = L.lib(), _stream(xq)
+        ws, n = _grouped_ws(lib, M, N, K, G, dev, st)
+        L.check(lib.asq_linear_w8a8_grouped_ws(xq.data_ptr(), w.data_ptr(), out.data_ptr(), _DT[out_dtype], group_offsets.data_ptr(), G, M, N, K,
+                                               s_group.data_ptr(), _ptr(s_row), _ptr(bias), _ptr(ws), n, st), "asq_linear_w8a8_grouped")
     return out
 
 

@@ -438,6 +438,50 @@ def test_grouped_launch_equals_per_group_calls(counts, per_token, K, dev):
             o += c
 
 
+@pytest.mark.parametrize("counts,N,K", [
+    ([256] * 8, 256, 2048),                       # 8 tiles, one per XCD: every tile is a tail tile, split in 2 (16 K tiles / 8)
+    ([300, 0, 17, 256, 1, 511, 100, 90], 512, 8192),   # 22 tiles: XCDs hold 2 or 3 tail tiles, 8 K pieces each
+    ([1000, 24, 700, 3, 0, 260], 1000, 4096),     # ragged N (no staged epilogue), 4 K pieces
+    ([129] * 40, 256, 3072),                      # 40 groups, 5 tail tiles per XCD x 3 pieces (24 K tiles / 8)
+    ([2048, 2048], 4352, 2048),                   # 272 tiles = 34 per XCD: one full round + 2 tail tiles x 2 pieces
+])
+def test_grouped_launch_tail_split_is_exact(counts, N, K, dev):
+    """The grouped launch's scheduler (asq_gemm_p8.h): tiles shared equally by the XCDs and, with a workspace, the tiles of a less than half
+    full last round split along K and summed in the launch.  With workspace == without == one call per group, bit for bit (fp16 epilogue with
+    row scales and bias; int32 sums are order-independent), three launches in a row on one workspace, tickets left at zero."""
+    from autosmoothquant_amd import ops, _lib as L
+    lib = L.lib()
+    G, M = len(counts), sum(counts)
+    st = torch.cuda.current_stream().cuda_stream
+    xq = torch.from_numpy(detrng.int8_uniform(190, M + G, (M, K))).to(dev)
+    w = torch.from_numpy(detrng.int8_uniform(191, G + N, (G, N, K))).to(dev)
+    sg = torch.from_numpy((np.abs(detrng.normal(192, G, (G,))) * 1e-3 + 1e-4).astype(np.float32)).to(dev)
+    bias = torch.from_numpy(detrng.normal(193, G, (G, N)).astype(np.float32)).to(dev)
+    s_row = torch.from_numpy((np.abs(detrng.normal(194, M, (M,))) * 0.01 + 1e-3).astype(np.float32)).to(dev)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device=dev)
+    n = lib.asq_grouped_workspace_bytes(M, N, K, G)
+    hdr = lib.asq_workspace_header_bytes()
+    assert n == hdr + (64 << 20)
+    ws = torch.full((n,), 0x3C, dtype=torch.uint8, device=dev)
+    L.check(lib.asq_workspace_init(ws.data_ptr(), n, st), "init")
+    args = (xq.data_ptr(), w.data_ptr())
+    tail = (offs.data_ptr(), G, M, N, K, sg.data_ptr(), s_row.data_ptr(), bias.data_ptr())
+    plain = torch.empty((M, N), dtype=torch.float16, device=dev)
+    L.check(lib.asq_linear_w8a8_grouped(*args, plain.data_ptr(), L.ASQ_F16, *tail, st), "grouped")
+    for rep in range(3):
+        got = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
+        L.check(lib.asq_linear_w8a8_grouped_ws(*args, got.data_ptr(), L.ASQ_F16, *tail, ws.data_ptr(), n, st), "grouped_ws")
+        assert torch.equal(got, plain), rep
+    assert int(ws[16:hdr].view(torch.int32).abs().max()) == 0
+    o = 0
+    for g, c in enumerate(counts):
+        if c:
+            ref = ops.linear_w8a8(xq[o:o + c].contiguous(), w[g], torch.float16, float(sg[g]), s_row[o:o + c].contiguous(), None, bias[g])
+            assert torch.equal(plain[o:o + c], ref), (g, c)
+        o += c
+    assert torch.equal(ops.linear_w8a8_grouped(xq, w, offs, sg, torch.float16, s_row, bias), plain)   # (the module-level wrapper keeps its own workspace)
+
+
 def test_forward_outputs_never_require_grad(dev):
     """The reference decorates forward with @torch.no_grad(); here no autograd graph is recorded at all, so even an input
     that requires grad (under grad mode) yields an output that does not."""
