@@ -169,6 +169,7 @@ struct EpiI32 {
 // out = dequant(acc) (+bias) -> DT.  HAS_* are compile-time so the hot instantiations carry no
 // dead loads or branches; `order` is a wave-uniform runtime select.
 template <int DT, bool HAS_ROW, bool HAS_COL, bool HAS_BIAS> struct EpiDequant {
+    static constexpr bool kGroupable = true;  // has per-group scales: grouped launches instantiate gemm_i8_p8<Epi, 0, true>
     using Mma = MmaI8;
     static constexpr bool kHasRow = HAS_ROW, kHasCol = HAS_COL, kHasBias = HAS_BIAS;
     static constexpr int kOutBytes = (DT == ASQ_F32) ? 4 : 2;
@@ -404,6 +405,7 @@ struct EpiI8 {  // out = sat_i8(rne(alpha*acc + beta*c)), c = previous out
 // quantiser) or, when null, the host scalar.  Tolerance-checked (the reference dequantises both
 // operands and calls F.linear; its summation order is unspecified).
 template <int DT, bool HAS_BIAS, class MMA_ = MmaFp8> struct EpiFp8 {
+    static constexpr bool kGroupable = true;
     using Mma = MMA_;
     static constexpr bool kHasRow = true, kHasCol = false, kHasBias = HAS_BIAS;
     static constexpr int kOutBytes = (DT == ASQ_F32) ? 4 : 2;
@@ -1037,6 +1039,8 @@ static inline bool grouped_tail_split_enabled()
     return on;
 }
 
+template <class Epi, class = void> struct IsGroupable : std::false_type {};
+template <class Epi> struct IsGroupable<Epi, std::enable_if_t<Epi::kGroupable>> : std::true_type {};
 template <class Epi, class = void> struct HasColView : std::false_type {};
 template <class Epi> struct HasColView<Epi, std::enable_if_t<Epi::kColView>> : std::true_type {};
 
@@ -1047,19 +1051,21 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
                      size_t ws_bytes, const int *goffs = nullptr, int ngroups = 0, int peel_role = 0 /* 0 top level, 1 main part, 2 remainder (128 x 128 tiles) */)
 {
     if (M == 0 || N == 0) return ASQ_OK;
-    if (goffs != nullptr) {  // grouped: tiled kernel only; grid = host-side upper bound on the number of tiles
+    if constexpr (!IsGroupable<Epi>::value) {
+        ASQ_REQUIRE(goffs == nullptr, ASQ_ERR_DIM, "%s: this epilogue has no grouped form", what);
+    } else if (goffs != nullptr) {  // grouped: tiled kernel only; grid = host-side upper bound on the number of tiles
         const bool ok = (((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0) && K % 128 == 0 && K >= 128 && K <= (1 << 24);
         ASQ_REQUIRE(ok, ASQ_ERR_DIM, "%s: grouped launch needs K %% 128 == 0 and 16-B aligned operands", what);
         const int64_t tn = (N + 255) / 256;
         int64_t tiles = (M / 256 + ngroups) * tn;   // upper bound on sum ceil(m_g / 256) * tn
         char *gws = nullptr;
         if (ngroups <= P8_GROUPED_SCAN_MAX) {       // balanced scheduler: blocks b = 8 * slot + xcd, up to one extra round of K pieces per XCD
-            tiles = 8 * ((tiles + 7) / 8 + P8_CUS_PER_XCD);
+            tiles = 8 * ((tiles + 7) / 8 + 2 + P8_CUS_PER_XCD);   // (+2: full and half tiles are dealt to the XCDs separately)
             if constexpr (Epi::Mma::kIsInt)
                 if (ws_hdr != nullptr && ws_bytes >= P8_GROUPED_WS_BYTES && grouped_tail_split_enabled()) gws = (char *)ws_hdr;
         }
         ASQ_REQUIRE(tiles < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
-        auto kfn = gemm_i8_p8<Epi>;
+        auto kfn = gemm_i8_p8<Epi, 0, true>;
         hipError_t e = ensure_dynamic_lds((const void *)kfn, P8_LDS_BYTES);
         if (e != hipSuccess) {
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));

@@ -51,7 +51,7 @@ constexpr int P8_GROUPED_SCAN_MAX = 64;     // groups a block may scan twice (ti
 constexpr int P8_CUS_PER_XCD = 32;          // MI355X: 256 CUs in 8 XCDs; one 128-KiB-LDS block per CU
 constexpr int P8_TAIL_SPLIT_MAX = 8;        // K pieces of a tail tile
 #ifndef P8_FIX_BATCH
-#define P8_FIX_BATCH 16                     // 16-B loads per lane in flight while the last piece sums the others' images
+#define P8_FIX_BATCH 8                      // 16-B loads per lane in flight while the last piece sums the others' images
 #endif
 constexpr int P8_TAIL_MIN_KTILES = 8;       // ... each at least this many 128-byte K tiles
 constexpr size_t P8_GROUPED_WS_BYTES = (size_t)8 * P8_CUS_PER_XCD * 256 * 256 * 4;  // 256 register images of 256 KiB
@@ -133,7 +133,7 @@ __device__ __forceinline__ void p8_dma16(const int8_t *sbase, unsigned voff, uns
                  : "memory");
 }
 
-template <class Epi, int ABL = 0>
+template <class Epi, int ABL = 0, bool GRP = false>   // GRP: the grouped launch (goffs != null); the plain instantiation carries none of its code
 __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N,
                                                      int64_t K, int tiles_m, int tiles_n, int ksplit, const int *__restrict__ goffs, int ngroups,
                                                      char *gws, Epi epi_in)
@@ -151,63 +151,96 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
     // Grouped mode (goffs != null; Mixtral-style experts): x rows are sorted by group, goffs[0..ngroups]
     // are the row offsets (device int32), w is [ngroups][N][K].  The grid is a host-side upper bound; each block finds its
     // (group, tile) by a scalar scan, surplus blocks exit.
-    //   ngroups <= P8_GROUPED_SCAN_MAX: the block first sums the tile count T of the launch and the remap runs over T, not over the
-    //   grid: every XCD (blocks b = 8*slot + xcd) gets T/8 consecutive tiles, instead of the last XCDs holding the grid's surplus blocks
-    //   and idling.  With a workspace (gws) the tiles an XCD would run in its last, less than half full round (32 CUs, one block each)
-    //   are split along K into S = 32/tail pieces that fill the round; the pieces leave their accumulators in the workspace as register
-    //   images and the last one to arrive (ticket in the workspace header, as in asq_gemm_wstream.h) adds them in split order and runs
-    //   the epilogue: exact for int32.
+    //   ngroups <= P8_GROUPED_SCAN_MAX: the block first counts the launch's tiles and the remap runs over that count, not over the
+    //   grid: every XCD (blocks b = 8 * slot + xcd) gets an equal share, instead of the last XCDs holding the grid's surplus blocks
+    //   and idling.  Tiles come in two kinds: FULL (256 rows of a group) and HALF -- a group's last tile when it has <= 128 rows;
+    //   its rows [0,64) / [64,128) go to the two wave groups' first row halves and the K loop skips phases P3 / P4 (half the matrix
+    //   work instead of a full tile of padding).  An XCD runs its full tiles first, then its half tiles (long jobs first).
+    //   With a workspace (gws) the tiles an XCD would run in its last, less than half full round (32 CUs, one block each) are split
+    //   along K into S = 32 / tail pieces that fill the round; the pieces leave their accumulators in the workspace as register
+    //   images and the last one to arrive (ticket in the workspace header, as in asq_gemm_wstream.h) adds them and runs the
+    //   epilogue: exact for int32.
     constexpr int GM = 4;
-    int split = 0, id, grp = 0, ksp = ksplit;
+    constexpr bool MMA_kIsInt_ = Epi::Mma::kIsInt;
+    int split = 0, id, grp = 0, ksp = ksplit, moff = 0;
+    bool half_rt = false;
     int tsplit = 0, tsplits = 1, tpart0 = 0, ttail = 0, tticket = 0;  // K split of a tail tile inside a grouped launch
     int64_t m_base = 0;
     const int64_t M_all = M;
-    if (goffs != nullptr) {
+    if constexpr (GRP) {
         int gid, e = 0, r0 = 0, r1 = 0, tm_e = 0;
-        if (ngroups <= P8_GROUPED_SCAN_MAX) {
-            int T = 0;
-            for (int g = 0; g < ngroups; ++g) T += ((goffs[g + 1] - goffs[g] + 255) >> 8) * tiles_n;
+        const bool sched = ngroups <= P8_GROUPED_SCAN_MAX;
+        if (sched) {
+            int F = 0, Hh = 0;  // tiles of the two kinds
+            for (int g = 0; g < ngroups; ++g) {
+                const int m = goffs[g + 1] - goffs[g];
+                const int h = (MMA_kIsInt_ && m > 0 && ((m - 1) & 255) < 128) ? 1 : 0;  // (int8 only: the guarded phases cost the fp8 instantiations spills)
+                F += (((m + 255) >> 8) - h) * tiles_n;
+                Hh += h * tiles_n;
+            }
             const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-            const int q = T >> 3, r = T & 7;
-            const int c = q + (xcd < r ? 1 : 0), base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-            const int tail = c & (P8_CUS_PER_XCD - 1);
-            int S = 1;
-            if (gws != nullptr && tail > 0 && tail <= P8_CUS_PER_XCD / 2) {
-                S = P8_CUS_PER_XCD / tail;
-                S = S < P8_TAIL_SPLIT_MAX ? S : P8_TAIL_SPLIT_MAX;
+            const int qf = F >> 3, rf = F & 7, qh = Hh >> 3, rh = Hh & 7, xr = 7 - xcd;  // (the odd full tiles go to the low XCDs, the odd half tiles to the high ones)
+            const int cF = qf + (xcd < rf ? 1 : 0), baseF = xcd < rf ? xcd * (qf + 1) : rf * (qf + 1) + (xcd - rf) * qf;
+            const int cH = qh + (xr < rh ? 1 : 0), baseH = xr < rh ? xr * (qh + 1) : rh * (qh + 1) + (xr - rh) * qh;
+            // The XCD's last, incomplete round: tf full tiles left over by the complete rounds of 32 and the half tiles behind them
+            // (or, with no full tile left over, the half tiles left over by THEIR complete rounds); in half-tile units of work:
+            const int tf = cF & (P8_CUS_PER_XCD - 1), th = tf > 0 ? cH : (cH & (P8_CUS_PER_XCD - 1));
+            const int Wt = 2 * tf + th;
+            int SF = 1, SH = 1;  // K pieces of a tail full / half tile: equal durations, at most 32 pieces in all
+            if (MMA_kIsInt_ && gws != nullptr && Wt > 0 && Wt <= P8_CUS_PER_XCD) {
+                SH = Wt <= P8_CUS_PER_XCD / 4 ? 4 : Wt <= P8_CUS_PER_XCD / 2 ? 2 : 1;
+                SF = 2 * SH;
                 const int by_k = (int)(K / 128) / P8_TAIL_MIN_KTILES;
-                S = S < by_k ? S : by_k;
-                if (S < 2) S = 1;
+                SF = SF < by_k ? SF : by_k;
+                SH = SH < by_k ? SH : by_k;
+                if (SF < 2) SF = 1;
+                if (SH < 2) SH = 1;
             }
-            const int body = S > 1 ? c - tail : c;
+            const bool cut = SF > 1 || SH > 1;
+            const int body = cF + cH - (cut ? tf + th : 0);
+            int seq;  // position in this XCD's sequence [full tiles | half tiles]
             if (slot < body) {
-                gid = base + slot;
+                seq = slot;
             } else {
-                const int t = slot - body;
-                if (S == 1 || t >= tail * S) return;  // surplus block (uniform for the whole block, before any barrier)
-                const int ti = t % tail;
-                gid = base + body + ti;
-                tsplit = t / tail;
-                tsplits = S;
-                ksp = S;
-                ttail = tail;
-                tpart0 = xcd * P8_CUS_PER_XCD + ti;   // partial (tile ti, split s) lives at tpart0 + s * tail
-                tticket = xcd * (P8_CUS_PER_XCD / 2) + ti;
+                int t = slot - body, S, ti, kind0, cnt;
+                if (!cut) return;  // surplus block (uniform for the whole block, before any barrier)
+                if (t < tf * SF) {
+                    S = SF, cnt = tf, kind0 = 0, seq = cF - tf;
+                } else {
+                    t -= tf * SF;
+                    if (t >= th * SH) return;
+                    S = SH, cnt = th, kind0 = tf * SF, seq = cF + cH - th;
+                }
+                ti = t % cnt;
+                seq += ti;
+                if (S > 1) {
+                    tsplit = t / cnt;
+                    tsplits = S;
+                    ksp = S;
+                    ttail = cnt;
+                    tpart0 = xcd * P8_CUS_PER_XCD + kind0 + ti;          // image of (tile ti, piece s) at tpart0 + s * cnt
+                    tticket = xcd * P8_CUS_PER_XCD + (kind0 ? tf : 0) + ti;
+                }
             }
+            half_rt = seq >= cF;
+            gid = half_rt ? baseH + (seq - cF) : baseF + seq;
         } else {
             gid = xcd_remap(blockIdx.x, gridDim.x);
         }
         for (; e < ngroups; ++e) {
             r0 = goffs[e];
             r1 = goffs[e + 1];
-            tm_e = (r1 - r0 + 255) >> 8;
-            const int cnt = tm_e * tiles_n;
+            const int m = r1 - r0;
+            const int h = (MMA_kIsInt_ && sched && m > 0 && ((m - 1) & 255) < 128) ? 1 : 0;
+            tm_e = ((m + 255) >> 8) - h;                       // full tile rows of this group
+            const int cnt = (half_rt ? h : tm_e) * tiles_n;
             if (gid < cnt) break;
             gid -= cnt;
         }
         if (e == ngroups) return;  // uniform for the whole block, before any barrier
         id = gid;
-        tiles_m = tm_e;
+        tiles_m = half_rt ? 1 : tm_e;
+        moff = half_rt ? tm_e : 0;    // the half tile is the group's last tile row
         m_base = r0;
         M = r1;  // rows >= r1 belong to the next group: clamp loads, mask stores
         w += (int64_t)e * N * K;
@@ -219,6 +252,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
         split = lid / nwg;
         id = lid - split * nwg;
     }
+    const bool half = GRP && MMA_kIsInt_ ? half_rt : false;
     unsigned long long ws_magic = 0;
     if (tsplits > 1) ws_magic = *(const volatile unsigned long long *)gws;  // checked at the ticket (asq_workspace_init wrote it)
     const Epi epi = epi_in.rebased(grp, tsplits > 1 ? 0 : split, M_all, N);
@@ -227,7 +261,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
     const int first_m = group * GM;
     const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
     const int tile_m = first_m + in_group % gm, tile_n = in_group / gm;
-    const int64_t m0 = m_base + (int64_t)tile_m * 256, n0 = (int64_t)tile_n * 256;
+    const int64_t m0 = m_base + (int64_t)(tile_m + moff) * 256, n0 = (int64_t)tile_n * 256;
 
     // ---- DMA sources: uniform tile base (SGPR pair, + k advanced per K-tile) + 32-bit lane offset.
     // This wave fills row-groups 2*wave, 2*wave+1 (8 rows each) of every unit.
@@ -241,7 +275,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
     for (int i = 0; i < 2; ++i) {
         const int ru = (wave * 2 + i) * 8 + (lane >> 3);          // row within the unit, 0..127
         const unsigned cb = (unsigned)(((lane & 7) ^ ((ru >> 1) & 7)) * 16);  // swizzled source chunk
-        int64_t rxe = (ru >> 6) * 128 + (ru & 63), rxo = rxe + 64;  // local tile rows
+        int64_t rxe = half ? ru : (ru >> 6) * 128 + (ru & 63), rxo = rxe + 64;  // local tile rows (half tile: rows [0,128) feed the first row halves)
         int64_t rwe = (ru >> 5) * 64 + (ru & 31), rwo = rwe + 32;
         rxe = rxe < mrem ? rxe : mrem;
         rxo = rxo < mrem ? rxo : mrem;
@@ -385,10 +419,12 @@ if constexpr (MMA::kIsInt) {
         P8_STAMP(0);
         issue(2, NS, kn);
         P8_STAMP(1);
+        if (!half) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) xf[j][ks] = p8_ldfrag<ABL>(xb[S][ks] + 3 * P8_UNIT + j * 4096, lane);
+                for (int ks = 0; ks < 4; ++ks) xf[j][ks] = p8_ldfrag<ABL>(xb[S][ks] + 3 * P8_UNIT + j * 4096, lane);
+        }
         P8_STAMP(2);
         P8_STAMP(3);
         P8_BAR();
@@ -397,6 +433,7 @@ if constexpr (MMA::kIsInt) {
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(5);
         P8_PRIO(1);
+        if (!half) {  // (a half tile has no second row half: phases P3 / P4 only keep the DMA / barrier cadence)
 if constexpr (MMA::kIsInt) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
@@ -407,6 +444,7 @@ if constexpr (MMA::kIsInt) {
             for (int kp = 0; kp < 4; kp += 2)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[1][1][j] = p8_mfma2<ABL, MMA>(wb[kp], wb[kp + 1], xf[j][kp], xf[j][kp + 1], acc[1][1][j]);
+        }
         }
         P8_PRIO(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -427,6 +465,7 @@ if constexpr (MMA::kIsInt) {
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(5);
         P8_PRIO(1);
+        if (!half) {
 if constexpr (MMA::kIsInt) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
@@ -437,6 +476,7 @@ if constexpr (MMA::kIsInt) {
             for (int kp = 0; kp < 4; kp += 2)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[1][0][j] = p8_mfma2<ABL, MMA>(wa[kp], wa[kp + 1], xf[j][kp], xf[j][kp + 1], acc[1][0][j]);
+        }
         }
         P8_PRIO(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -464,7 +504,7 @@ if constexpr (MMA::kIsInt) {
     P8_WAIT_VM(0);          // drain the dead prefetches before LDS is released
     if (wm == 0) P8_BAR();  // balance the stagger barrier
 
-    if (tsplits > 1) {  // block-uniform: a K piece of a tail tile of a grouped launch (see the top of the kernel)
+    if constexpr (GRP && MMA::kIsInt) if (tsplits > 1) {  // block-uniform: a K piece of a tail tile of a grouped launch (see the top of the kernel; int32 only)
         typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
         typedef decltype(acc[0][0][0][0]) elem_ref;
         typedef std::remove_cv_t<std::remove_reference_t<elem_ref>> elem_t;
@@ -498,7 +538,7 @@ if constexpr (MMA::kIsInt) {
             if (sp == tsplit) continue;
             const int src = (tpart0 + sp * ttail) * PART + tid * 16;
 #pragma unroll
-            for (int i0 = 0; i0 < 32; i0 += P8_FIX_BATCH) {   // (64 VGPRs of loads in flight beside the 128 accumulators)
+            for (int i0 = 0; i0 < 32; i0 += P8_FIX_BATCH) {   // (32 VGPRs of loads in flight beside the 128 accumulators; 16 spills)
                 v4u_ v[P8_FIX_BATCH];
 #pragma unroll
                 for (int u = 0; u < P8_FIX_BATCH; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, src + (i0 + u) * 8192, 0, 16 /* sc1 */);
@@ -521,13 +561,16 @@ if constexpr (MMA::kIsInt) {
     auto get = [&](int in, int im) -> const acc_t & { return acc[im >> 1][in][im & 1]; };
     bool staged = false;
     if constexpr (Epi::kOutBytes >= 2) staged = ((((uintptr_t)epi.out) & 15) == 0) && (((N | epi.N) * Epi::kOutBytes) % 16 == 0);  // N: this launch's column bound, epi.N: the row stride
+    // (half tile: wave group wm holds rows [64 wm, 64 wm + 64) in its first row half; the second half is masked by the row bound)
+    const int64_t mw0 = m0 + (half ? wm * 64 : wm * 128);
+    const int64_t Mw = half && mw0 + 64 < M ? mw0 + 64 : M;
     if (staged) {
         if constexpr (Epi::kOutBytes >= 2) {
             P8_BAR();  // every wave's ring reads are done and every wave's (dead) DMAs have landed: the ring becomes staging space
-            epilogue_wave_staged<4, P8_STORE_POLICY(ABL)>(epi, get, m0 + wm * 128, n0 + wn * 64, lane, M, N, lds0 + wave * 16384);
+            epilogue_wave_staged<4, P8_STORE_POLICY(ABL)>(epi, get, mw0, n0 + wn * 64, lane, Mw, N, lds0 + wave * 16384);
         }
     } else {
-        epilogue_wave<2, 4>(epi, get, [](int im) { return im * 32; }, m0 + wm * 128, n0 + wn * 64, lane, M, N);
+        epilogue_wave<2, 4>(epi, get, [](int im) { return im * 32; }, mw0, n0 + wn * 64, lane, Mw, N);
     }
 #ifdef ASQ_P8_PROBE
     if constexpr (ABL & 128) {

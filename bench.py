@@ -151,6 +151,14 @@ def make_moe_workload(device, seed, dtype, skew=False):
         return ops.linear_w8a8_grouped(aq, st["w2"], st["offs"], st["s2"], dtype, srow)
     st["grouped_fused"] = grouped_fused
 
+    def grouped_fused_fast():   # ... with the opt-in hardware exp2/rcp SiLU (ASQ_SILU_FAST: +-1 int8 of the exact kernel, asserted in tests/test_hip_n1.py)
+        xq, _ = ops.quantize_act(st["x"], "per-tensor-round")
+        h1 = ops.linear_w8a8_grouped(xq, st["w1"], st["offs"], st["s1"], dtype)
+        h3 = ops.linear_w8a8_grouped(xq, st["w3"], st["offs"], st["s3"], dtype)
+        aq, srow = ops.silu_mul_quantize(h1, h3, per_token=True, fast=True)
+        return ops.linear_w8a8_grouped(aq, st["w2"], st["offs"], st["s2"], dtype, srow)
+    st["grouped_fused_fast"] = grouped_fused_fast
+
     s1h, s3h, s2h = st["s1"].tolist(), st["s3"].tolist(), st["s2"].tolist()
 
     def sequential():   # what the reference's Python expert loop amounts to (models/mixtral.py:142-145)
@@ -508,6 +516,15 @@ def main():
                 st["grouped_fused"]()
             torch.cuda.synchronize()
             moe_extra["grouped_fused_silu_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
+        if "grouped_fused_fast" in st:
+            for _ in range(5):
+                st["grouped_fused_fast"]()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                st["grouped_fused_fast"]()
+            torch.cuda.synchronize()
+            moe_extra["grouped_fused_fast_silu_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
     elif layer_mode:
         mods, xs = make_layer_workload(spec, device, seed=1234 if rank == 0 else 99 + rank, dtype=tdt, fuse_norm=args.fuse_norm, fuse_qkv=args.fuse_qkv)
         nlayers = len(mods)
