@@ -175,11 +175,12 @@ int asq_linear_w8a8_grouped(const int8_t *xq, const int8_t *w, void *out, int ou
                             int64_t M, int64_t N, int64_t K,
                             const float *s_group, const float *s_row, const float *bias, void *stream);
 /* The same launch with a workspace (contract above: asq_workspace_init once, one launch at a time).  Scheduling inside the launch, for
- * ngroups <= 64: each XCD gets an equal share of the launch's tiles (counted on the device from group_offsets), and with a workspace of
- * asq_grouped_workspace_bytes() (8 KiB header + 64 MiB; 0 = this shape never uses one) the tiles of an XCD's last, less than half full round
- * split their K loop into 2..8 pieces that fill the round; the pieces are summed in the launch (exact int32, ticket in the header) before the
- * epilogue.  Mixtral w2 (N 4096, K 14336, 8192 routed rows): 2.25 rounds -> 2 rounds + a quarter-length one.  Results are bit-identical to
- * asq_linear_w8a8_grouped. */
+ * ngroups <= 64 (both entry points): each XCD gets an equal share of the launch's tiles (counted on the device from group_offsets); a group's
+ * last tile with <= 128 rows runs as a half tile (half the matrix work instead of a full tile of padding).  With a workspace of
+ * asq_grouped_workspace_bytes() (8 KiB header + 64 MiB; 0 = this shape never uses one) the tiles of an XCD's last incomplete round split
+ * their K loop into 2..8 pieces that fill the round; the pieces are summed in the launch (exact int32, ticket in the header) before the
+ * epilogue.  Mixtral w2 (N 4096, K 14336, 8192 routed rows): 2.25 rounds -> 2 rounds + a short one (517 -> 452 us).  Results are
+ * bit-identical to asq_linear_w8a8_grouped. */
 size_t asq_grouped_workspace_bytes(int64_t M, int64_t N, int64_t K, int ngroups);
 int asq_linear_w8a8_grouped_ws(const int8_t *xq, const int8_t *w, void *out, int out_dtype,
                                const int32_t *group_offsets, int ngroups,
