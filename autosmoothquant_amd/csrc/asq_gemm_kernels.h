@@ -642,6 +642,108 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
     }
 }
 
+// Interior fast path of the staged epilogue (2-byte outputs): the wave tile lies completely inside the output (no row /
+// column bound anywhere), so every per-store compare-and-branch of epilogue_wave_staged disappears, and the three stages
+// are software-pipelined over the NTM 32-row token tiles instead of running back to back:
+//
+//     pack(0);   for im = 0 .. NTM-1:   issue the LDS reads of tile im  |  pack(im + 1)  |  global stores of tile im
+//
+// so the LDS round trip of tile im is covered by the conversions of tile im + 1, and the stores leave the wave spaced by VALU
+// work instead of in one burst.  What round 3 measured on the old form (tools/ubench/valu_rate + the ISA): the conversions
+// themselves are ~2.7k cycles per SIMD for a 256 x 256 fp16 tile, but every store instruction was its own serial chain --
+// bound compare + branch, ds_read_b128, s_waitcnt lgkmcnt(0) with the LDS latency exposed, four v_cndmask for the half flip,
+// a 64-bit VALU address -- ~160 cycles per store with one wave per SIMD (gemm_i8_p4: 13.6k-cycle epilogue), half hidden
+// with two (gemm_i8_p8: 7.7k).  Here a store costs two ds_read_b64 (the half flip is in the read ADDRESS), two SALU adds for
+// the row base and one global_store_dwordx4 with an SGPR base and a per-lane 32-bit offset computed once.
+// Image of one token tile: [32 rows][NTN x 64 B], NTM images side by side (no reuse: no wait for a previous tile's reads).
+//   NTN = 2 (128-B rows): chunk position = c ^ ((row >> 1) & 7), 8-byte halves flipped on odd rows          (as the slow path)
+//   NTN = 4 (256-B rows): chunk position p = c ^ (row & 15),     8-byte halves flipped for p >= 8            (as gemm_i8_p4's)
+// Both make the transposing ds_write_b64 (16 consecutive rows, one chunk) and the lane-linear reads conflict-free, and in both
+// a lane of the read side is flipped iff (lane >> 3) & 1.  Needs NTM * 32 * NTN * 64 bytes of wave-private LDS at `stage`.
+template <int NTM, int NTN, class Epi, class Get>
+__device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, unsigned stage)
+{
+    static_assert(Epi::kOutBytes == 2, "2-byte outputs");
+    static_assert(NTN == 2 || NTN == 4, "wave tile of 64 or 128 channels");
+    typedef __attribute__((address_space(3))) v2u *lds_u2;
+    constexpr int ROWB = NTN * 64;     // bytes per image row
+    constexpr int IMG = 32 * ROWB;     // one token tile: 4 / 8 KiB
+    constexpr int CH = ROWB / 16;      // 16-byte chunks per row: 8 / 16
+    constexpr int RPR = 1024 / ROWB;   // rows per 1-KiB read: 8 / 4
+    constexpr int NRD = 32 / RPR;      // reads per token tile: 4 / 8
+    constexpr int NV = NTN == 2 ? 2 : 4;  // distinct per-lane column offsets over the reads of a tile
+    const int ml = lane & 31, hi = lane >> 5;
+
+    float sr[NTM];
+#pragma unroll
+    for (int im = 0; im < NTM; ++im) sr[im] = Epi::kHasRow ? epi.row(mw0 + im * 32 + ml) : 1.0f;
+    v4f sc[NTN][4], bb[NTN][4];
+#pragma unroll
+    for (int in = 0; in < NTN; ++in)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) epi.cols(nw0 + in * 32 + 8 * g + 4 * hi, nw0 + NTN * 32, sc[in][g], bb[in][g]);
+
+    // write addresses: one per chunk c, reused by every token tile through the immediate offset
+    unsigned wa[CH];
+    {
+        unsigned w0;
+        if constexpr (NTN == 2) w0 = ml * ROWB + (((ml >> 1) & 7) << 4) + 8 * (hi ^ (ml & 1));
+        else w0 = ml * ROWB + ((ml & 15) << 4) + 8 * (hi ^ ((ml >> 3) & 1));
+#pragma unroll
+        for (int c = 0; c < CH; ++c) wa[c] = stage + (w0 ^ (unsigned)((c << 4) | (NTN == 4 ? (c >> 3) << 3 : 0)));
+    }
+    // read addresses (lane-linear, the 8-byte halves swapped for flipped lanes) and the lane's byte offsets in the output
+    // (one base register per read of a tile, opaque to the compiler: with a shared base it fuses the reads of two ROWS into one ds_read2st64_b64 and
+    // then needs four v_mov per store to bring a row's halves together; this way a row's two ds_read_b64 land in the store's register quad)
+    const unsigned flip = (lane >> 3) & 1;
+    unsigned ra0[NRD], ra1[NRD];
+#pragma unroll
+    for (int i = 0; i < NRD; ++i) {
+        ra0[i] = stage + lane * 16 + 8 * flip + i * 1024;
+        ra1[i] = ra0[i] ^ 8;
+        asm volatile("" : "+v"(ra0[i]), "+v"(ra1[i]));
+    }
+    const unsigned ldb = __builtin_amdgcn_readfirstlane((unsigned)(epi.N * 2));   // row pitch in bytes (the fast path requires 8 * ldb < 2^31)
+    const unsigned cb0 = (unsigned)(((lane & (CH - 1)) ^ (lane >> 4)) << 4);
+    unsigned voff[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) voff[j] = (unsigned)(lane / CH) * ldb + (cb0 ^ (unsigned)(64 * j));
+    typedef __attribute__((address_space(1))) v4i *glb_v4i;
+    const uint64_t tile = (uint64_t)(uintptr_t)uniform_ptr((const int8_t *)epi.out + (mw0 * epi.N + nw0) * 2);
+
+    using acc4_t = typename Epi::Mma::acc4_t;
+    auto pack_tile = [&](int im) {
+#pragma unroll
+        for (int in = 0; in < NTN; ++in) {
+            const typename Epi::Mma::acc_t a = get(in, im);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(lds_u2)(uintptr_t)(wa[in * 4 + g] + im * IMG) = epi.pack((acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g]);
+        }
+    };
+    pack_tile(0);
+#pragma unroll
+    for (int im = 0; im < NTM; ++im) {
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        v2u lo[NRD], up[NRD];
+#pragma unroll
+        for (int i = 0; i < NRD; ++i) {
+            lo[i] = *(lds_u2)(uintptr_t)(ra0[i] + im * IMG);
+            up[i] = *(lds_u2)(uintptr_t)(ra1[i] + im * IMG);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (im + 1 < NTM) pack_tile(im + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NRD; ++i) {
+            const uint64_t rowbase = tile + (uint64_t)(im * 32 + i * RPR) * ldb;   // SGPR pair: two scalar adds per store
+            *(glb_v4i)(uintptr_t)(rowbase + voff[i % NV]) = (v4i){(int)lo[i][0], (int)lo[i][1], (int)up[i][0], (int)up[i][1]};   // global_store_dwordx4 voff, data, s[base]
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // "generic": any M, N, K, any alignment.  64x64x64 tile, 4 waves (2x2), single LDS buffer.
 // Correctness net for odd shapes (K % 128 != 0, unaligned rows); not a tuned kernel.

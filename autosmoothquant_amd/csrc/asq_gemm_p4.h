@@ -111,7 +111,7 @@ __device__ __forceinline__ void p4_epilogue_rows(const Epi &epi, Get get, int64_
 }
 
 // PROBE (tools/ubench/clock_probe, needs ASQ_P8_PROBE): 1 = stamps; +2 = no LDS-DMA in the loop, +4 = no vmcnt wait / barrier in the
-// loop, +8 = no fragment ds_reads (ablations: results invalid).  Production: 0.
+// loop, +8 = no fragment ds_reads (ablations: results invalid), +16 = the round-2 epilogue (A/B against epilogue_wave_rows).  Production: 0.
 template <class Epi, int PROBE = 0>
 __global__ void __launch_bounds__(256, 1) gemm_i8_p4(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
                                                      int tiles_m, int tiles_n, Epi epi_in)
@@ -259,7 +259,12 @@ __global__ void __launch_bounds__(256, 1) gemm_i8_p4(const int8_t *__restrict__ 
     const int64_t mw0 = m0 + wm * 128, nw0 = n0 + wn * 128;
     static_assert(Epi::kOutBytes == 2, "gemm_i8_p4: 2-byte outputs (launch_gemm sends the other epilogues to p8)");
     const bool staged = ((((uintptr_t)epi.out) & 15) == 0) && (((N | epi.N) * Epi::kOutBytes) % 16 == 0);  // N: this launch's column bound, epi.N: the row stride
-    if (staged) {
+    // interior wave tile: pipelined, no bound checks (epilogue_wave_rows).  Only for the scalar-scale epilogues: with per-channel scales and a bias the
+    // 128 x 128 wave tile holds 128 registers of column vectors, and the pipelined form's extra address registers push it into scratch.
+    constexpr bool kRows = !Epi::kHasCol && !Epi::kHasBias;
+    if (kRows && !(PROBE & 16) && staged && mw0 + 128 <= M && nw0 + 128 <= N && epi.N < (int64_t(1) << 27)) {
+        if constexpr (kRows) epilogue_wave_rows<4, 4>(epi, [&](int in, int im) -> const v16i & { return acc[in][im]; }, mw0, nw0, lane, lds0 + wave * 32768);
+    } else if (staged) {
         p4_epilogue_rows(epi, [&](int in, int im) -> const v16i & { return acc[in][im]; }, mw0, nw0, lane, M, N, lds0 + wave * 16384);
     } else {  // unaligned output / ragged row pitch: direct stores in the matrix-core layout, two 128 x 64 halves
         epilogue_wave<2, 4>(epi, [&](int in, int im) -> const v16i & { return acc[in][im]; }, [](int im) { return im * 32; }, mw0, nw0, lane, M, N);

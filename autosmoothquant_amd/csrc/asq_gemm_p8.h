@@ -65,6 +65,7 @@ constexpr size_t P8_GROUPED_WS_BYTES = (size_t)8 * P8_CUS_PER_XCD * 256 * 256 * 
 //   ABL 1 = no LDS-DMA, 2 = no fragment ds_reads, 4 = no MFMA, 8 = no barriers, 16 = every fragment read issued twice,
 //       32 = timing stamps of block 0 waves 0/4, 64 = no s_setprio, 128 = per-block stamps,
 //       256 / 512 / 768 = epilogue stores nt / sc1 / sc0 sc1 instead of P8_STORE_DEFAULT.
+//       2048 = the round-2 staged epilogue on interior tiles too (A/B against epilogue_wave_rows).
 #ifdef ASQ_P8_PROBE
 static __device__ unsigned long long p8_dbg[2][4][8];
 // ABL & 128: per-block {start, prologue done, loop done, end} in s_memtime ticks, xcc_id, tile id, {start, end} in s_memrealtime (100 MHz) ticks
@@ -127,6 +128,9 @@ template <int ABL> __device__ __forceinline__ v4i p8_ldfrag(unsigned lds_addr, i
 __device__ __forceinline__ void p8_dma16(const int8_t *sbase, unsigned voff, unsigned lds_dst)
 {
     unsigned keep;
+#ifdef ASQ_P8_PROBE   // (some ablation instantiations of tools/ubench/clock_probe evaluate base + k on the VALU: pin it again; production builds are untouched)
+    sbase = uniform_ptr(sbase);
+#endif
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
@@ -567,7 +571,13 @@ if constexpr (MMA::kIsInt) {
     if (staged) {
         if constexpr (Epi::kOutBytes >= 2) {
             P8_BAR();  // every wave's ring reads are done and every wave's (dead) DMAs have landed: the ring becomes staging space
-            epilogue_wave_staged<4, P8_STORE_POLICY(ABL)>(epi, get, mw0, n0 + wn * 64, lane, Mw, N, lds0 + wave * 16384);
+            bool rows_path = false;
+            if constexpr (Epi::kOutBytes == 2 && P8_STORE_POLICY(ABL) == 0 && !(ABL & 2048))   // interior wave tile: no bound checks, pipelined (epilogue_wave_rows)
+                rows_path = !half && mw0 + 128 <= M && n0 + wn * 64 + 64 <= N && epi.N < (int64_t(1) << 27);
+            if (rows_path) {
+                if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<4, 2>(epi, get, mw0, n0 + wn * 64, lane, lds0 + wave * 16384);
+            } else
+                epilogue_wave_staged<4, P8_STORE_POLICY(ABL)>(epi, get, mw0, n0 + wn * 64, lane, Mw, N, lds0 + wave * 16384);
         }
     } else {
         epilogue_wave<2, 4>(epi, get, [](int im) { return im * 32; }, mw0, n0 + wn * 64, lane, Mw, N);

@@ -465,6 +465,10 @@ def main():
                     help="untimed steps run for this long BEFORE the --warmup steps: after an idle period the power controller starts ~15-25 %% below "
                          "the clock it settles at under sustained GEMM load and takes ~20 ms to get there (profiles/r2_clock_power_evidence.md section 4); "
                          "0 disables; reported as dvfs_settle_ms")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for --gpus > 1.  nccl (= RCCL over xGMI) is the measured configuration; gloo exists so that the WHOLE multi-rank flow "
+                         "(arena broadcast, fingerprints, barriers, max-over-ranks timing) can be rehearsed on a box with fewer GPUs than ranks: ranks then share "
+                         "device LOCAL_RANK %% device_count and the line is marked rehearsal=true (not a scaling measurement)")
     ap.add_argument("--no-cfg3", action="store_true", help="default workload only: skip the LLaMA-2-7B 32-layer decoder forward (BASELINE configs[2]) that is timed after the main step")
     args = ap.parse_args()
 
@@ -474,12 +478,20 @@ def main():
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    rehearsal = world > 1 and args.dist_backend != "nccl"
+    if local_rank >= ndev and not rehearsal:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} HIP device(s) are visible (one process per GPU)")
+    dev_index = local_rank % ndev if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     from autosmoothquant_amd import _lib, replica
     _lib.lib()  # fail loudly if the HIP library is missing
@@ -710,6 +722,9 @@ def main():
             out["step_fused_qkv"] = fused_qkv
         if bcast:
             out["weight_broadcast"] = bcast
+        if rehearsal:
+            out["rehearsal"] = True
+            out["config"]["parallelism"] += f" -- REHEARSAL over gloo with {ndev} device(s) shared by {world} ranks: exercises the multi-rank code path, not a scaling measurement"
         if moe_extra:
             out["config"].update(moe_extra)
             out["config"]["note"] = "step = quantise + grouped w1, w3 + SiLU*mul (torch) + per-token quantise + grouped w2; TOPS counts the " + ("fp8 flops (FP8LinearDynamic math, unit-scale block-scaled MFMA)" if args.fp8 else "int8 ops")

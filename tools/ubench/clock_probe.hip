@@ -14,7 +14,7 @@
 //   uniform full-range uniform int8 (the r1 ceiling of 3500 TOPS was measured on this)
 //   zeros
 //
-//   usage: clock_probe [seconds per arm = 1.5] [what = all | gemm | mfma | abl | pmc]
+//   usage: clock_probe [seconds per arm = 1.5] [what = all | gemm | mfma | abl | pmc | p4 | epi]
 //   build: see Makefile (-DASQ_P8_PROBE is set by this file)
 #define ASQ_P8_PROBE 1
 #include "../../autosmoothquant_amd/csrc/asq_api.hip"
@@ -504,6 +504,15 @@ int main(int argc, char **argv)
         run_gemm_p4("benchK16k", dxb, dwb, e16, M, N, KL, seconds, smp);
         run_gemm("p8 bench", dxb, dwb, e16, M, N, K, seconds, smp);
         run_gemm_p4("bench", dxb, dwb, e16, M, N, K, seconds, smp);
+    }
+    if (what == "epi") {   // round 3: the pipelined interior epilogue (epilogue_wave_rows); p4 against its round-2 epilogue in one process (for p8 run the previous build's "gemm" arm beside this)
+        for (int rep = 0; rep < 2; ++rep) {
+            run_gemm("p8 rows", dxb, dwb, e16, M, N, K, seconds, smp);
+            run_gemm_p4<decltype(e16), 17>("r2epi", dxb, dwb, e16, M, N, K, seconds, smp);
+            run_gemm_p4("rows", dxb, dwb, e16, M, N, K, seconds, smp);
+        }
+        run_gemm("u rows", dxu, dwu, e16, M, N, K, seconds, smp);
+        run_gemm_p4("u rows", dxu, dwu, e16, M, N, K, seconds, smp);
     }
     if (what == "all" || what == "abl") {
         printf("== gemm_i8_p8 ablations on bench data: what each part of the schedule costs in time, clock and power (results invalid) ==\n");
