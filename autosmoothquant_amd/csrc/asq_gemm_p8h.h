@@ -205,7 +205,12 @@ if constexpr (MMA::kIsInt) {
     if (staged) {
         if constexpr (Epi::kOutBytes >= 2) {
             __builtin_amdgcn_s_barrier();  // all ring reads done, all (dead) DMAs landed: the ring becomes staging space
-            epilogue_wave_staged<2>(epi, get, m0 + wm * 64, n0 + wn * 64, lane, M, N, lds0 + wave * 16384);
+            bool rows_path = false;
+            if constexpr (Epi::kOutBytes == 2) rows_path = m0 + wm * 64 + 64 <= M && n0 + wn * 64 + 64 <= N && epi.N < (int64_t(1) << 27);   // interior wave tile
+            if (rows_path) {
+                if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<2, 2>(epi, get, m0 + wm * 64, n0 + wn * 64, lane, lds0 + wave * 16384);
+            } else
+                epilogue_wave_staged<2>(epi, get, m0 + wm * 64, n0 + wn * 64, lane, M, N, lds0 + wave * 16384);
         }
     } else {
         epilogue_wave<2, 2>(epi, get, [](int im) { return im * 32; }, m0 + wm * 64, n0 + wn * 64, lane, M, N);

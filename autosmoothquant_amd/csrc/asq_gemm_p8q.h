@@ -211,7 +211,12 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8q(const int8_t *__restrict__
     if (staged) {
         if constexpr (Epi::kOutBytes >= 2) {
             __builtin_amdgcn_s_barrier();  // all ring reads done, all (dead) DMAs landed: the ring becomes staging space
-            epilogue_wave_staged<1>(epi, get, m0 + wm * 32, n0 + wn * 64, lane, M, N, lds0 + wave * 16384);
+            bool rows_path = false;
+            if constexpr (Epi::kOutBytes == 2) rows_path = m0 + wm * 32 + 32 <= M && n0 + wn * 64 + 64 <= N && epi.N < (int64_t(1) << 27);   // interior wave tile
+            if (rows_path) {
+                if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<1, 2>(epi, get, m0 + wm * 32, n0 + wn * 64, lane, lds0 + wave * 16384);
+            } else
+                epilogue_wave_staged<1>(epi, get, m0 + wm * 32, n0 + wn * 64, lane, M, N, lds0 + wave * 16384);
         }
     } else {
         epilogue_wave<2, 1>(epi, get, [](int im) { return im * 32; }, m0 + wm * 32, n0 + wn * 64, lane, M, N);
