@@ -15,6 +15,7 @@ int forced_kernel()
             else if (!strcmp(e, "p8")) v = KERN_P8;
             else if (!strcmp(e, "p8h")) v = KERN_P8H;
             else if (!strcmp(e, "p4")) v = KERN_P4;
+            else if (!strcmp(e, "p16")) v = KERN_P16;
             else if (!strcmp(e, "p8q")) v = KERN_P8Q;
             else if (!strcmp(e, "skinny")) v = KERN_SKINNY;
         }
@@ -39,11 +40,12 @@ using namespace asq;
 extern "C" const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K)
 {
     const GemmKernel kern = pick_kernel(nullptr, nullptr, M, N, K);
-    if (plan_tail_peel(kern, M, N, K).n_main > 0) return kern == KERN_P8 ? "p8+tail" : kern == KERN_P8H ? "p8h+tail" : "p4+tail";
+    if (plan_tail_peel(kern, M, N, K).n_main > 0) return kern == KERN_P8 ? "p8+tail" : kern == KERN_P8H ? "p8h+tail" : kern == KERN_P16 ? "p16+tail" : "p4+tail";
     switch (kern) {
     case KERN_P8: return "p8";
     case KERN_P8H: return "p8h";
     case KERN_P4: return "p4";
+    case KERN_P16: return "p16";
     case KERN_P8Q: return "p8q";
     case KERN_SKINNY: return "skinny";
     default: return "generic";

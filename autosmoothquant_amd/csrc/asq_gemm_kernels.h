@@ -660,11 +660,16 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
 //   NTN = 4 (256-B rows): chunk position p = c ^ (row & 15),     8-byte halves flipped for p >= 8            (as gemm_i8_p4's)
 // Both make the transposing ds_write_b64 (16 consecutive rows, one chunk) and the lane-linear reads conflict-free, and in both
 // a lane of the read side is flipped iff (lane >> 3) & 1.  Needs NTM * 32 * NTN * 64 bytes of wave-private LDS at `stage`.
-template <int NTM, int NTN, class Epi, class Get>
+// L16: the accumulators are in the 16 x 16 layout of v_mfma_i32_16x16x64_i8 (gemm_i8_p16): lane l owns token (l & 15) and channels 4 * (l >> 4) .. + 3 of
+// 16 x 16 tiles, get(in16, im16) returns 4 registers.  The images, the read side and the stores are the same; a lane writes, for 16-channel tile in16 and
+// 16-token tile im16 = 2 * im + h, the 8 bytes of chunk 2 * in16 + (q >> 1), half q & 1 of row 16 * h + t (16 consecutive lanes = 16 rows, one chunk:
+// conflict-free under the same swizzle).
+template <int NTM, int NTN, bool L16 = false, class Epi, class Get>
 __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, unsigned stage)
 {
     static_assert(Epi::kOutBytes == 2, "2-byte outputs");
     static_assert(NTN == 2 || NTN == 4, "wave tile of 64 or 128 channels");
+    static_assert(!L16 || NTN == 2, "16 x 16 layout: 64-channel wave tiles");
     typedef __attribute__((address_space(3))) v2u *lds_u2;
     constexpr int ROWB = NTN * 64;     // bytes per image row
     constexpr int IMG = 32 * ROWB;     // one token tile: 4 / 8 KiB
@@ -672,25 +677,33 @@ __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int6
     constexpr int RPR = 1024 / ROWB;   // rows per 1-KiB read: 8 / 4
     constexpr int NRD = 32 / RPR;      // reads per token tile: 4 / 8
     constexpr int NV = NTN == 2 ? 2 : 4;  // distinct per-lane column offsets over the reads of a tile
-    const int ml = lane & 31, hi = lane >> 5;
+    const int ml = L16 ? (lane & 15) : (lane & 31), hi = L16 ? (lane >> 4) : (lane >> 5);   // L16: token within the tile, channel quad 0..3
+    constexpr int NSR = L16 ? 2 * NTM : NTM;   // row scales: one per 16- / 32-token tile
+    constexpr int NSC = L16 ? 1 : 4;           // column vectors per 16- / 32-channel tile
 
-    float sr[NTM];
+    float sr[NSR];
 #pragma unroll
-    for (int im = 0; im < NTM; ++im) sr[im] = Epi::kHasRow ? epi.row(mw0 + im * 32 + ml) : 1.0f;
-    v4f sc[NTN][4], bb[NTN][4];
+    for (int i = 0; i < NSR; ++i) sr[i] = Epi::kHasRow ? epi.row(mw0 + i * (L16 ? 16 : 32) + ml) : 1.0f;
+    v4f sc[L16 ? 2 * NTN : NTN][NSC], bb[L16 ? 2 * NTN : NTN][NSC];
+    if constexpr (L16) {
 #pragma unroll
-    for (int in = 0; in < NTN; ++in)
+        for (int in = 0; in < 2 * NTN; ++in) epi.cols(nw0 + in * 16 + 4 * hi, nw0 + NTN * 32, sc[in][0], bb[in][0]);
+    } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) epi.cols(nw0 + in * 32 + 8 * g + 4 * hi, nw0 + NTN * 32, sc[in][g], bb[in][g]);
+        for (int in = 0; in < NTN; ++in)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) epi.cols(nw0 + in * 32 + 8 * g + 4 * hi, nw0 + NTN * 32, sc[in][g], bb[in][g]);
+    }
 
-    // write addresses: one per chunk c, reused by every token tile through the immediate offset
+    // write addresses: one per chunk c (L16: per 16-channel tile), reused by every token tile through the immediate offset
     unsigned wa[CH];
     {
         unsigned w0;
-        if constexpr (NTN == 2) w0 = ml * ROWB + (((ml >> 1) & 7) << 4) + 8 * (hi ^ (ml & 1));
+        if constexpr (L16) w0 = ml * ROWB + ((((hi >> 1) ^ (ml >> 1)) & 7) << 4) + 8 * ((hi ^ ml) & 1);
+        else if constexpr (NTN == 2) w0 = ml * ROWB + (((ml >> 1) & 7) << 4) + 8 * (hi ^ (ml & 1));
         else w0 = ml * ROWB + ((ml & 15) << 4) + 8 * (hi ^ ((ml >> 3) & 1));
 #pragma unroll
-        for (int c = 0; c < CH; ++c) wa[c] = stage + (w0 ^ (unsigned)((c << 4) | (NTN == 4 ? (c >> 3) << 3 : 0)));
+        for (int c = 0; c < CH; ++c) wa[c] = stage + (w0 ^ (unsigned)(L16 ? (c << 5) : ((c << 4) | (NTN == 4 ? (c >> 3) << 3 : 0))));   // (L16: c = in16, only 2 * NTN of them used)
     }
     // read addresses (lane-linear, the 8-byte halves swapped for flipped lanes) and the lane's byte offsets in the output
     // (one base register per read of a tile, opaque to the compiler: with a shared base it fuses the reads of two ROWS into one ds_read2st64_b64 and
@@ -713,12 +726,20 @@ __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int6
 
     using acc4_t = typename Epi::Mma::acc4_t;
     auto pack_tile = [&](int im) {
+        if constexpr (L16) {
 #pragma unroll
-        for (int in = 0; in < NTN; ++in) {
-            const typename Epi::Mma::acc_t a = get(in, im);
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *(lds_u2)(uintptr_t)(wa[in * 4 + g] + im * IMG) = epi.pack((acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g]);
+                for (int in = 0; in < 2 * NTN; ++in)
+                    *(lds_u2)(uintptr_t)(wa[in] + im * IMG + h * 16 * ROWB) = epi.pack(get(in, 2 * im + h), sr[2 * im + h], sc[in][0], bb[in][0]);
+        } else {
+#pragma unroll
+            for (int in = 0; in < NTN; ++in) {
+                const auto a = get(in, im);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(lds_u2)(uintptr_t)(wa[in * 4 + g] + im * IMG) = epi.pack((acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g]);
+            }
         }
     };
     pack_tile(0);
@@ -810,6 +831,7 @@ constexpr int WS_MAX_GROUPS = (WS_HEADER_BYTES - 16) / 4;
 
 #include "asq_gemm_p8.h"
 #include "asq_gemm_p4.h"
+#include "asq_gemm_p16.h"
 #include "asq_gemm_p8h.h"
 #include "asq_gemm_p8q.h"
 #include "asq_gemm_skinny.h"
@@ -857,7 +879,7 @@ __global__ void __launch_bounds__(256) splitk_reduce(const int32_t *__restrict__
 // ---------------------------------------------------------------------------------
 // dispatch + launch
 // ---------------------------------------------------------------------------------
-enum GemmKernel { KERN_GENERIC = 0, KERN_SKINNY = 1, KERN_P8 = 2, KERN_P8H = 3, KERN_P4 = 4, KERN_P8Q = 5 };
+enum GemmKernel { KERN_GENERIC = 0, KERN_SKINNY = 1, KERN_P8 = 2, KERN_P8H = 3, KERN_P4 = 4, KERN_P8Q = 5, KERN_P16 = 6 };
 
 int forced_kernel();  // env ASQ_GEMM_KERNEL=generic|skinny|p8|p8h (development / A-B aid), asq_gemm.hip
 
@@ -867,7 +889,7 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
     const bool tiled_ok = aligned && K % 128 == 0 && K >= 128 && K <= (1 << 24);
     const int f = forced_kernel();
     if (f == KERN_GENERIC) return KERN_GENERIC;
-    if (tiled_ok && (f == KERN_P8 || f == KERN_P8H || f == KERN_P4 || f == KERN_P8Q)) return (GemmKernel)f;
+    if (tiled_ok && (f == KERN_P8 || f == KERN_P8H || f == KERN_P4 || f == KERN_P8Q || f == KERN_P16)) return (GemmKernel)f;
     if (tiled_ok && M <= 1024 && M * K < (1ll << 32) && f == KERN_SKINNY) return KERN_SKINNY;  // (32-bit row offsets in the DMA address)
     if (tiled_ok && f < 0) {
         // measured crossover (tools/cold_grid.sh: 48..256 rows x 8 LLaMA/OPT/Mixtral weight shapes, weights rotated
@@ -1115,7 +1137,7 @@ static inline TailPeel plan_tail_peel(GemmKernel kern, int64_t M, int64_t N, int
 {
     TailPeel p;
     // (the remainder launch costs ~13 us at K = 4096; the extra wave it replaces ~20 us for the 128-row kernel, 35-45 us for the 256-row ones)
-    if (kern != KERN_P8 && kern != KERN_P4 && kern != KERN_P8H) return p;
+    if (kern != KERN_P8 && kern != KERN_P4 && kern != KERN_P8H && kern != KERN_P16) return p;
     static const bool disabled = getenv("ASQ_NO_TAIL") != nullptr;  // development / A-B aid
     if (disabled || forced_kernel() >= 0 || forced_ksplit() > 0 || N % 4 != 0 || K < 4096) return p;  // (a short K loop makes the extra wave cheap)
     const int64_t rows = kern == KERN_P8H ? 128 : 256;
@@ -1201,6 +1223,20 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
             return (int)e;
         }
         hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(256), P4_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, epi);
+        return asq_after_launch(s, what);
+    }
+    // the 256 x 256 kernel on v_mfma_i32_16x16x64_i8 (asq_gemm_p16.h): plain launches with 2-byte outputs
+    if (kern == KERN_P16 && !kP4) kern = KERN_P8;
+    if constexpr (kP4) if (kern == KERN_P16) {
+        const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
+        ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
+        auto kfn = gemm_i8_p16<Epi>;
+        hipError_t e = ensure_dynamic_lds((const void *)kfn, P8_LDS_BYTES);
+        if (e != hipSuccess) {
+            asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+            return (int)e;
+        }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, epi);
         return asq_after_launch(s, what);
     }
     if (kern == KERN_P8) {

@@ -1,0 +1,254 @@
+// "p16": the 256(m) x 256(n) x 128(k) INT8 GEMM of asq_gemm_p8.h on the OTHER int8 matrix instruction,
+// v_mfma_i32_16x16x64_i8.  Included by asq_gemm_kernels.h after asq_gemm_p8.h (shares its LDS-DMA helper, unit images, ring,
+// phase / barrier cadence and XCD tile map; plain launches only: no groups, no K split, int8 operands).
+//
+// Why.  At 4096^3 on real operands the MI355X runs this GEMM against its 1.4 kW socket limit, so its time is its energy
+// (profiles/r2_clock_power_evidence.md): ~30 of the 46.5 mJ are the matrix cores' own.  tools/ubench/mfma_shape_power (operands in
+// registers, ~1 s per arm, profiles/r3_mfma_shape_power.txt) sustains
+//                                   v_mfma_i32_32x32x32_i8      v_mfma_i32_16x16x64_i8
+//     zeros                              4955 TOPS                   4889        (not power-limited: the issue rates)
+//     bench-like operands                3386                        3911  +15.5 %
+//     uniform int8                       3146                        3743  +19 %
+// the 16 x 16 x 64 form moves a quarter of the accumulator registers per instruction (4 instead of 16 for half the MACs: half the
+// accumulator traffic per MAC) for the same operand bytes.  The fragment bytes read from LDS per MAC are set by the wave tile
+// (128 x 64, unchanged), not by the instruction shape.
+//
+// What changes against p8 (everything else is its schedule, line for line):
+//   * a phase (quadrant of 64 tokens x 32 channels x 128 k) is 2 k-steps of 64 x {2 channel tiles x 4 token tiles} = 16 MFMAs of 16 cycles
+//     (p8: 4 k-steps x 2 tiles = 8 of 32 cycles); the W fragment stays for 4 consecutive instructions;
+//   * a fragment is 16 rows x 64 k-bytes: lane l reads row (l & 15), 16-byte chunk (kstep * 4 + (l >> 4)) of the unit image
+//     [128 rows][8 chunks], chunk ^= (row >> 1) & 7.  With ds_read_b128's four 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32)
+//     every group touches 16 different 16-byte slots of the 256-byte bank row: conflict-free on the image p8 already builds;
+//   * accumulators: acc[m-half][n-half][token tile 0..3][channel tile 0..1], 4 registers each (128 in all, as p8); in the matrix-core
+//     layout lane l owns token (l & 15) and channels 4 * (l >> 4) .. + 3 of a 16 x 16 tile -- again 4 consecutive channels of one
+//     token, so the staged row epilogue only needs other write addresses (epilogue_wave_rows<.., L16 = true>).
+// Edge tiles, unaligned outputs and 4-byte outputs leave through direct stores (epilogue_wave16): launch_gemm dispatches this kernel for
+// 2-byte outputs only.
+#pragma once
+
+namespace asq {
+
+struct MmaI8x16 {  // one v_mfma_i32_16x16x64_i8: 16 (A rows) x 16 (B rows) x 64 k-bytes, exact
+    static __device__ __forceinline__ v4i mma(const v4i &a, const v4i &b, const v4i &c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
+};
+
+// Direct-store epilogue of a 128(m) x 64(n) wave tile in the 16 x 16 layout (edge tiles / unaligned / 4-byte outputs): a store instruction
+// touches 16 rows with 4 x 8 (16) bytes each -- slow, and only used where the row epilogue cannot be.
+template <class Epi, class Get> __device__ __forceinline__ void epilogue_wave16(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, int64_t M, int64_t N)
+{
+    const int t = lane & 15, q = lane >> 4;
+    static_for<4>([&](auto in_) __attribute__((always_inline)) {
+        constexpr int in16 = decltype(in_)::value;
+        const int64_t n = nw0 + in16 * 16 + 4 * q;
+        v4f sc = (v4f){0.f, 0.f, 0.f, 0.f}, bb = (v4f){0.f, 0.f, 0.f, 0.f};
+        if (n < N) epi.cols(n, N, sc, bb);
+        static_for<8>([&](auto im_) __attribute__((always_inline)) {
+            constexpr int im16 = decltype(im_)::value;
+            const int64_t m = mw0 + im16 * 16 + t;
+            if (m < M && n < N) {
+                const float sr = Epi::kHasRow ? epi.row(m) : 1.0f;
+                epi.store4(m, n, get(in16, im16), sr, sc, bb, N);
+            }
+        });
+    });
+}
+
+template <class Epi, int ABL = 0>
+__global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
+                                                      int tiles_m, int tiles_n, Epi epi_in)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    static_assert(P8_ABL_OK(ABL), "probe variants need -DASQ_P8_PROBE (tools/ubench)");
+    static_assert(Epi::Mma::kIsInt, "int8 operands");
+
+    P8_BLK_RT(6);
+    P8_BLK(0);
+    constexpr int GM = 4;
+    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const Epi epi = epi_in.rebased(0, 0, M, N);
+    const int per_group = GM * tiles_n;
+    const int group = id / per_group, in_group = id - group * per_group;
+    const int first_m = group * GM;
+    const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int tile_m = first_m + in_group % gm, tile_n = in_group / gm;
+    const int64_t m0 = (int64_t)tile_m * 256, n0 = (int64_t)tile_n * 256;
+
+    // ---- DMA sources (as p8): this wave fills row-groups 2*wave, 2*wave+1 (8 rows each) of every unit
+    const int nt = (int)(K / 128);
+    const int8_t *const xbase = uniform_ptr(x + m0 * K);
+    const int8_t *const wbase = uniform_ptr(w + n0 * K);
+    const int64_t mrem = M - m0 - 1, nrem = N - n0 - 1;  // last valid local row
+    unsigned voff[4][2];  // [kind][i]: X-even, W-even, W-odd, X-odd
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ru = (wave * 2 + i) * 8 + (lane >> 3);                      // row within the unit, 0..127
+        const unsigned cb = (unsigned)(((lane & 7) ^ ((ru >> 1) & 7)) * 16);  // swizzled source chunk
+        int64_t rxe = (ru >> 6) * 128 + (ru & 63), rxo = rxe + 64;            // local tile rows
+        int64_t rwe = (ru >> 5) * 64 + (ru & 31), rwo = rwe + 32;
+        rxe = rxe < mrem ? rxe : mrem;
+        rxo = rxo < mrem ? rxo : mrem;
+        rwe = rwe < nrem ? rwe : nrem;
+        rwo = rwo < nrem ? rwo : nrem;
+        voff[0][i] = (unsigned)(rxe * K) + cb;
+        voff[1][i] = (unsigned)(rwe * K) + cb;
+        voff[2][i] = (unsigned)(rwo * K) + cb;
+        voff[3][i] = (unsigned)(rxo * K) + cb;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
+    const unsigned dma_dst = lds0 + wave * 2048;  // + stage*P8_STAGE + kind*P8_UNIT + i*1024
+
+    // ---- fragment read addresses: one VGPR per (stage, operand, k-step of 64); + 2048 * tile (16 rows) + the unit as immediates
+    const int t16 = lane & 15, q16 = lane >> 4, sw = (t16 >> 1) & 7;
+    unsigned xb[2][2], wbp[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const unsigned off = lds0 + t16 * 128 + ((((kk * 4 + q16) ^ sw)) << 4) + s * P8_STAGE;
+            xb[s][kk] = off + wm * 64 * 128;   // X units: this wave's 64 rows
+            wbp[s][kk] = off + wn * 32 * 128;  // W units: this wave's 32 rows
+            asm volatile("" : "+v"(xb[s][kk]), "+v"(wbp[s][kk]));
+        }
+
+    v4i acc[2][2][4][2];  // [m-half][n-half][token tile][channel tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (v4i){0, 0, 0, 0};
+
+    const int klast = (nt - 1) * 128;
+    auto issue = [&](int kind, int stage, int k0) {
+        const int8_t *b = ((kind == 0 || kind == 3) ? xbase : wbase) + k0;  // SALU
+#pragma unroll
+        for (int i = 0; i < 2; ++i) p8_dma16(b, voff[kind][i], dma_dst + stage * P8_STAGE + kind * P8_UNIT + i * 1024);
+    };
+
+    // ---- prologue: K-tile 0 entirely (units 0..3), wait for the two units P1 reads
+#pragma unroll
+    for (int kind = 0; kind < 4; ++kind) issue(kind, 0, 0);
+    P8_WAIT_VM(4);
+    P8_BAR();
+    if (wm == 1) P8_BAR();  // stagger: the wm=1 group runs one barrier behind
+    P8_BLK(1);
+
+    v4i xf[4][2], wa[2][2], wb[2][2];  // [tile][k-step]
+    auto ld = [&](unsigned a) { return *(p8_lds_v4i)(uintptr_t)a; };
+    // 16 MFMAs of one quadrant: k-step outermost, then the W fragment (kept for 4 instructions), then the token tiles
+    auto quadrant = [&](v4i (&A)[4][2], const v4i (&wf)[2][2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) A[jt][it] = MmaI8x16::mma(wf[it][kk], xf[jt][kk], A[jt][it]);
+    };
+
+    // one K-tile at LDS stage S (compile-time), prefetching K-tile (t+1) into stage S^1: p8's four phases
+    auto ktile = [&](auto stage_tag, int t) {
+        constexpr int S = decltype(stage_tag)::value, NS = S ^ 1;
+        int kn = (t + 1) * 128;
+        kn = kn < klast ? kn : klast;
+
+        // ---------------- P1: (m-half 0, n-half 0): reads W-even (4) + X-even (8)
+        issue(0, NS, kn);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) wa[it][kk] = ld(wbp[S][kk] + 1 * P8_UNIT + it * 2048);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) xf[jt][kk] = ld(xb[S][kk] + 0 * P8_UNIT + jt * 2048);
+        P8_WAIT_VM(4);
+        P8_BAR();
+        P8_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        P8_PRIO(1);
+        quadrant(acc[0][0], wa);
+        P8_PRIO(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_BAR();
+
+        // ---------------- P2: (m-half 0, n-half 1): reads W-odd (4)
+        issue(1, NS, kn);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) wb[it][kk] = ld(wbp[S][kk] + 2 * P8_UNIT + it * 2048);
+        P8_WAIT_VM(4);
+        P8_BAR();
+        P8_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        P8_PRIO(1);
+        quadrant(acc[0][1], wb);
+        P8_PRIO(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_BAR();
+
+        // ---------------- P3: (m-half 1, n-half 1): reads X-odd (8)
+        issue(2, NS, kn);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) xf[jt][kk] = ld(xb[S][kk] + 3 * P8_UNIT + jt * 2048);
+        P8_BAR();
+        P8_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        P8_PRIO(1);
+        quadrant(acc[1][1], wb);
+        P8_PRIO(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_BAR();
+
+        // ---------------- P4: (m-half 1, n-half 0): W-even fragments are still in wa[]
+        issue(3, NS, kn);
+        P8_WAIT_VM(4);
+        P8_BAR();
+        __builtin_amdgcn_sched_barrier(0);
+        P8_PRIO(1);
+        quadrant(acc[1][0], wa);
+        P8_PRIO(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_BAR();
+    };
+
+    int t = 0;
+    for (; t + 1 < nt; t += 2) {
+        ktile(std::integral_constant<int, 0>{}, t);
+        ktile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (t < nt) ktile(std::integral_constant<int, 0>{}, t);
+
+    P8_BLK(2);
+    P8_WAIT_VM(0);          // drain the dead prefetches before LDS is released
+    if (wm == 0) P8_BAR();  // balance the stagger barrier
+
+    // accumulator tile (in16 = 16-channel tile 0..3, im16 = 16-token tile 0..7) -> rows mw0 + 16*im16, cols nw0 + 16*in16
+    auto get = [&](int in16, int im16) -> const v4i & { return acc[im16 >> 2][in16 >> 1][im16 & 3][in16 & 1]; };
+    const int64_t mw0 = m0 + wm * 128, nw0 = n0 + wn * 64;
+    bool rows_path = false;
+    if constexpr (Epi::kOutBytes == 2)
+        rows_path = ((((uintptr_t)epi.out) & 15) == 0) && ((epi.N * 2) % 16 == 0) && mw0 + 128 <= M && nw0 + 64 <= N && epi.N < (int64_t(1) << 27);
+    if constexpr (Epi::kOutBytes == 2) P8_BAR();  // (block-uniform) every wave's ring reads are done and every wave's (dead) DMAs have landed: the ring becomes staging space
+    if (rows_path) {
+        if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<4, 2, true>(epi, get, mw0, nw0, lane, lds0 + wave * 16384);
+    } else {
+        epilogue_wave16(epi, get, mw0, nw0, lane, M, N);
+    }
+#ifdef ASQ_P8_PROBE
+    if constexpr (ABL & 128) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        P8_BLK(3);
+        P8_BLK_RT(7);
+    }
+#endif
+}
+
+}  // namespace asq
