@@ -914,11 +914,12 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
             if (th >= 16 && th <= 128 && K < 16384 && !(K >= 8192 && th >= 40 && th < 80)) return KERN_P8Q;
             return KERN_P8H;
         }
-        // 256 x 256 tiles, 8 waves (p8) or 4 waves with 128 x 128 per wave (p4: fewer LDS bytes per MFMA, but a one-wave-per-SIMD epilogue
-        // that costs 6k cycles more per tile).  Measured (ASQ_GEMM_KERNEL=p8|p4 tools/kbench.py, alternating, profiles/r2_p4_experiment.md):
-        // p4 wins once the K loop is >= 64 K-tiles long -- 4096x4096x8192 +1.7 %, x11008 (LLaMA down_proj) +1.9 %, x16384 +3.0 %,
-        // 8192^3 +2.4 % -- and loses 1 % at 4096^3.  (launch_gemm sends fp8 and grouped launches to p8.)
-        return K >= 8192 ? KERN_P4 : KERN_P8;
+        // 256 x 256 tiles: gemm_i8_p16, p8's schedule on v_mfma_i32_16x16x64_i8.  Under the socket power limit the GEMM's time is its energy, and the
+        // 16 x 16 x 64 instruction moves half the accumulator bytes per MAC: measured against p8 in one process (profiles/r3_p8_vs_p16_ab.txt, bit-identical
+        // outputs) 4096^3 56.8 -> 51.1 us, 8192 x 4096 x 4096 -8 %, 16384 x 12288 x 4096 -8 %, 4096 x 4096 x 8192 102.3 -> 92.0 (p4, the round-2 choice for
+        // K >= 8192 -- 128 x 128 per wave, a third fewer fragment bytes -- gained 1.7-3 % there).  launch_gemm sends what p16 does not carry (4-byte and
+        // int8 outputs, fp8 operands, K splits, grouped launches) to p8; p8 and p4 stay reachable through ASQ_GEMM_KERNEL.
+        return KERN_P16;
     }
     return KERN_GENERIC;
 }

@@ -46,7 +46,7 @@ def test_argument_errors_without_gpu():
     assert h.asq_gemm_workspace_bytes(32, 5120, 20480) == hdr + 256 * 2 * 2 * 8192    # cfg4's per-GPU shape: stream-K, 256 blocks x 2 segments x 16 KB partial tiles
     assert h.asq_gemm_workspace_bytes(1, 5120, 20480) == 0              # ... but not at one row (the reduction costs more than it saves)
     assert h.asq_workspace_init(None, 1 << 20, None) == -1 and h.asq_workspace_init(256, 100, None) == -5
-    assert h.asq_gemm_kernel_name(4096, 4096, 4096) == b"p8"
+    assert h.asq_gemm_kernel_name(4096, 4096, 4096) == b"p16"
     assert h.asq_gemm_kernel_name(64, 14336, 4096) == b"skinny"          # decode batch: weight stream
     assert h.asq_gemm_kernel_name(128, 4096, 4096) == b"skinny"          # 2 m-blocks x 256 channel tiles: the weight stream (11.7 vs 15.0 us)
     assert h.asq_gemm_kernel_name(192, 4096, 4096) == b"p8q"             # more rows on >= 16 tiles of 128 x 256: the 128 x 128 kernel
@@ -60,15 +60,15 @@ def test_argument_errors_without_gpu():
     assert h.asq_gemm_kernel_name(512, 4096, 11008) == b"p8h"            # 64 tiles at a long K: p8h's split-K is as good, kept
     assert h.asq_gemm_kernel_name(64, 5120, 20480) == b"p8h"
     assert h.asq_gemm_kernel_name(2048, 4096, 4096) == b"p8h"            # 128 tiles of 256 rows
-    assert h.asq_gemm_kernel_name(2048, 5120, 5120) == b"p8"             # 160 tiles: the 256-row kernel is the more efficient one
+    assert h.asq_gemm_kernel_name(2048, 5120, 5120) == b"p16"            # 160 tiles: the 256-row kernel is the more efficient one
     assert h.asq_gemm_kernel_name(4, 4096, 4095) == b"generic"
     # tail peel: 6 x 43 = 258 tiles of 256 rows -> 252 in the main launch + one tile column as 12 x 2 tiles of 128 x 128
-    assert h.asq_gemm_kernel_name(1536, 11008, 4096) == b"p8+tail" and h.asq_gemm_workspace_bytes(1536, 11008, 4096) == hdr + 4 * 1536 * 256 * 4   # 24 tiles of 128 x 128, 4 K splits
-    assert h.asq_gemm_kernel_name(3072, 11008, 8192) == b"p4+tail"
-    assert h.asq_gemm_kernel_name(1536, 12288, 4096) == b"p8+tail"       # 288 tiles: 6 tile columns (36 tiles' worth) as 128 x 128 tiles
+    assert h.asq_gemm_kernel_name(1536, 11008, 4096) == b"p16+tail" and h.asq_gemm_workspace_bytes(1536, 11008, 4096) == hdr + 4 * 1536 * 256 * 4   # 24 tiles of 128 x 128, 4 K splits
+    assert h.asq_gemm_kernel_name(3072, 11008, 8192) == b"p16+tail"
+    assert h.asq_gemm_kernel_name(1536, 12288, 4096) == b"p16+tail"       # 288 tiles: 6 tile columns (36 tiles' worth) as 128 x 128 tiles
     assert h.asq_gemm_kernel_name(768, 11008, 4096) == b"p8h+tail"       # 258 tiles of 128 rows
-    assert h.asq_gemm_kernel_name(2048, 11008, 4096) == b"p8"            # last wave 88 / 256 full: left alone
-    assert h.asq_gemm_kernel_name(65536, 11008, 4096) == b"p8"           # cfg3: 43 full waves
+    assert h.asq_gemm_kernel_name(2048, 11008, 4096) == b"p16"           # last wave 88 / 256 full: left alone
+    assert h.asq_gemm_kernel_name(65536, 11008, 4096) == b"p16"          # cfg3: 43 full waves
 
 
 def test_dispatcher_on_the_model_shapes():
@@ -85,8 +85,8 @@ def test_dispatcher_on_the_model_shapes():
         (1, "llama"): "skinny", (4, "llama"): "skinny", (32, "llama"): "skinny",
         (1, "opt"): "skinny", (32, "opt"): "skinny", (1, "mixtral"): "skinny", (32, "mixtral"): "skinny",
         # prefill chunks / cfg3: the 256 x 256 tile (4 waves once K >= 8192)
-        (4096, "llama"): {"qkvo": "p8", "gate_up": "p8", "down": "p4", "qkv_fused": "p8"},
-        (65536, "llama"): {"qkvo": "p8", "gate_up": "p8", "down": "p4", "qkv_fused": "p8"},
+        (4096, "llama"): {"qkvo": "p16", "gate_up": "p16", "down": "p16", "qkv_fused": "p16"},
+        (65536, "llama"): {"qkvo": "p16", "gate_up": "p16", "down": "p16", "qkv_fused": "p16"},
     }
     for (rows, fam), cls in want.items():
         for name, (N, K) in {"llama": llama, "opt": opt, "mixtral": mixtral}[fam].items():

@@ -494,10 +494,10 @@ def test_forward_outputs_never_require_grad(dev):
             assert not y.requires_grad and y.grad_fn is None
 
 
-@pytest.mark.parametrize("kern,ksplit", [("p8", 3), ("p8", 1), ("p4", 0), ("p8h", 4), ("p8q", 0), ("p8q", 3), ("skinny", 0), ("generic", 0)])
+@pytest.mark.parametrize("kern,ksplit", [("p16", 0), ("p8", 3), ("p8", 1), ("p4", 0), ("p8h", 4), ("p8q", 0), ("p8q", 3), ("skinny", 0), ("generic", 0)])
 def test_forced_kernel_paths_in_a_child_process(kern, ksplit, dev):
     """Dispatcher branches the shape heuristics never pick by themselves -- notably split-K on the 256-row kernel (pick_kernel hands
-    p8 only >= 144 tiles, pick_ksplit splits only < 118) and the opt-in 4-wave kernel p4 -- forced through ASQ_GEMM_KERNEL / ASQ_KSPLIT (read once per process,
+    p8 only >= 144 tiles, pick_ksplit splits only < 118) the 32 x 32 x 32 kernels p8 / p4 that gemm_i8_p16 replaced as the default, p16 itself on ragged shapes -- forced through ASQ_GEMM_KERNEL / ASQ_KSPLIT (read once per process,
     hence the child) and compared with the oracle's exact GEMM, int32 and fused fp16 epilogue, ragged M and N."""
     import subprocess
     import sys
@@ -508,7 +508,7 @@ import detrng
 from oracle import w8a8 as O
 from autosmoothquant_amd import ops
 dev = torch.device("cuda:0")
-for (M, N, K) in [(300, 520, 1536), (64, 256, 512)]:
+for (M, N, K) in [(300, 520, 1536), (64, 256, 512), (512, 768, 640)]:
     x, w = detrng.int8_uniform(160, M, (M, K)), detrng.int8_uniform(161, N, (N, K))
     xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
     out = torch.empty((M, N), dtype=torch.int32, device=dev)
@@ -520,6 +520,12 @@ for (M, N, K) in [(300, 520, 1536), (64, 256, 512)]:
     y = ops.linear_w8a8(xd, wd, torch.float16, 2e-3, torch.from_numpy(s_row).to(dev), None, torch.from_numpy(bias).to(dev))
     ref = O.dequant_epilogue(acc, np.float32(2e-3), s_row, bias, "f16")
     assert np.array_equal(y.float().cpu().numpy(), ref), ("f16", M, N, K)
+    # scalar-scale epilogue, bf16; per-channel scales + bias, f16 (the interior row epilogues have their own code for each)
+    y = ops.linear_w8a8(xd, wd, torch.bfloat16, 3e-3, None, None, None)
+    assert np.array_equal(y.float().cpu().numpy(), O.dequant_epilogue(acc, np.float32(3e-3), None, None, "bf16")), ("bf16", M, N, K)
+    s_col = (np.abs(detrng.normal(164, N, (N,))) * 1e-3 + 1e-4).astype(np.float32)
+    y = ops.linear_w8a8(xd, wd, torch.float16, 1.0, None, torch.from_numpy(s_col).to(dev), torch.from_numpy(bias).to(dev))
+    assert np.array_equal(y.float().cpu().numpy(), O.dequant_epilogue(acc, s_col, None, bias, "f16")), ("f16 per-channel", M, N, K)
 print("ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
     env = dict(os.environ, ASQ_GEMM_KERNEL=kern)
