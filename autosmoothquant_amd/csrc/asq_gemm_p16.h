@@ -26,6 +26,10 @@
 // 2-byte outputs only.
 #pragma once
 
+#ifndef P16_ORDER
+#define P16_ORDER 1   // issue order inside a quadrant: 0 = the weight fragment stays for 4 instructions, 1 = the activation fragment stays for 2
+#endif
+
 namespace asq {
 
 struct MmaI8x16 {  // one v_mfma_i32_16x16x64_i8: 16 (A rows) x 16 (B rows) x 64 k-bytes, exact
@@ -143,11 +147,27 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
     // 16 MFMAs of one quadrant: k-step outermost, then the W fragment (kept for 4 instructions), then the token tiles
     auto quadrant = [&](v4i (&A)[4][2], const v4i (&wf)[2][2]) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk) {
+#if P16_ORDER == 1
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) A[jt][it] = MmaI8x16::mma(wf[it][kk], xf[jt][kk], A[jt][it]);
+#elif P16_ORDER == 2   // as 1 with the weight fragments snaking (w0, w1 | w1, w0 | ...): exactly one operand changes between consecutive instructions
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int it = (jt & 1) ? 1 - i : i;
+                    A[jt][it] = MmaI8x16::mma(wf[it][kk], xf[jt][kk], A[jt][it]);
+                }
+#else
 #pragma unroll
             for (int it = 0; it < 2; ++it)
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) A[jt][it] = MmaI8x16::mma(wf[it][kk], xf[jt][kk], A[jt][it]);
+#endif
+        }
     };
 
     // one K-tile at LDS stage S (compile-time), prefetching K-tile (t+1) into stage S^1: p8's four phases

@@ -70,6 +70,62 @@ template <int SHAPE, int MODE> static double run(int *out, double seconds)
     return tail_n ? tail_sum / tail_n : best_tail;
 }
 
+// p16's quadrant (2 weight fragments x 4 activation fragments x 2 k-steps = 16 instructions on 8 accumulators) in different issue orders:
+//   0: k-step, weight fragment, activation fragment   (the weight fragment stays for 4 instructions)  -- what gemm_i8_p16 issues
+//   1: k-step, activation fragment, weight fragment   (the activation fragment stays for 2)
+//   2: as 0 with the activation fragments snaking (.., x3 | x3, x2, ..)
+//   3: as 0 with the roles swapped (activations = A operand, weights = B)
+template <int ORDER> __global__ void __launch_bounds__(512) kq(int iters, int *out)
+{
+    v4i wf[2][2], xf[4][2];
+    unsigned s = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 999u;
+    for (int i = 0; i < 2; ++i) for (int kk = 0; kk < 2; ++kk) for (int j = 0; j < 4; ++j) {
+        unsigned v = 0; for (int b = 0; b < 4; ++b) v |= (unsigned)gauss_byte(s, 21.7f) << (8 * b); wf[i][kk][j] = (int)v; }
+    for (int i = 0; i < 4; ++i) for (int kk = 0; kk < 2; ++kk) for (int j = 0; j < 4; ++j) {
+        unsigned v = 0; for (int b = 0; b < 4; ++b) v |= (unsigned)gauss_byte(s, 2.9f) << (8 * b); xf[i][kk][j] = (int)v; }
+    v4i acc[4][2];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = (v4i){0};
+    for (int it_ = 0; it_ < iters; ++it_) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            if (ORDER == 1) {
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) acc[jt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[it][kk], xf[jt][kk], acc[jt][it], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int jt = (ORDER == 2 && it == 1) ? 3 - j : j;
+                        if (ORDER == 3) acc[jt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(xf[jt][kk], wf[it][kk], acc[jt][it], 0, 0, 0);
+                        else acc[jt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[it][kk], xf[jt][kk], acc[jt][it], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    int r = 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 4; ++e) r += acc[i][j][e];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <int ORDER> static double runq(int *out, double seconds)
+{
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int iters = 20000;
+    double total_ms = 0, tail_sum = 0; int tail_n = 0;
+    while (total_ms < seconds * 1e3) {
+        CK(hipEventRecord(e0));
+        for (int l = 0; l < 10; ++l) hipLaunchKernelGGL((kq<ORDER>), dim3(256), dim3(512), 0, 0, iters, out);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        total_ms += ms;
+        const double tops = 2.0 * 16 * 16384.0 * iters * 8 * 256 * 10 / (ms * 1e-3) / 1e12;
+        if (total_ms > seconds * 500) { tail_sum += tops; ++tail_n; }
+    }
+    return tail_sum / (tail_n ? tail_n : 1);
+}
+
 int main(int argc, char **argv)
 {
     const double seconds = argc > 1 ? atof(argv[1]) : 1.0;
@@ -83,5 +139,8 @@ int main(int argc, char **argv)
         for (int m = 0; m < 3; ++m)
             printf("%-38s 32x32x32: %6.0f TOPS   16x16x64: %6.0f TOPS   ratio %.3f\n", modes[m], t[0][m], t[1][m], t[1][m] / t[0][m]);
     }
+    for (int rep = 0; rep < 2; ++rep)
+        printf("16x16x64, p16 quadrant, bench-like operands: order 0 (W stays 4) %6.0f | 1 (X stays 2) %6.0f | 2 (snake) %6.0f | 3 (roles swapped) %6.0f TOPS\n",
+               runq<0>(out, seconds), runq<1>(out, seconds), runq<2>(out, seconds), runq<3>(out, seconds));
     return 0;
 }
