@@ -532,6 +532,31 @@ __device__ __forceinline__ void epilogue_wave(const Epi &epi, Get get, MOff moff
     });
 }
 
+struct MmaI8x16 {  // one v_mfma_i32_16x16x64_i8: 16 (A rows) x 16 (B rows) x 64 k-bytes, exact
+    static __device__ __forceinline__ v4i mma(const v4i &a, const v4i &b, const v4i &c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
+};
+
+// Direct-store epilogue of a 128(m) x 64(n) wave tile in the 16 x 16 layout (edge tiles / unaligned / 4-byte outputs): a store instruction
+// touches 16 rows with 4 x 8 (16) bytes each -- slow, and only used where the row epilogue cannot be.
+template <class Epi, class Get> __device__ __forceinline__ void epilogue_wave16(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, int64_t M, int64_t N)
+{
+    const int t = lane & 15, q = lane >> 4;
+    static_for<4>([&](auto in_) __attribute__((always_inline)) {
+        constexpr int in16 = decltype(in_)::value;
+        const int64_t n = nw0 + in16 * 16 + 4 * q;
+        v4f sc = (v4f){0.f, 0.f, 0.f, 0.f}, bb = (v4f){0.f, 0.f, 0.f, 0.f};
+        if (n < N) epi.cols(n, N, sc, bb);
+        static_for<8>([&](auto im_) __attribute__((always_inline)) {
+            constexpr int im16 = decltype(im_)::value;
+            const int64_t m = mw0 + im16 * 16 + t;
+            if (m < M && n < N) {
+                const float sr = Epi::kHasRow ? epi.row(m) : 1.0f;
+                epi.store4(m, n, get(in16, im16), sr, sc, bb, N);
+            }
+        });
+    });
+}
+
 // Coalescing epilogue of the 256x256 kernel (wave tile 128(m) x 64(n): NTN = 2, NTM = 4).
 // In the matrix-core layout a lane owns ONE token and 4 consecutive channels, so a direct store
 // instruction touches 32 different output rows with 16 B each: measured ~10-12 B/clk per CU, 12.9k
@@ -554,7 +579,44 @@ template <int POL> __device__ __forceinline__ void store16_policy(void *p, const
     else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
 
-template <int NTM, int POL = 0, class Epi, class Get>  // NTM = 32-row token tiles of the wave tile: 4 (256-row block tile) or 2 (128-row)
+// 16 x 16 accumulator layout (v_mfma_i32_16x16x64_i8; gemm_i8_p8<.., L16 = true>): the write side of the staged epilogue.  Lane l owns token (l & 15) and
+// channels 4 * (l >> 4) .. + 3 of every 16 x 16 tile; get(in16, im16) returns its 4 registers.  The images (and so the read / store side) are the ones of the
+// 32 x 32 layout: 2-byte outputs [rows][128 B] with chunk ^= (row >> 1) & 7 and the 8-byte halves flipped on odd rows, 4-byte outputs [64 rows][256 B] with
+// chunk ^= row & 15.  16 consecutive lanes write 16 consecutive rows of one chunk: conflict-free in both.
+template <int NTM, class Epi, class Get>
+__device__ __forceinline__ void staged_write16(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, int64_t M, int64_t N, unsigned stage, int pass)
+{
+    constexpr int EB = Epi::kOutBytes;
+    typedef __attribute__((address_space(3))) v4i *lds_v4i;
+    typedef __attribute__((address_space(3))) v2u *lds_u2;
+    const int t = lane & 15, q = lane >> 4;
+    v4f sc[4], bb[4];
+#pragma unroll
+    for (int in = 0; in < 4; ++in) {
+        const int64_t n = nw0 + in * 16 + 4 * q;
+        sc[in] = (v4f){0.f, 0.f, 0.f, 0.f};
+        bb[in] = (v4f){0.f, 0.f, 0.f, 0.f};
+        if (n < N) epi.cols(n, N, sc[in], bb[in]);
+    }
+    constexpr int NT = EB == 2 ? 2 * NTM : (NTM >= 2 ? 4 : 2);   // 16-token tiles per staging pass: the whole wave tile (2-byte) or 64 rows (4-byte)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int im16 = pass * NT + i, row = 16 * i + t;
+        const int64_t m = mw0 + 16 * im16 + t;
+        float sr = 1.0f;
+        if constexpr (Epi::kHasRow) {
+            if (m < M) sr = epi.row(m);
+        }
+#pragma unroll
+        for (int in = 0; in < 4; ++in) {
+            const auto v = epi.pack(get(in, im16), sr, sc[in], bb[in]);
+            if constexpr (EB == 2) *(lds_u2)(uintptr_t)(stage + row * 128 + (((2 * in + (q >> 1)) ^ ((row >> 1) & 7)) << 4) + 8 * ((q ^ row) & 1)) = v;
+            else *(lds_v4i)(uintptr_t)(stage + row * 256 + (((4 * in + q) ^ (row & 15)) << 4)) = v;
+        }
+    }
+}
+
+template <int NTM, int POL = 0, bool L16 = false, class Epi, class Get>  // NTM = 32-row token tiles of the wave tile: 4 (256-row block tile) or 2 (128-row)
 __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, int64_t M, int64_t N, unsigned stage)
 {
     constexpr int EB = Epi::kOutBytes;
@@ -564,39 +626,45 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
     typedef __attribute__((address_space(3))) v2u *lds_u2;
     const int ml = lane & 31, hi = lane >> 5;
     float sr[NTM];
-#pragma unroll
-    for (int im = 0; im < NTM; ++im) {
-        const int64_t m = mw0 + im * 32 + ml;
-        sr[im] = 1.0f;
-        if constexpr (Epi::kHasRow) {
-            if (m < M) sr[im] = epi.row(m);
-        }
-    }
     v4f sc[2][4], bb[2][4];
+    if constexpr (!L16) {
 #pragma unroll
-    for (int in = 0; in < 2; ++in)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int64_t n = nw0 + in * 32 + 8 * g + 4 * hi;
-            sc[in][g] = (v4f){0.f, 0.f, 0.f, 0.f};
-            bb[in][g] = (v4f){0.f, 0.f, 0.f, 0.f};
-            if (n < N) epi.cols(n, N, sc[in][g], bb[in][g]);
+        for (int im = 0; im < NTM; ++im) {
+            const int64_t m = mw0 + im * 32 + ml;
+            sr[im] = 1.0f;
+            if constexpr (Epi::kHasRow) {
+                if (m < M) sr[im] = epi.row(m);
+            }
         }
+#pragma unroll
+        for (int in = 0; in < 2; ++in)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t n = nw0 + in * 32 + 8 * g + 4 * hi;
+                sc[in][g] = (v4f){0.f, 0.f, 0.f, 0.f};
+                bb[in][g] = (v4f){0.f, 0.f, 0.f, 0.f};
+                if (n < N) epi.cols(n, N, sc[in][g], bb[in][g]);
+            }
+    }
     char *const outb = (char *)epi.out;
     using acc4_t = typename Epi::Mma::acc4_t;
     if constexpr (EB == 2) {
+        if constexpr (L16) {
+            staged_write16<NTM>(epi, get, mw0, nw0, lane, M, N, stage, 0);
+        } else {
 #pragma unroll
-        for (int im = 0; im < NTM; ++im) {
-            const int row = 32 * im + ml;
+            for (int im = 0; im < NTM; ++im) {
+                const int row = 32 * im + ml;
 #pragma unroll
-            for (int in = 0; in < 2; ++in) {
-                const typename Epi::Mma::acc_t a = get(in, im);
+                for (int in = 0; in < 2; ++in) {
+                    const auto a = get(in, im);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const v2u v = epi.pack((acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g]);
-                    // ds_write_b64 is served in groups of 16 consecutive lanes over 32 banks: rows 2j and 2j+1 share a chunk
-                    // position, so odd rows take the other 8-byte half (without it: 2-way conflict, SQ_LDS_BANK_CONFLICT)
-                    *(lds_u2)(uintptr_t)(stage + row * 128 + (((in * 4 + g) ^ ((row >> 1) & 7)) << 4) + 8 * (hi ^ (row & 1))) = v;
+                    for (int g = 0; g < 4; ++g) {
+                        const v2u v = epi.pack((acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g]);
+                        // ds_write_b64 is served in groups of 16 consecutive lanes over 32 banks: rows 2j and 2j+1 share a chunk
+                        // position, so odd rows take the other 8-byte half (without it: 2-way conflict, SQ_LDS_BANK_CONFLICT)
+                        *(lds_u2)(uintptr_t)(stage + row * 128 + (((in * 4 + g) ^ ((row >> 1) & 7)) << 4) + 8 * (hi ^ (row & 1))) = v;
+                    }
                 }
             }
         }
@@ -614,16 +682,20 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
         constexpr int TP = NTM >= 2 ? 2 : 1;  // 32-row tiles per staging pass (4-byte outputs: 64 rows fill the wave's 16 KiB)
 #pragma unroll
         for (int h = 0; h < NTM / TP; ++h) {
+            if constexpr (L16) {
+                staged_write16<NTM>(epi, get, mw0, nw0, lane, M, N, stage, h);
+            } else {
 #pragma unroll
-            for (int imh = 0; imh < TP; ++imh) {
-                const int im = TP * h + imh, row = 32 * imh + ml;
+                for (int imh = 0; imh < TP; ++imh) {
+                    const int im = TP * h + imh, row = 32 * imh + ml;
 #pragma unroll
-                for (int in = 0; in < 2; ++in) {
-                    const typename Epi::Mma::acc_t a = get(in, im);
+                    for (int in = 0; in < 2; ++in) {
+                        const auto a = get(in, im);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const v4i v = epi.pack((acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g]);
-                        *(lds_v4i)(uintptr_t)(stage + row * 256 + (((in * 8 + 2 * g + hi) ^ (row & 15)) << 4)) = v;
+                        for (int g = 0; g < 4; ++g) {
+                            const v4i v = epi.pack((acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g]);
+                            *(lds_v4i)(uintptr_t)(stage + row * 256 + (((in * 8 + 2 * g + hi) ^ (row & 15)) << 4)) = v;
+                        }
                     }
                 }
             }
@@ -1190,7 +1262,12 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
                 if (ws_hdr != nullptr && ws_bytes >= P8_GROUPED_WS_BYTES && grouped_tail_split_enabled()) gws = (char *)ws_hdr;
         }
         ASQ_REQUIRE(tiles < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
+        // int8 groups run on v_mfma_i32_16x16x64_i8 (the L16 form of the kernel: asq_gemm_p16.h for why); ASQ_GROUPED_MMA=32 keeps the 32 x 32 x 32 form (A/B)
+        static const bool mma32 = [] { const char *e = getenv("ASQ_GROUPED_MMA"); return e && atoi(e) == 32; }();
         auto kfn = gemm_i8_p8<Epi, 0, true>;
+        if constexpr (Epi::Mma::kIsInt) {
+            if (!mma32) kfn = gemm_i8_p8<Epi, 0, true, true>;
+        }
         hipError_t e = ensure_dynamic_lds((const void *)kfn, P8_LDS_BYTES);
         if (e != hipSuccess) {
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));

@@ -32,31 +32,6 @@
 
 namespace asq {
 
-struct MmaI8x16 {  // one v_mfma_i32_16x16x64_i8: 16 (A rows) x 16 (B rows) x 64 k-bytes, exact
-    static __device__ __forceinline__ v4i mma(const v4i &a, const v4i &b, const v4i &c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
-};
-
-// Direct-store epilogue of a 128(m) x 64(n) wave tile in the 16 x 16 layout (edge tiles / unaligned / 4-byte outputs): a store instruction
-// touches 16 rows with 4 x 8 (16) bytes each -- slow, and only used where the row epilogue cannot be.
-template <class Epi, class Get> __device__ __forceinline__ void epilogue_wave16(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, int64_t M, int64_t N)
-{
-    const int t = lane & 15, q = lane >> 4;
-    static_for<4>([&](auto in_) __attribute__((always_inline)) {
-        constexpr int in16 = decltype(in_)::value;
-        const int64_t n = nw0 + in16 * 16 + 4 * q;
-        v4f sc = (v4f){0.f, 0.f, 0.f, 0.f}, bb = (v4f){0.f, 0.f, 0.f, 0.f};
-        if (n < N) epi.cols(n, N, sc, bb);
-        static_for<8>([&](auto im_) __attribute__((always_inline)) {
-            constexpr int im16 = decltype(im_)::value;
-            const int64_t m = mw0 + im16 * 16 + t;
-            if (m < M && n < N) {
-                const float sr = Epi::kHasRow ? epi.row(m) : 1.0f;
-                epi.store4(m, n, get(in16, im16), sr, sc, bb, N);
-            }
-        });
-    });
-}
-
 template <class Epi, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
                                                       int tiles_m, int tiles_n, Epi epi_in)

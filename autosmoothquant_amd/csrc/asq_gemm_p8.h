@@ -137,7 +137,9 @@ __device__ __forceinline__ void p8_dma16(const int8_t *sbase, unsigned voff, uns
                  : "memory");
 }
 
-template <class Epi, int ABL = 0, bool GRP = false>   // GRP: the grouped launch (goffs != null); the plain instantiation carries none of its code
+// L16: the matrix work on v_mfma_i32_16x16x64_i8 instead of 32x32x32 (see asq_gemm_p16.h: less energy per MAC, +8-10 % under the socket power limit; int8 only).
+// Same units, DMAs, phases and barriers; a quadrant is 2 k-steps x {4 token tiles x 2 channel tiles} of 16 x 16, the accumulators are acc16[m-half][n-half][4][2].
+template <class Epi, int ABL = 0, bool GRP = false, bool L16 = false>   // GRP: the grouped launch (goffs != null); the plain instantiation carries none of its code
 __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N,
                                                      int64_t K, int tiles_m, int tiles_n, int ksplit, const int *__restrict__ goffs, int ngroups,
                                                      char *gws, Epi epi_in)
@@ -308,9 +310,35 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
             asm volatile("" : "+v"(xb[s][ks]), "+v"(wbp[s][ks]));
         }
 
+    unsigned xb16[2][2], wbp16[2][2];   // L16: one VGPR per (stage, operand, k-step of 64); + 2048 * tile (16 rows) + the unit as immediates
+    if constexpr (L16) {
+        const int t16 = lane & 15, q16 = lane >> 4, sw16 = (t16 >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const unsigned off = lds0 + t16 * 128 + ((((kk * 4 + q16) ^ sw16)) << 4) + s * P8_STAGE;
+                xb16[s][kk] = off + wm * 64 * 128;
+                wbp16[s][kk] = off + wn * 32 * 128;
+                asm volatile("" : "+v"(xb16[s][kk]), "+v"(wbp16[s][kk]));
+            }
+    }
+
     using MMA = typename Epi::Mma;
     using acc_t = typename MMA::acc_t;
+    static_assert(!L16 || MMA::kIsInt, "the 16 x 16 x 64 form is the int8 instruction");
     acc_t acc[2][2][2];  // [m-half][n-half][j]
+    v4i acc16[2][2][4][2];  // L16: [m-half][n-half][token tile][channel tile]
+    if constexpr (L16) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) acc16[a][b][c][d] = (v4i){0, 0, 0, 0};
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -337,6 +365,17 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
     P8_BLK(1);
 
     v4i xf[2][4], wa[4], wb[4];
+    v4i xf16[4][2], wa16[2][2], wb16[2][2];   // L16: [tile][k-step]
+    // L16: the 16 matrix instructions of a quadrant; the activation fragment stays for two instructions, the weight fragments alternate (asq_gemm_p16.h)
+    auto quadrant16 = [&](v4i (&A)[4][2], const v4i (&wf)[2][2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) A[jt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[it][kk], xf16[jt][kk], A[jt][it], 0, 0, 0);
+    };
+    auto ld16 = [&](unsigned a) { return *(p8_lds_v4i)(uintptr_t)a; };
 #ifdef ASQ_P8_PROBE
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tacc[4][7] = {};
     (void)st;
@@ -353,12 +392,23 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
         P8_STAMP(0);
         issue(0, NS, kn);
         P8_STAMP(1);
+        if constexpr (L16) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) wa16[it][kk] = ld16(wbp16[S][kk] + 1 * P8_UNIT + it * 2048);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) xf16[jt][kk] = ld16(xb16[S][kk] + 0 * P8_UNIT + jt * 2048);
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wa[ks] = p8_ldfrag<ABL>(wbp[S][ks] + 1 * P8_UNIT, lane);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) xf[j][ks] = p8_ldfrag<ABL>(xb[S][ks] + 0 * P8_UNIT + j * 4096, lane);
+        }
         P8_STAMP(2);
         P8_WAIT_VM(4);
         P8_STAMP(3);
@@ -368,7 +418,9 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(5);
         P8_PRIO(1);
-if constexpr (MMA::kIsInt) {
+if constexpr (L16) {
+            quadrant16(acc16[0][0], wa16);
+        } else if constexpr (MMA::kIsInt) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -390,8 +442,15 @@ if constexpr (MMA::kIsInt) {
         P8_STAMP(0);
         issue(1, NS, kn);
         P8_STAMP(1);
+        if constexpr (L16) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) wb16[it][kk] = ld16(wbp16[S][kk] + 2 * P8_UNIT + it * 2048);
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wb[ks] = p8_ldfrag<ABL>(wbp[S][ks] + 2 * P8_UNIT, lane);
+        }
         P8_STAMP(2);
         P8_WAIT_VM(4);
         P8_STAMP(3);
@@ -401,7 +460,9 @@ if constexpr (MMA::kIsInt) {
         __builtin_amdgcn_sched_barrier(0);
         P8_STAMP(5);
         P8_PRIO(1);
-if constexpr (MMA::kIsInt) {
+if constexpr (L16) {
+            quadrant16(acc16[0][1], wb16);
+        } else if constexpr (MMA::kIsInt) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -424,10 +485,17 @@ if constexpr (MMA::kIsInt) {
         issue(2, NS, kn);
         P8_STAMP(1);
         if (!half) {
+            if constexpr (L16) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) xf16[jt][kk] = ld16(xb16[S][kk] + 3 * P8_UNIT + jt * 2048);
+            } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) xf[j][ks] = p8_ldfrag<ABL>(xb[S][ks] + 3 * P8_UNIT + j * 4096, lane);
+            }
         }
         P8_STAMP(2);
         P8_STAMP(3);
@@ -438,7 +506,9 @@ if constexpr (MMA::kIsInt) {
         P8_STAMP(5);
         P8_PRIO(1);
         if (!half) {  // (a half tile has no second row half: phases P3 / P4 only keep the DMA / barrier cadence)
-if constexpr (MMA::kIsInt) {
+if constexpr (L16) {
+            quadrant16(acc16[1][1], wb16);
+        } else if constexpr (MMA::kIsInt) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -470,7 +540,9 @@ if constexpr (MMA::kIsInt) {
         P8_STAMP(5);
         P8_PRIO(1);
         if (!half) {
-if constexpr (MMA::kIsInt) {
+if constexpr (L16) {
+            quadrant16(acc16[1][0], wa16);
+        } else if constexpr (MMA::kIsInt) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -518,10 +590,15 @@ if constexpr (MMA::kIsInt) {
         const int my = (tpart0 + tsplit * ttail) * PART + tid * 16;
         // (offset in the VGPR, soffset 0 and a wait state after the stores: see the note on buffer stores in asq_gemm_wstream.h)
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const acc_t &A = acc[i >> 4][(i >> 3) & 1][(i >> 2) & 1];
-            const int j = (i & 3) * 4;
-            const v4e_ v = {A[j], A[j + 1], A[j + 2], A[j + 3]};
+        for (int i = 0; i < 32; ++i) {   // (the image is the accumulator registers in their own order: the layout does not matter)
+            v4e_ v;
+            if constexpr (L16) {
+                v = __builtin_bit_cast(v4e_, acc16[i >> 4][(i >> 3) & 1][(i >> 1) & 3][i & 1]);
+            } else {
+                const acc_t &A = acc[i >> 4][(i >> 3) & 1][(i >> 2) & 1];
+                const int j = (i & 3) * 4;
+                v = (v4e_){A[j], A[j + 1], A[j + 2], A[j + 3]};
+            }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, v), rsrc, my + i * 8192, 0, 16 /* sc1: write-through */);
         }
         asm volatile("s_nop 1\n\ts_waitcnt vmcnt(0)" ::: "memory");
@@ -549,18 +626,45 @@ if constexpr (MMA::kIsInt) {
 #pragma unroll
                 for (int u = 0; u < P8_FIX_BATCH; ++u) {
                     const int i = i0 + u;
-                    acc_t &A = acc[i >> 4][(i >> 3) & 1][(i >> 2) & 1];
-                    const int j = (i & 3) * 4;
                     const v4e_ a = __builtin_bit_cast(v4e_, v[u]);
-                    A[j] += a[0];
-                    A[j + 1] += a[1];
-                    A[j + 2] += a[2];
-                    A[j + 3] += a[3];
+                    if constexpr (L16) {
+                        v4i &A = acc16[i >> 4][(i >> 3) & 1][(i >> 1) & 3][i & 1];
+                        A += __builtin_bit_cast(v4i, a);
+                    } else {
+                        acc_t &A = acc[i >> 4][(i >> 3) & 1][(i >> 2) & 1];
+                        const int j = (i & 3) * 4;
+                        A[j] += a[0];
+                        A[j + 1] += a[1];
+                        A[j + 2] += a[2];
+                        A[j + 3] += a[3];
+                    }
                 }
             }
         }
     }
 
+    if constexpr (L16) {
+        // accumulator tile (in16 = 16-channel tile 0..3, im16 = 16-token tile 0..7) -> rows mw0 + 16*im16, cols n0 + wn*64 + 16*in16
+        auto get16 = [&](int in16, int im16) -> const v4i & { return acc16[im16 >> 2][in16 >> 1][im16 & 3][in16 & 1]; };
+        bool staged16 = false;
+        if constexpr (Epi::kOutBytes >= 2) staged16 = ((((uintptr_t)epi.out) & 15) == 0) && (((N | epi.N) * Epi::kOutBytes) % 16 == 0);
+        const int64_t mw0 = m0 + (half ? wm * 64 : wm * 128), nw0 = n0 + wn * 64;   // (half tile: see below)
+        const int64_t Mw = half && mw0 + 64 < M ? mw0 + 64 : M;
+        if (staged16) {
+            if constexpr (Epi::kOutBytes >= 2) {
+                P8_BAR();
+                bool rows_path = false;
+                if constexpr (Epi::kOutBytes == 2) rows_path = !half && mw0 + 128 <= M && nw0 + 64 <= N && epi.N < (int64_t(1) << 27);
+                if (rows_path) {
+                    if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<4, 2, true>(epi, get16, mw0, nw0, lane, lds0 + wave * 16384);
+                } else
+                    epilogue_wave_staged<4, 0, true>(epi, get16, mw0, nw0, lane, Mw, N, lds0 + wave * 16384);
+            }
+        } else {
+            epilogue_wave16(epi, get16, mw0, nw0, lane, Mw, N);
+        }
+        return;
+    }
     // accumulator tile (in = n-half, im = 2*m-half + j) -> rows m0 + wm*128 + 32*im, cols n0 + wn*64 + 32*in
     auto get = [&](int in, int im) -> const acc_t & { return acc[im >> 1][in][im & 1]; };
     bool staged = false;

@@ -353,13 +353,20 @@ def measure_dominant_kernel(mod, x, iters=10, batch=20, warm=200):
 def pmc_traffic(kernel_key, M, N, K):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r*_pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc
-    runs).  bench.py cannot read PMCs itself; null when no committed measurement matches."""
-    import glob
+    runs).  bench.py cannot read PMCs itself; null when no committed measurement matches -- the kernel, the shape AND the
+    sha256 of libasq_hip.so the counters were collected with (tools/summarise_profiles.py records it; the build is byte-reproducible)."""
+    import glob, hashlib
     best = None
+    try:
+        lib_sha = hashlib.sha256(open(os.path.join(ROOT, "autosmoothquant_amd", "libasq_hip.so"), "rb").read()).hexdigest()
+    except OSError:
+        return None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
         try:
             d = json.load(open(path))
         except Exception:
+            continue
+        if d.get("library_sha256") != lib_sha:   # counters of another build of the library say nothing about this one: null rather than stale
             continue
         for name, e in d.get("kernels", {}).items():
             if kernel_key in name and e.get("shape", [4096, 4096, 4096]) == [M, N, K]:

@@ -40,7 +40,9 @@ def pmc_means(counter):
 
 fetch, write = pmc_means("FETCH_SIZE"), pmc_means("WRITE_SIZE")
 bench = last_json_line(os.path.join(src, "bench.json"))
+import hashlib
 out = {
+    "library_sha256": hashlib.sha256(open(os.path.join(root, "autosmoothquant_amd", "libasq_hip.so"), "rb").read()).hexdigest(),   # bench.py reports these bytes only for THIS build of the library
     "command": "rocprofv3 --kernel-trace --pmc <C> --output-format csv -- python bench.py --no-cpu-baseline --no-cfg3 --steps 5 --warmup 2  (one pass per counter, C in {FETCH_SIZE, WRITE_SIZE})",
     "units": "rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KiB per dispatch",
     "gfx950_correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md 'HBM'); check: quant_flat_vec reads exactly M*K*2 B and writes M*K B",
@@ -57,7 +59,7 @@ for key in sorted(fetch, key=lambda k: -fetch[k][0]):
     e = {"grid_size": grid, "dispatches_sampled": n, "FETCH_SIZE_KiB_raw": round(f_kib, 1), "WRITE_SIZE_KiB_raw": round(w_kib, 1),
          "fetch_bytes_corrected": int(f_kib * 1024 * 2), "write_bytes": int(w_kib * 1024)}
     e["traffic_bytes_per_launch"] = e["fetch_bytes_corrected"] + e["write_bytes"]
-    if "gemm_i8_p8<" in short and grid == 256 * 512:  # 256 tiles of 256x256: the M=N=K=4096 launches of the default workload
+    if ("gemm_i8_p8<" in short or "gemm_i8_p16<" in short) and grid == 256 * 512:  # 256 tiles of 256x256: the M=N=K=4096 launches of the default workload
         e["shape"] = [4096, 4096, 4096]
         e["algorithmic_bytes_per_launch"] = 4096 * 4096 * (1 + 1 + 2)
         e["traffic_over_algorithmic"] = round(e["traffic_bytes_per_launch"] / e["algorithmic_bytes_per_launch"], 2)
@@ -79,7 +81,7 @@ for counter in ("MfmaUtil", "SQ_INSTS_VALU_MFMA_I8", "SQ_LDS_BANK_CONFLICT", "SQ
 if extra:
     json.dump({"command": "rocprofv3 --kernel-trace --pmc <C> -- python bench.py --no-cpu-baseline --no-cfg3 --steps 5 --warmup 2 (one pass per counter)",
                "notes": "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * SIMD_NUM) in percent (rocprofv3 derived metric); "
-                        "SQ_INSTS_VALU_MFMA_I8: 4096^3 with 32x32x32 tiles needs 2*4096^3 / (2*32*32*32) = 2097152 wave-level MFMAs",
+                        "SQ_INSTS_VALU_MFMA_I8: 4096^3 needs 2*4096^3 / (2*16*16*64) = 4194304 wave-level v_mfma_i32_16x16x64_i8 (gemm_i8_p16; 2097152 of the 32x32x32 form for gemm_i8_p8)",
                "kernels": extra}, open(os.path.join(dst, f"{tag}_pmc_mfma_lds.json"), "w"), indent=1)
     print(json.dumps(extra, indent=1)[:2500])
 # cfg3 (32-layer LLaMA-2-7B decoder forward, 65536 tokens): per-kernel share of the GPU time, reference composition and N1-fused
