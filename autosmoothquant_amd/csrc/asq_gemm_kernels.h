@@ -536,9 +536,9 @@ struct MmaI8x16 {  // one v_mfma_i32_16x16x64_i8: 16 (A rows) x 16 (B rows) x 64
     static __device__ __forceinline__ v4i mma(const v4i &a, const v4i &b, const v4i &c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
 };
 
-// Direct-store epilogue of a 128(m) x 64(n) wave tile in the 16 x 16 layout (edge tiles / unaligned / 4-byte outputs): a store instruction
+// Direct-store epilogue of a (16 * NT16)(m) x 64(n) wave tile in the 16 x 16 layout (edge tiles / unaligned / 4-byte outputs): a store instruction
 // touches 16 rows with 4 x 8 (16) bytes each -- slow, and only used where the row epilogue cannot be.
-template <class Epi, class Get> __device__ __forceinline__ void epilogue_wave16(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, int64_t M, int64_t N)
+template <int NT16 = 8, class Epi, class Get> __device__ __forceinline__ void epilogue_wave16(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, int64_t M, int64_t N)
 {
     const int t = lane & 15, q = lane >> 4;
     static_for<4>([&](auto in_) __attribute__((always_inline)) {
@@ -546,7 +546,7 @@ template <class Epi, class Get> __device__ __forceinline__ void epilogue_wave16(
         const int64_t n = nw0 + in16 * 16 + 4 * q;
         v4f sc = (v4f){0.f, 0.f, 0.f, 0.f}, bb = (v4f){0.f, 0.f, 0.f, 0.f};
         if (n < N) epi.cols(n, N, sc, bb);
-        static_for<8>([&](auto im_) __attribute__((always_inline)) {
+        static_for<NT16>([&](auto im_) __attribute__((always_inline)) {
             constexpr int im16 = decltype(im_)::value;
             const int64_t m = mw0 + im16 * 16 + t;
             if (m < M && n < N) {
@@ -1226,6 +1226,14 @@ static inline TailPeel plan_tail_peel(GemmKernel kern, int64_t M, int64_t N, int
     return p;
 }
 
+// ASQ_MMA=32: the tiled int8 kernels other than p16 / p8 / p4 themselves (grouped launches, p8h, p8q) keep v_mfma_i32_32x32x32_i8 instead of the 16 x 16 x 64 form
+// (development / A-B aid; read once)
+static inline bool mma32_forced()
+{
+    static const bool v = [] { const char *e = getenv("ASQ_MMA"); return e && atoi(e) == 32; }();
+    return v;
+}
+
 // ASQ_GROUPED_SPLIT=0: grouped launches never split the K loop of their tail tiles (A/B switch; the default is on when a workspace is passed)
 static inline bool grouped_tail_split_enabled()
 {
@@ -1262,11 +1270,10 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
                 if (ws_hdr != nullptr && ws_bytes >= P8_GROUPED_WS_BYTES && grouped_tail_split_enabled()) gws = (char *)ws_hdr;
         }
         ASQ_REQUIRE(tiles < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
-        // int8 groups run on v_mfma_i32_16x16x64_i8 (the L16 form of the kernel: asq_gemm_p16.h for why); ASQ_GROUPED_MMA=32 keeps the 32 x 32 x 32 form (A/B)
-        static const bool mma32 = [] { const char *e = getenv("ASQ_GROUPED_MMA"); return e && atoi(e) == 32; }();
+        // int8 groups run on v_mfma_i32_16x16x64_i8 (the L16 form of the kernel: asq_gemm_p16.h for why); ASQ_MMA=32 keeps the 32 x 32 x 32 form (A/B)
         auto kfn = gemm_i8_p8<Epi, 0, true>;
         if constexpr (Epi::Mma::kIsInt) {
-            if (!mma32) kfn = gemm_i8_p8<Epi, 0, true, true>;
+            if (!mma32_forced()) kfn = gemm_i8_p8<Epi, 0, true, true>;
         }
         hipError_t e = ensure_dynamic_lds((const void *)kfn, P8_LDS_BYTES);
         if (e != hipSuccess) {
@@ -1349,7 +1356,7 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
         const int ksplit = (kInt && ws != nullptr && (((uintptr_t)ws) & 15) == 0) ? pick_ksplit_p8h(tm * tn, K, M, N, ws_bytes) : 1;
         if constexpr (kInt) if (ksplit > 1) {
             EpiI32 slab{(int32_t *)ws, N, true};
-            auto kfn = gemm_i8_p8h<EpiI32>;
+            auto kfn = mma32_forced() ? gemm_i8_p8h<EpiI32> : gemm_i8_p8h<EpiI32, false, true>;
             hipError_t e = ensure_dynamic_lds((const void *)kfn, P8H_LDS_BYTES);
             if (e != hipSuccess) {
                 asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
@@ -1362,6 +1369,9 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
             return asq_after_launch(s, what);
         }
         auto kfn = gemm_i8_p8h<Epi>;
+        if constexpr (kInt) {
+            if (!mma32_forced()) kfn = gemm_i8_p8h<Epi, false, true>;
+        }
         hipError_t e = ensure_dynamic_lds((const void *)kfn, P8H_LDS_BYTES);
         if (e != hipSuccess) {
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
@@ -1374,7 +1384,7 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
         const int ksplit = (kInt && ws != nullptr && (((uintptr_t)ws) & 15) == 0) ? pick_ksplit_p8q(tm * tn, K, M, N, ws_bytes) : 1;
         if constexpr (kInt) if (ksplit > 1) {
             EpiI32 slab{(int32_t *)ws, N, true};
-            auto kfn = gemm_i8_p8q<EpiI32>;
+            auto kfn = mma32_forced() ? gemm_i8_p8q<EpiI32> : gemm_i8_p8q<EpiI32, false, true>;
             hipError_t e = ensure_dynamic_lds((const void *)kfn, P8Q_LDS_BYTES);
             if (e != hipSuccess) {
                 asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
@@ -1387,6 +1397,9 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
             return asq_after_launch(s, what);
         }
         auto kfn = gemm_i8_p8q<Epi>;
+        if constexpr (kInt) {
+            if (!mma32_forced()) kfn = gemm_i8_p8q<Epi, false, true>;
+        }
         hipError_t e = ensure_dynamic_lds((const void *)kfn, P8Q_LDS_BYTES);
         if (e != hipSuccess) {
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));

@@ -38,7 +38,9 @@ constexpr int P8H_LDS_BYTES = 3 * P8H_STAGE;  // 144 KiB
 #define P8H_BLK(i) do { } while (0)
 #endif
 
-template <class Epi, bool PROBE = false>  // PROBE: per-block s_memtime stamps for tools/ubench/p8_probe (production: false)
+// L16 (int8 only): the matrix work on v_mfma_i32_16x16x64_i8 (asq_gemm_p16.h for why): a phase is 2 k-steps x {4 token tiles x 2 channel tiles} = 16
+// instructions of 16 cycles on acc16[n-half][token tile][channel tile]; fragments 16 rows x 64 k-bytes from the same unit images.
+template <class Epi, bool PROBE = false, bool L16 = false>  // PROBE: per-block s_memtime stamps for tools/ubench/p8_probe (production: false)
 __global__ void __launch_bounds__(512, 2) gemm_i8_p8h(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
                                                       int tiles_m, int tiles_n, int ksplit, Epi epi_in)
 {
@@ -95,8 +97,32 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8h(const int8_t *__restrict__
             asm volatile("" : "+v"(xb[s][ks]), "+v"(wbp[s][ks]));
         }
 
+    unsigned xb16[3][2], wbp16[3][2];   // L16: one VGPR per (stage, operand, k-step of 64)
+    if constexpr (L16) {
+        const int t16 = lane & 15, q16 = lane >> 4, sw16 = (t16 >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const unsigned off = lds0 + t16 * 128 + ((((kk * 4 + q16) ^ sw16)) << 4) + s * P8H_STAGE;
+                xb16[s][kk] = off + wm * 64 * 128;
+                wbp16[s][kk] = off + wn * 32 * 128;
+                asm volatile("" : "+v"(xb16[s][kk]), "+v"(wbp16[s][kk]));
+            }
+    }
+
     using MMA = typename Epi::Mma;
     using acc_t = typename MMA::acc_t;
+    static_assert(!L16 || MMA::kIsInt, "the 16 x 16 x 64 form is the int8 instruction");
+    v4i acc16[2][4][2];  // L16: [n-half][token tile][channel tile]
+    if constexpr (L16) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc16[a][b][c] = (v4i){0, 0, 0, 0};
+    }
     acc_t acc[2][2];  // [n-half][j]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -127,6 +153,15 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8h(const int8_t *__restrict__
     P8H_BLK(1);
 
     v4i xf[2][4], wf[4];
+    v4i xf16[4][2], wf16[2][2];   // L16: [tile][k-step]
+    auto quadrant16 = [&](v4i (&A)[4][2]) {   // the activation fragment stays for two instructions, the weight fragments alternate
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) A[jt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf16[it][kk], xf16[jt][kk], A[jt][it], 0, 0, 0);
+    };
     auto ktile = [&](auto stage_tag, int t) {
         constexpr int S = decltype(stage_tag)::value, NS = (S + 2) % 3;
         int kn = (t + 2) * 128;  // SALU
@@ -134,18 +169,31 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8h(const int8_t *__restrict__
 
         // ---------------- P1: n-half 0
         issue_a(NS, kn);
+        if constexpr (L16) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) wf16[it][kk] = *(p8_lds_v4i)(uintptr_t)(wbp16[S][kk] + 1 * P8_UNIT + it * 2048);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) xf16[jt][kk] = *(p8_lds_v4i)(uintptr_t)(xb16[S][kk] + jt * 2048);
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wf[ks] = *(p8_lds_v4i)(uintptr_t)(wbp[S][ks] + 1 * P8_UNIT);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) xf[j][ks] = *(p8_lds_v4i)(uintptr_t)(xb[S][ks] + j * 4096);
+        }
         P8_WAIT_VM(8);
         __builtin_amdgcn_s_barrier();
         P8_WAIT_LGKM0();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-if constexpr (MMA::kIsInt) {
+if constexpr (L16) {
+            quadrant16(acc16[0]);
+        } else if constexpr (MMA::kIsInt) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -162,14 +210,23 @@ if constexpr (MMA::kIsInt) {
 
         // ---------------- P2: n-half 1
         issue_b(NS, kn);
+        if constexpr (L16) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) wf16[it][kk] = *(p8_lds_v4i)(uintptr_t)(wbp16[S][kk] + 2 * P8_UNIT + it * 2048);
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wf[ks] = *(p8_lds_v4i)(uintptr_t)(wbp[S][ks] + 2 * P8_UNIT);
+        }
         P8_WAIT_VM(8);
         __builtin_amdgcn_s_barrier();
         P8_WAIT_LGKM0();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-if constexpr (MMA::kIsInt) {
+if constexpr (L16) {
+            quadrant16(acc16[1]);
+        } else if constexpr (MMA::kIsInt) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -198,6 +255,27 @@ if constexpr (MMA::kIsInt) {
     P8_WAIT_VM(0);                                // drain the dead prefetches before LDS is released
     if (wm == 0) __builtin_amdgcn_s_barrier();    // balance the stagger barrier
 
+    if constexpr (L16) {
+        // accumulator tile (in16 = 16-channel tile 0..3, im16 = 16-token tile 0..3) -> rows m0 + wm*64 + 16*im16, cols n0 + wn*64 + 16*in16
+        auto get16 = [&](int in16, int im16) -> const v4i & { return acc16[in16 >> 1][im16][in16 & 1]; };
+        bool staged16 = false;
+        if constexpr (Epi::kOutBytes >= 2) staged16 = ((((uintptr_t)epi.out) & 15) == 0) && (((N | epi.N) * Epi::kOutBytes) % 16 == 0);
+        const int64_t mw0 = m0 + wm * 64, nw0 = n0 + wn * 64;
+        if (staged16) {
+            if constexpr (Epi::kOutBytes >= 2) {
+                __builtin_amdgcn_s_barrier();
+                bool rows_path = false;
+                if constexpr (Epi::kOutBytes == 2) rows_path = mw0 + 64 <= M && nw0 + 64 <= N && epi.N < (int64_t(1) << 27);
+                if (rows_path) {
+                    if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<2, 2, true>(epi, get16, mw0, nw0, lane, lds0 + wave * 16384);
+                } else
+                    epilogue_wave_staged<2, 0, true>(epi, get16, mw0, nw0, lane, M, N, lds0 + wave * 16384);
+            }
+        } else {
+            epilogue_wave16<4>(epi, get16, mw0, nw0, lane, M, N);
+        }
+        return;
+    }
     // accumulator tile (in = n-half, im = j) -> rows m0 + wm*64 + 32*im, cols n0 + wn*64 + 32*in
     auto get = [&](int in, int im) -> const acc_t & { return acc[in][im]; };
     bool staged = false;

@@ -28,7 +28,9 @@ constexpr int P8Q_MX_LDS_BYTES = P8Q_LDS_BYTES + 2 * 4096;  // + two buffers of 
 // fetch the next 16 scale bytes of the tile's 128 + 128 rows with one LDS-DMA each; a lane reads the dword of its row and K-tile next to the
 // fragments and hands byte `hi` (k 0..63 of the tile) / byte 2 + `hi` (k 64..127) to v_mfma_scale_f32_32x32x64_f8f6f4 -- the lane (r, h) of that
 // instruction supplies the scale of the h-th 32-k block of row r.
-template <class Epi, bool MX = false>
+// L16 (int8 only): the matrix work on v_mfma_i32_16x16x64_i8 (asq_gemm_p16.h for why): per K-tile 2 k-steps x {2 token tiles x 4 channel tiles}
+// = 16 instructions of 16 cycles on acc16[token tile][channel tile]; fragments 16 rows x 64 k-bytes from the same unit images.
+template <class Epi, bool MX = false, bool L16 = false>
 __global__ void __launch_bounds__(512, 2) gemm_i8_p8q(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
                                                       int tiles_m, int tiles_n, int ksplit, Epi epi_in, const uint8_t *__restrict__ xs,
                                                       const uint8_t *__restrict__ ws)
@@ -81,11 +83,33 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8q(const int8_t *__restrict__
             asm volatile("" : "+v"(xb[s][ks]), "+v"(wbp[s][ks]));
         }
 
+    unsigned xb16[4][2], wbp16[4][2];   // L16: one VGPR per (stage, k-step of 64) and operand
+    if constexpr (L16) {
+        const int t16 = lane & 15, q16 = lane >> 4, sw16 = (t16 >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const unsigned off = lds0 + t16 * 128 + ((((kk * 4 + q16) ^ sw16)) << 4) + s * P8Q_STAGE;
+                xb16[s][kk] = off + wm * 32 * 128;
+                wbp16[s][kk] = off + P8_UNIT + wn * 64 * 128;
+                asm volatile("" : "+v"(xb16[s][kk]), "+v"(wbp16[s][kk]));
+            }
+    }
+
     using MMA = typename Epi::Mma;
     using acc_t = typename MMA::acc_t;
+    static_assert(!L16 || (MMA::kIsInt && !MX), "the 16 x 16 x 64 form is the int8 instruction");
     acc_t acc[2];  // [n-half]
     acc[0] = (acc_t){0};
     acc[1] = (acc_t){0};
+    v4i acc16[2][4];  // L16: [token tile][channel tile]
+    if constexpr (L16) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc16[a][b] = (v4i){0, 0, 0, 0};
+    }
 
     const int nt = kt1 - kt0;  // K-tiles of this block (>= 1)
     const int klast = (nt - 1) * 128;
@@ -127,16 +151,28 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8q(const int8_t *__restrict__
     P8_WAIT_VM(8);
     __builtin_amdgcn_s_barrier();
     v4i xf[2][4], wf[2][2][4];  // [register set = K-tile parity]
+    v4i xf16[2][2][2], wf16[2][4][2];  // L16: [register set][tile][k-step]
     [[maybe_unused]] unsigned sxr[2] = {0, 0}, swr[2][2] = {{0, 0}, {0, 0}};  // MX: the row's 4 scale bytes of the K-tile, shifted so that byte 0 / 2 are this lane's
     typedef const __attribute__((address_space(3))) unsigned *p8q_lds_u32;
     auto read_frags = [&](auto stage_tag, auto set_tag, int tile) {
         constexpr int S = decltype(stage_tag)::value, R = decltype(set_tag)::value;
+        if constexpr (L16) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) xf16[R][jt][kk] = *(p8_lds_v4i)(uintptr_t)(xb16[S][kk] + jt * 2048);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) wf16[R][it][kk] = *(p8_lds_v4i)(uintptr_t)(wbp16[S][kk] + it * 2048);
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) xf[R][ks] = *(p8_lds_v4i)(uintptr_t)(xb[S][ks]);
 #pragma unroll
         for (int in = 0; in < 2; ++in)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) wf[R][in][ks] = *(p8_lds_v4i)(uintptr_t)(wbp[S][ks] + in * 4096);
+        }
         if constexpr (MX) {
             const unsigned off = ((tile >> 2) & 1) * 4096 + S * 4;  // scale buffer of the tile's group, dword of the tile (S = tile % 4)
             sxr[R] = *(p8q_lds_u32)(uintptr_t)(sx_addr + off);
@@ -175,6 +211,13 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8q(const int8_t *__restrict__
                 const v8i B1 = {xf[R][2][0], xf[R][2][1], xf[R][2][2], xf[R][2][3], xf[R][3][0], xf[R][3][1], xf[R][3][2], xf[R][3][3]};
                 acc[in] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A1, B1, acc[in], 0, 0, 2, swv, 2, sx);
             }
+        } else if constexpr (L16) {   // the activation fragment stays, the weight fragments cycle (asq_gemm_p16.h)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) acc16[jt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf16[R][it][kk], xf16[R][jt][kk], acc16[jt][it], 0, 0, 0);
         } else if constexpr (MMA::kIsInt) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
@@ -204,6 +247,27 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8q(const int8_t *__restrict__
     P8_WAIT_VM(0);    // drain the dead prefetches
     P8_WAIT_LGKM0();  // ... and the fragment reads past the last tile, before LDS becomes staging space
 
+    if constexpr (L16) {
+        // accumulator tile (in16 = 16-channel tile 0..3, im16 = 16-token tile 0..1) -> rows m0 + wm*32 + 16*im16, cols n0 + wn*64 + 16*in16
+        auto get16 = [&](int in16, int im16) -> const v4i & { return acc16[im16][in16]; };
+        bool staged16 = false;
+        if constexpr (Epi::kOutBytes >= 2) staged16 = ((((uintptr_t)epi.out) & 15) == 0) && (((N | epi.N) * Epi::kOutBytes) % 16 == 0);
+        const int64_t mw0 = m0 + wm * 32, nw0 = n0 + wn * 64;
+        if (staged16) {
+            if constexpr (Epi::kOutBytes >= 2) {
+                __builtin_amdgcn_s_barrier();
+                bool rows_path = false;
+                if constexpr (Epi::kOutBytes == 2) rows_path = mw0 + 32 <= M && nw0 + 64 <= N && epi.N < (int64_t(1) << 27);
+                if (rows_path) {
+                    if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<1, 2, true>(epi, get16, mw0, nw0, lane, lds0 + wave * 16384);
+                } else
+                    epilogue_wave_staged<1, 0, true>(epi, get16, mw0, nw0, lane, M, N, lds0 + wave * 16384);
+            }
+        } else {
+            epilogue_wave16<2>(epi, get16, mw0, nw0, lane, M, N);
+        }
+        return;
+    }
     // accumulator tile (in = n-half, im = 0) -> rows m0 + wm*32, cols n0 + wn*64 + 32*in
     auto get = [&](int in, int) -> const acc_t & { return acc[in]; };
     bool staged = false;

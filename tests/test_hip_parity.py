@@ -494,8 +494,9 @@ def test_forward_outputs_never_require_grad(dev):
             assert not y.requires_grad and y.grad_fn is None
 
 
-@pytest.mark.parametrize("kern,ksplit", [("p16", 0), ("p8", 3), ("p8", 1), ("p4", 0), ("p8h", 4), ("p8q", 0), ("p8q", 3), ("skinny", 0), ("generic", 0)])
-def test_forced_kernel_paths_in_a_child_process(kern, ksplit, dev):
+@pytest.mark.parametrize("kern,ksplit,mma", [("p16", 0, 16), ("p8", 3, 16), ("p8", 1, 16), ("p4", 0, 16), ("p8h", 4, 16), ("p8h", 0, 16), ("p8q", 0, 16), ("p8q", 3, 16),
+                                             ("p8h", 4, 32), ("p8h", 0, 32), ("p8q", 0, 32), ("p8q", 3, 32), ("skinny", 0, 16), ("generic", 0, 16)])
+def test_forced_kernel_paths_in_a_child_process(kern, ksplit, mma, dev):
     """Dispatcher branches the shape heuristics never pick by themselves -- notably split-K on the 256-row kernel (pick_kernel hands
     p8 only >= 144 tiles, pick_ksplit splits only < 118) the 32 x 32 x 32 kernels p8 / p4 that gemm_i8_p16 replaced as the default, p16 itself on ragged shapes -- forced through ASQ_GEMM_KERNEL / ASQ_KSPLIT (read once per process,
     hence the child) and compared with the oracle's exact GEMM, int32 and fused fp16 epilogue, ragged M and N."""
@@ -529,6 +530,8 @@ for (M, N, K) in [(300, 520, 1536), (64, 256, 512), (512, 768, 640)]:
 print("ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
     env = dict(os.environ, ASQ_GEMM_KERNEL=kern)
+    if mma == 32:   # the 128-row kernels on v_mfma_i32_32x32x32_i8 (their form before the 16 x 16 x 64 one became the default; still what fp8 runs on)
+        env["ASQ_MMA"] = "32"
     if ksplit:
         env["ASQ_KSPLIT"] = str(ksplit)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)

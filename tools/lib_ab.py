@@ -19,6 +19,8 @@ ap.add_argument("--per-token", action="store_true")
 ap.add_argument("--bias", action="store_true")
 ap.add_argument("--a-kernel", default=None, help="ASQ_GEMM_KERNEL seen by library A (the library reads it once, at its first launch)")
 ap.add_argument("--b-kernel", default=None)
+ap.add_argument("--a-env", default="", help="KEY=VAL[,KEY=VAL] set while library A makes its first launches (the libraries read their switches once)")
+ap.add_argument("--b-env", default="")
 args = ap.parse_args()
 
 vp, i64, f32, sz, cint = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t, ctypes.c_int
@@ -39,6 +41,7 @@ if os.path.abspath(args.a) == os.path.abspath(args.b):   # the same build twice 
     args.b = twin
 libs = {"A": load(args.a), "B": load(args.b)}
 forced = {"A": args.a_kernel, "B": args.b_kernel}
+extra_env = {"A": dict(kv.split("=", 1) for kv in args.a_env.split(",") if kv), "B": dict(kv.split("=", 1) for kv in args.b_env.split(",") if kv)}
 dev = torch.device("cuda:0")
 tdt = {"f16": torch.float16, "bf16": torch.bfloat16}[args.dtype]
 DT = {"f16": 1, "bf16": 2}[args.dtype]
@@ -67,6 +70,9 @@ for sh in args.shapes.split(","):
             os.environ["ASQ_GEMM_KERNEL"] = forced[k]
         else:
             os.environ.pop("ASQ_GEMM_KERNEL", None)
+        for key in set(extra_env["A"]) | set(extra_env["B"]):
+            os.environ.pop(key, None)
+        os.environ.update(extra_env[k])
         call(k)
     torch.cuda.synchronize()
     same = torch.equal(outs["A"].view(torch.int16), outs["B"].view(torch.int16))
