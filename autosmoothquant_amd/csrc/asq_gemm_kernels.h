@@ -1311,7 +1311,11 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
         return asq_after_launch(s, what);
     }
     // the 256 x 256 kernel on v_mfma_i32_16x16x64_i8 (asq_gemm_p16.h): plain launches with 2-byte outputs
-    if (kern == KERN_P16 && !kP4) kern = KERN_P8;
+    bool p8_l16 = false;   // what p16 does not carry runs on p8 -- in its L16 mode (the same 16 x 16 x 64 instruction) unless p8 itself was asked for
+    if (kern == KERN_P16 && !kP4) {
+        kern = KERN_P8;
+        p8_l16 = kInt && !mma32_forced();
+    }
     if constexpr (kP4) if (kern == KERN_P16) {
         const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
         ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
@@ -1331,7 +1335,7 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
         if constexpr (kInt) if (ksplit > 1) {
             // pass 1: int32 partial slabs; pass 2: reduce + the caller's epilogue
             EpiI32 slab{(int32_t *)ws, N, true};
-            auto kfn = gemm_i8_p8<EpiI32>;
+            auto kfn = p8_l16 ? gemm_i8_p8<EpiI32, 0, false, true> : gemm_i8_p8<EpiI32>;
             hipError_t e = ensure_dynamic_lds((const void *)kfn, P8_LDS_BYTES);
             if (e != hipSuccess) {
                 asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
@@ -1344,6 +1348,9 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
             return asq_after_launch(s, what);
         }
         auto kfn = gemm_i8_p8<Epi>;
+        if constexpr (kInt && !kP4) {   // (2-byte outputs have gemm_i8_p16 for this)
+            if (p8_l16) kfn = gemm_i8_p8<Epi, 0, false, true>;
+        }
         hipError_t e = ensure_dynamic_lds((const void *)kfn, P8_LDS_BYTES);
         if (e != hipSuccess) {
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));

@@ -494,6 +494,29 @@ def test_forward_outputs_never_require_grad(dev):
             assert not y.requires_grad and y.grad_fn is None
 
 
+def test_large_shapes_with_4_byte_and_ragged_outputs(dev):
+    """>= 144 tiles of 256 x 256 with outputs gemm_i8_p16 does not carry (fp32, int32) go to p8's 16 x 16 x 64 mode, ragged edges to the bounded staged /
+    direct epilogues of that layout: int32 == torch._int_mm (an independent exact GEMM), fp32 / fp16 == the same fp32 operation sequence in torch."""
+    from autosmoothquant_amd import ops
+    for (M, N, K) in [(3072, 3072, 512), (3000, 3100, 384), (2900, 3330, 256)]:
+        xq = torch.from_numpy(detrng.int8_uniform(210, M, (M, K))).to(dev)
+        w = torch.from_numpy(detrng.int8_uniform(211, N, (N, K))).to(dev)
+        Mp, Np = (M + 7) // 8 * 8, (N + 7) // 8 * 8    # (_int_mm wants multiples of 8)
+        xp = torch.zeros((Mp, K), dtype=torch.int8, device=dev); xp[:M] = xq
+        wp = torch.zeros((Np, K), dtype=torch.int8, device=dev); wp[:N] = w
+        acc = torch._int_mm(xp, wp.t())[:M, :N].contiguous()
+        out = torch.empty((M, N), dtype=torch.int32, device=dev)
+        ops.gemm_i8_i32(xq, w, out)
+        assert torch.equal(out, acc), ("i32", M, N, K)
+        s_row = torch.from_numpy((np.abs(detrng.normal(212, M, (M,))) * 0.01 + 1e-3).astype(np.float32)).to(dev)
+        bias = torch.from_numpy(detrng.normal(213, N, (N,)).astype(np.float32)).to(dev)
+        ds = (torch.tensor(2e-3, dtype=torch.float32, device=dev) * s_row)[:, None]
+        ref = ds * acc.float() + bias[None, :]
+        assert torch.equal(ops.linear_w8a8(xq, w, torch.float32, 2e-3, s_row, None, bias), ref), ("f32", M, N, K)
+        assert torch.equal(ops.linear_w8a8(xq, w, torch.float16, 2e-3, s_row, None, bias), ref.half()), ("f16", M, N, K)
+        assert torch.equal(ops.linear_w8a8(xq, w, torch.bfloat16, 2e-3, None, None, None), (torch.tensor(2e-3, dtype=torch.float32, device=dev) * acc.float()).bfloat16()), ("bf16", M, N, K)
+
+
 @pytest.mark.parametrize("kern,ksplit,mma", [("p16", 0, 16), ("p8", 3, 16), ("p8", 1, 16), ("p4", 0, 16), ("p8h", 4, 16), ("p8h", 0, 16), ("p8q", 0, 16), ("p8q", 3, 16),
                                              ("p8h", 4, 32), ("p8h", 0, 32), ("p8q", 0, 32), ("p8q", 3, 32), ("skinny", 0, 16), ("generic", 0, 16)])
 def test_forced_kernel_paths_in_a_child_process(kern, ksplit, mma, dev):
