@@ -16,6 +16,7 @@ int forced_kernel()
             else if (!strcmp(e, "p8h")) v = KERN_P8H;
             else if (!strcmp(e, "p4")) v = KERN_P4;
             else if (!strcmp(e, "p16")) v = KERN_P16;
+            else if (!strcmp(e, "p4x16")) v = KERN_P4X16;
             else if (!strcmp(e, "p8q")) v = KERN_P8Q;
             else if (!strcmp(e, "skinny")) v = KERN_SKINNY;
         }
@@ -46,6 +47,7 @@ extern "C" const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K)
     case KERN_P8H: return "p8h";
     case KERN_P4: return "p4";
     case KERN_P16: return "p16";
+    case KERN_P4X16: return "p4x16";
     case KERN_P8Q: return "p8q";
     case KERN_SKINNY: return "skinny";
     default: return "generic";

@@ -536,12 +536,12 @@ struct MmaI8x16 {  // one v_mfma_i32_16x16x64_i8: 16 (A rows) x 16 (B rows) x 64
     static __device__ __forceinline__ v4i mma(const v4i &a, const v4i &b, const v4i &c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
 };
 
-// Direct-store epilogue of a (16 * NT16)(m) x 64(n) wave tile in the 16 x 16 layout (edge tiles / unaligned / 4-byte outputs): a store instruction
+// Direct-store epilogue of a (16 * NT16)(m) x (16 * NC16)(n) wave tile in the 16 x 16 layout (edge tiles / unaligned / 4-byte outputs): a store instruction
 // touches 16 rows with 4 x 8 (16) bytes each -- slow, and only used where the row epilogue cannot be.
-template <int NT16 = 8, class Epi, class Get> __device__ __forceinline__ void epilogue_wave16(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, int64_t M, int64_t N)
+template <int NT16 = 8, int NC16 = 4, class Epi, class Get> __device__ __forceinline__ void epilogue_wave16(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, int64_t M, int64_t N)
 {
     const int t = lane & 15, q = lane >> 4;
-    static_for<4>([&](auto in_) __attribute__((always_inline)) {
+    static_for<NC16>([&](auto in_) __attribute__((always_inline)) {
         constexpr int in16 = decltype(in_)::value;
         const int64_t n = nw0 + in16 * 16 + 4 * q;
         v4f sc = (v4f){0.f, 0.f, 0.f, 0.f}, bb = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -741,7 +741,6 @@ __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int6
 {
     static_assert(Epi::kOutBytes == 2, "2-byte outputs");
     static_assert(NTN == 2 || NTN == 4, "wave tile of 64 or 128 channels");
-    static_assert(!L16 || NTN == 2, "16 x 16 layout: 64-channel wave tiles");
     typedef __attribute__((address_space(3))) v2u *lds_u2;
     constexpr int ROWB = NTN * 64;     // bytes per image row
     constexpr int IMG = 32 * ROWB;     // one token tile: 4 / 8 KiB
@@ -771,11 +770,13 @@ __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int6
     unsigned wa[CH];
     {
         unsigned w0;
-        if constexpr (L16) w0 = ml * ROWB + ((((hi >> 1) ^ (ml >> 1)) & 7) << 4) + 8 * ((hi ^ ml) & 1);
+        if constexpr (L16 && NTN == 2) w0 = ml * ROWB + ((((hi >> 1) ^ (ml >> 1)) & 7) << 4) + 8 * ((hi ^ ml) & 1);
+        else if constexpr (L16) w0 = ml * ROWB + (((hi >> 1) ^ ml) << 4) + 8 * ((hi & 1) ^ (ml >> 3));   // 256-B rows: position = chunk ^ row, halves flipped for positions >= 8
         else if constexpr (NTN == 2) w0 = ml * ROWB + (((ml >> 1) & 7) << 4) + 8 * (hi ^ (ml & 1));
         else w0 = ml * ROWB + ((ml & 15) << 4) + 8 * (hi ^ ((ml >> 3) & 1));
 #pragma unroll
-        for (int c = 0; c < CH; ++c) wa[c] = stage + (w0 ^ (unsigned)(L16 ? (c << 5) : ((c << 4) | (NTN == 4 ? (c >> 3) << 3 : 0))));   // (L16: c = in16, only 2 * NTN of them used)
+        for (int c = 0; c < CH; ++c)   // (L16: c = in16, chunk 2 * in16 + (q >> 1); only 2 * NTN of them used)
+            wa[c] = stage + (w0 ^ (unsigned)(L16 ? ((c << 5) | (NTN == 4 ? (c >> 2) << 3 : 0)) : ((c << 4) | (NTN == 4 ? (c >> 3) << 3 : 0))));
     }
     // read addresses (lane-linear, the 8-byte halves swapped for flipped lanes) and the lane's byte offsets in the output
     // (one base register per read of a tile, opaque to the compiler: with a shared base it fuses the reads of two ROWS into one ds_read2st64_b64 and
@@ -904,6 +905,7 @@ constexpr int WS_MAX_GROUPS = (WS_HEADER_BYTES - 16) / 4;
 #include "asq_gemm_p8.h"
 #include "asq_gemm_p4.h"
 #include "asq_gemm_p16.h"
+#include "asq_gemm_p4x16.h"
 #include "asq_gemm_p8h.h"
 #include "asq_gemm_p8q.h"
 #include "asq_gemm_skinny.h"
@@ -951,7 +953,7 @@ __global__ void __launch_bounds__(256) splitk_reduce(const int32_t *__restrict__
 // ---------------------------------------------------------------------------------
 // dispatch + launch
 // ---------------------------------------------------------------------------------
-enum GemmKernel { KERN_GENERIC = 0, KERN_SKINNY = 1, KERN_P8 = 2, KERN_P8H = 3, KERN_P4 = 4, KERN_P8Q = 5, KERN_P16 = 6 };
+enum GemmKernel { KERN_GENERIC = 0, KERN_SKINNY = 1, KERN_P8 = 2, KERN_P8H = 3, KERN_P4 = 4, KERN_P8Q = 5, KERN_P16 = 6, KERN_P4X16 = 7 };
 
 int forced_kernel();  // env ASQ_GEMM_KERNEL=generic|skinny|p8|p8h (development / A-B aid), asq_gemm.hip
 
@@ -961,7 +963,7 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
     const bool tiled_ok = aligned && K % 128 == 0 && K >= 128 && K <= (1 << 24);
     const int f = forced_kernel();
     if (f == KERN_GENERIC) return KERN_GENERIC;
-    if (tiled_ok && (f == KERN_P8 || f == KERN_P8H || f == KERN_P4 || f == KERN_P8Q || f == KERN_P16)) return (GemmKernel)f;
+    if (tiled_ok && (f == KERN_P8 || f == KERN_P8H || f == KERN_P4 || f == KERN_P8Q || f == KERN_P16 || f == KERN_P4X16)) return (GemmKernel)f;
     if (tiled_ok && M <= 1024 && M * K < (1ll << 32) && f == KERN_SKINNY) return KERN_SKINNY;  // (32-bit row offsets in the DMA address)
     if (tiled_ok && f < 0) {
         // measured crossover (tools/cold_grid.sh: 48..256 rows x 8 LLaMA/OPT/Mixtral weight shapes, weights rotated
@@ -1210,7 +1212,7 @@ static inline TailPeel plan_tail_peel(GemmKernel kern, int64_t M, int64_t N, int
 {
     TailPeel p;
     // (the remainder launch costs ~13 us at K = 4096; the extra wave it replaces ~20 us for the 128-row kernel, 35-45 us for the 256-row ones)
-    if (kern != KERN_P8 && kern != KERN_P4 && kern != KERN_P8H && kern != KERN_P16) return p;
+    if (kern != KERN_P8 && kern != KERN_P4 && kern != KERN_P8H && kern != KERN_P16 && kern != KERN_P4X16) return p;
     static const bool disabled = getenv("ASQ_NO_TAIL") != nullptr;  // development / A-B aid
     if (disabled || forced_kernel() >= 0 || forced_ksplit() > 0 || N % 4 != 0 || K < 4096) return p;  // (a short K loop makes the extra wave cheap)
     const int64_t rows = kern == KERN_P8H ? 128 : 256;
@@ -1309,6 +1311,24 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
         }
         hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(256), P4_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, epi);
         return asq_after_launch(s, what);
+    }
+    // four waves x 128 x 128 on the 16 x 16 x 64 instruction (asq_gemm_p4x16.h): scalar / per-token scale epilogues with 2-byte outputs; otherwise p16
+    if (kern == KERN_P4X16) {
+        constexpr bool kP4X = kP4 && !Epi::kHasCol && !Epi::kHasBias;
+        if constexpr (kP4X) {
+            const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
+            ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
+            auto kfn = gemm_i8_p4x16<Epi>;
+            hipError_t e = ensure_dynamic_lds((const void *)kfn, P4_LDS_BYTES);
+            if (e != hipSuccess) {
+                asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+                return (int)e;
+            }
+            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(256), P4_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, epi);
+            return asq_after_launch(s, what);
+        } else {
+            kern = KERN_P16;
+        }
     }
     // the 256 x 256 kernel on v_mfma_i32_16x16x64_i8 (asq_gemm_p16.h): plain launches with 2-byte outputs
     bool p8_l16 = false;   // what p16 does not carry runs on p8 -- in its L16 mode (the same 16 x 16 x 64 instruction) unless p8 itself was asked for

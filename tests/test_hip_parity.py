@@ -517,7 +517,7 @@ def test_large_shapes_with_4_byte_and_ragged_outputs(dev):
         assert torch.equal(ops.linear_w8a8(xq, w, torch.bfloat16, 2e-3, None, None, None), (torch.tensor(2e-3, dtype=torch.float32, device=dev) * acc.float()).bfloat16()), ("bf16", M, N, K)
 
 
-@pytest.mark.parametrize("kern,ksplit,mma", [("p16", 0, 16), ("p8", 3, 16), ("p8", 1, 16), ("p4", 0, 16), ("p8h", 4, 16), ("p8h", 0, 16), ("p8q", 0, 16), ("p8q", 3, 16),
+@pytest.mark.parametrize("kern,ksplit,mma", [("p16", 0, 16), ("p4x16", 0, 16), ("p8", 3, 16), ("p8", 1, 16), ("p4", 0, 16), ("p8h", 4, 16), ("p8h", 0, 16), ("p8q", 0, 16), ("p8q", 3, 16),
                                              ("p8h", 4, 32), ("p8h", 0, 32), ("p8q", 0, 32), ("p8q", 3, 32), ("skinny", 0, 16), ("generic", 0, 16)])
 def test_forced_kernel_paths_in_a_child_process(kern, ksplit, mma, dev):
     """Dispatcher branches the shape heuristics never pick by themselves -- notably split-K on the 256-row kernel (pick_kernel hands
