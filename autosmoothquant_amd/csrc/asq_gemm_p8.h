@@ -122,6 +122,9 @@ template <int ABL> __device__ __forceinline__ v4i p8_ldfrag(unsigned lds_addr, i
     }
 }
 
+#ifndef P8_DMA_MOD
+#define P8_DMA_MOD ""   // cache policy of the operand DMAs (" nt", " sc1", " sc0 sc1" measured in round 3: profiles/r3_dma_policy_ab.txt)
+#endif
 // LDS-DMA, 16 B per lane: global address = SGPR-pair base + 32-bit VGPR offset (no VALU address
 // math), LDS destination = M0 (wave-uniform) + lane*16.  hipcc does not count asm memory
 // operations: every consumer is ordered by this kernel's own counted s_waitcnt vmcnt + barrier.
@@ -131,7 +134,7 @@ __device__ __forceinline__ void p8_dma16(const int8_t *sbase, unsigned voff, uns
 #ifdef ASQ_P8_PROBE   // (some ablation instantiations of tools/ubench/clock_probe evaluate base + k on the VALU: pin it again; production builds are untouched)
     sbase = uniform_ptr(sbase);
 #endif
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" P8_DMA_MOD "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
