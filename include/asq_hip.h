@@ -255,10 +255,12 @@ int asq_linear_mxfp8(const uint8_t *xq, const uint8_t *x_scales, const uint8_t *
                      int64_t M, int64_t N, int64_t K, const float *bias, void *stream);
 
 /* ---- introspection for tests / bench: which GEMM kernel the dispatcher picks for a shape (aligned operands):
- * "skinny" (weight streaming), "p8q" (128x128x128 tiles), "p8h" (128x256x128 tiles), "p8" (256x256x128 tiles, 8 waves), "p4" (the same tile,
- * 4 waves: long K) or "generic";
- * "p8+tail" / "p4+tail" when the call runs as a main launch + a column remainder of 128 x 128 tiles.
- * Development overrides (read once per process): ASQ_GEMM_KERNEL=generic|skinny|p8q|p8h|p8|p4, ASQ_KSPLIT=n, ASQ_SK_NT=1|2, ASQ_NO_TAIL=1. */
+ * "skinny" (weight streaming), "p8q" (128x128x128 tiles), "p8h" (128x256x128 tiles), "p16" (256x256x128 tiles, 8 waves, on v_mfma_i32_16x16x64_i8;
+ * launches it does not carry -- 4-byte / int8 outputs, K splits -- run the same tile on gemm_i8_p8 in its 16x16x64 mode) or "generic";
+ * "p16+tail" / "p8h+tail" when the call runs as a main launch + a column remainder of 128 x 128 tiles.
+ * Development overrides (read once per process): ASQ_GEMM_KERNEL=generic|skinny|p8q|p8h|p16|p8|p4|p4x16 (p8 / p4: the 32x32x32-instruction kernels of
+ * rounds 1-2, p4x16: four waves on the 16x16x64 instruction), ASQ_MMA=32 (p8h / p8q / grouped launches on the 32x32x32 instruction), ASQ_KSPLIT=n,
+ * ASQ_SK_NT=1|2, ASQ_NO_TAIL=1. */
 const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K);
 
 #ifdef __cplusplus
