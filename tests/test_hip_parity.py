@@ -415,7 +415,8 @@ def test_full_size_fused_forward_matches_unfused(dev):
 @pytest.mark.parametrize("counts", [[300, 0, 17, 256, 1, 511], [40, 40], [0, 0, 5], [700]])
 @pytest.mark.parametrize("per_token", [False, True])
 @pytest.mark.parametrize("K", [256, 8192])   # (Mixtral w2 has the long K)
-def test_grouped_launch_equals_per_group_calls(counts, per_token, K, dev):
+@pytest.mark.parametrize("odt", [torch.float16, torch.float32])   # (2-byte: row / staged epilogues of the 16 x 16 layout; 4-byte: its 64-row staging passes)
+def test_grouped_launch_equals_per_group_calls(counts, per_token, K, odt, dev):
     """Mixtral-style grouped launch (one kernel over all experts, routing offsets on the device) ==
     one asq_linear_w8a8 call per expert, bit for bit; empty and ragged groups included."""
     from autosmoothquant_amd import ops
@@ -428,11 +429,11 @@ def test_grouped_launch_equals_per_group_calls(counts, per_token, K, dev):
     s_row = torch.from_numpy((np.abs(detrng.normal(144, M, (M,))) * 0.01 + 1e-3).astype(np.float32)).to(dev) if per_token else None
     offs = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device=dev)
     for use_bias in (False, True):
-        got = ops.linear_w8a8_grouped(xq, w, offs, sg, torch.float16, s_row, bias if use_bias else None)
+        got = ops.linear_w8a8_grouped(xq, w, offs, sg, odt, s_row, bias if use_bias else None)
         o = 0
         for g, c in enumerate(counts):
             if c:
-                ref = ops.linear_w8a8(xq[o:o + c].contiguous(), w[g], torch.float16, float(sg[g]), None if s_row is None else s_row[o:o + c].contiguous(),
+                ref = ops.linear_w8a8(xq[o:o + c].contiguous(), w[g], odt, float(sg[g]), None if s_row is None else s_row[o:o + c].contiguous(),
                                       None, bias[g] if use_bias else None)
                 assert torch.equal(got[o:o + c], ref), (g, c, use_bias)
             o += c
