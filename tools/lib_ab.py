@@ -17,6 +17,7 @@ ap.add_argument("--batch", type=int, default=50)
 ap.add_argument("--rounds", type=int, default=12)
 ap.add_argument("--per-token", action="store_true")
 ap.add_argument("--bias", action="store_true")
+ap.add_argument("--per-channel", action="store_true")
 ap.add_argument("--a-kernel", default=None, help="ASQ_GEMM_KERNEL seen by library A (the library reads it once, at its first launch)")
 ap.add_argument("--b-kernel", default=None)
 ap.add_argument("--a-env", default="", help="KEY=VAL[,KEY=VAL] set while library A makes its first launches (the libraries read their switches once)")
@@ -57,10 +58,11 @@ for sh in args.shapes.split(","):
         w = (torch.randn(N, K, device=dev, generator=g) * 21.7).round().clamp(-127, 127).to(torch.int8)
     s_row = torch.rand(M, device=dev, generator=g) * 0.01 + 0.001 if args.per_token else None
     bias = torch.randn(N, device=dev, generator=g) if args.bias else None
+    s_col = torch.rand(N, device=dev, generator=g) * 1e-3 + 1e-4 if args.per_channel else None
     outs = {k: torch.empty(M, N, dtype=tdt, device=dev) for k in libs}
 
     def call(k):
-        rc = libs[k].asq_linear_w8a8(x.data_ptr(), w.data_ptr(), outs[k].data_ptr(), DT, M, N, K, 1.25e-4, s_row.data_ptr() if s_row is not None else None, None,
+        rc = libs[k].asq_linear_w8a8(x.data_ptr(), w.data_ptr(), outs[k].data_ptr(), DT, M, N, K, 1.25e-4, s_row.data_ptr() if s_row is not None else None, s_col.data_ptr() if s_col is not None else None,
                                      bias.data_ptr() if bias is not None else None, 0, None, 0, stream)
         if rc != 0:
             raise RuntimeError(libs[k].asq_last_error().decode())
