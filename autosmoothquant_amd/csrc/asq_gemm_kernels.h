@@ -1490,19 +1490,28 @@ template <int DT, bool R, bool C, bool B> static inline int launch_dequant_one(c
                        s, "asq_linear_w8a8", a.ws, a.ws_bytes, a.goffs, a.ngroups);
 }
 
+// The 8 epilogue variants of one output dtype are compiled in TWO translation units (with / without per-token row scales: asq_gemm_inst_<dt>.hip,
+// asq_gemm_inst_<dt>_row.hip) -- each instantiates every tiled kernel for its 4 variants, and the longest TU sets the wall time of a parallel build.
+template <int DT, bool HAS_ROW> int launch_dequant_half(const DequantArgs &a, hipStream_t s);
+template <> int launch_dequant_half<ASQ_F32, false>(const DequantArgs &a, hipStream_t s);   // (declared before their first use: the probes under tools/ubench compile all of the TUs as one)
+template <> int launch_dequant_half<ASQ_F32, true>(const DequantArgs &a, hipStream_t s);
+template <> int launch_dequant_half<ASQ_F16, false>(const DequantArgs &a, hipStream_t s);
+template <> int launch_dequant_half<ASQ_F16, true>(const DequantArgs &a, hipStream_t s);
+template <> int launch_dequant_half<ASQ_BF16, false>(const DequantArgs &a, hipStream_t s);
+template <> int launch_dequant_half<ASQ_BF16, true>(const DequantArgs &a, hipStream_t s);
+template <int DT, bool HAS_ROW> static inline int launch_dequant_half_impl(const DequantArgs &a, hipStream_t s)
+{
+    const int key = (a.s_col ? 2 : 0) | (a.bias ? 1 : 0);
+    switch (key) {
+    case 0: return launch_dequant_one<DT, HAS_ROW, false, false>(a, s);
+    case 1: return launch_dequant_one<DT, HAS_ROW, false, true>(a, s);
+    case 2: return launch_dequant_one<DT, HAS_ROW, true, false>(a, s);
+    default: return launch_dequant_one<DT, HAS_ROW, true, true>(a, s);
+    }
+}
 template <int DT> static inline int launch_dequant_impl(const DequantArgs &a, hipStream_t s)
 {
-    const int key = (a.s_row ? 4 : 0) | (a.s_col ? 2 : 0) | (a.bias ? 1 : 0);
-    switch (key) {
-    case 0: return launch_dequant_one<DT, false, false, false>(a, s);
-    case 1: return launch_dequant_one<DT, false, false, true>(a, s);
-    case 2: return launch_dequant_one<DT, false, true, false>(a, s);
-    case 3: return launch_dequant_one<DT, false, true, true>(a, s);
-    case 4: return launch_dequant_one<DT, true, false, false>(a, s);
-    case 5: return launch_dequant_one<DT, true, false, true>(a, s);
-    case 6: return launch_dequant_one<DT, true, true, false>(a, s);
-    default: return launch_dequant_one<DT, true, true, true>(a, s);
-    }
+    return a.s_row ? launch_dequant_half<DT, true>(a, s) : launch_dequant_half<DT, false>(a, s);
 }
 
 }  // namespace asq

@@ -22,6 +22,9 @@
 #include "../../autosmoothquant_amd/csrc/asq_gemm_inst_f32.hip"
 #include "../../autosmoothquant_amd/csrc/asq_gemm_inst_f16.hip"
 #include "../../autosmoothquant_amd/csrc/asq_gemm_inst_bf16.hip"
+#include "../../autosmoothquant_amd/csrc/asq_gemm_inst_f32_row.hip"
+#include "../../autosmoothquant_amd/csrc/asq_gemm_inst_f16_row.hip"
+#include "../../autosmoothquant_amd/csrc/asq_gemm_inst_bf16_row.hip"
 #include "../../autosmoothquant_amd/csrc/asq_gemm.hip"
 #include <vector>
 #include <map>

@@ -4,8 +4,11 @@
 #include "../../autosmoothquant_amd/csrc/asq_api.hip"
 #include "../../autosmoothquant_amd/csrc/asq_quant.hip"
 #include "../../autosmoothquant_amd/csrc/asq_gemm_inst_f32.hip"
+#include "../../autosmoothquant_amd/csrc/asq_gemm_inst_f32_row.hip"
 #include "../../autosmoothquant_amd/csrc/asq_gemm_inst_f16.hip"
 #include "../../autosmoothquant_amd/csrc/asq_gemm_inst_bf16.hip"
+#include "../../autosmoothquant_amd/csrc/asq_gemm_inst_f16_row.hip"
+#include "../../autosmoothquant_amd/csrc/asq_gemm_inst_bf16_row.hip"
 #include "../../autosmoothquant_amd/csrc/asq_gemm.hip"
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
