@@ -128,6 +128,15 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
             for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
                 for (int it = 0; it < 2; ++it) A[jt][it] = MmaI8x16::mma(wf[it][kk], xf[jt][kk], A[jt][it]);
+#elif P16_ORDER == 3   // token tile outermost, both k-steps of a tile back to back (experiment: the same accumulator two instructions apart)
+            if (kk == 0) {
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) A[jt][it] = MmaI8x16::mma(wf[it][k2], xf[jt][k2], A[jt][it]);
+            }
 #elif P16_ORDER == 2   // as 1 with the weight fragments snaking (w0, w1 | w1, w0 | ...): exactly one operand changes between consecutive instructions
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
