@@ -14,7 +14,7 @@
 //   uniform full-range uniform int8 (the r1 ceiling of 3500 TOPS was measured on this)
 //   zeros
 //
-//   usage: clock_probe [seconds per arm = 1.5] [what = all | gemm | mfma | abl | pmc | p4 | epi]
+//   usage: clock_probe [seconds per arm = 1.5] [what = all | gemm | mfma | abl | pmc | p4 | epi | p16]
 //   build: see Makefile (-DASQ_P8_PROBE is set by this file)
 #define ASQ_P8_PROBE 1
 #include "../../autosmoothquant_amd/csrc/asq_api.hip"
@@ -341,6 +341,43 @@ template <class Epi, int PB = 1> static void run_gemm_p4(const char *name, const
            100.0 * (double)(K / 128) * 2048.0 / cyc);
 }
 
+// the default 256 x 256 kernel (gemm_i8_p16: p8's schedule on v_mfma_i32_16x16x64_i8) with the same stamps
+template <class Epi> static void run_gemm_p16(const char *name, const int8_t *x, const int8_t *w, Epi epi, int64_t M, int64_t N, int64_t K, double seconds, Sampler &smp)
+{
+    auto kfn = gemm_i8_p16<Epi, 128>;
+    CK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES));
+    const int tm = (int)((M + 255) / 256), tn = (int)((N + 255) / 256), nb = tm * tn < 4096 ? tm * tn : 4096;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int BATCH = 50;
+    auto launch = [&]() { hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8_LDS_BYTES, 0, x, w, M, N, K, tm, tn, epi); };
+    for (int i = 0; i < 5; ++i) launch();
+    CK(hipDeviceSynchronize());
+    smp.start();
+    const auto tstart = std::chrono::steady_clock::now();
+    std::vector<double> s_clk, s_us, s_cyc[4];
+    static unsigned long long h[4096][8];
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count() < seconds) {
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < BATCH; ++i) launch();
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(p8_blk), sizeof(h)));
+        double clk = 0, c[4] = {0, 0, 0, 0};
+        for (int b = 0; b < nb; ++b) {
+            clk += (double)(h[b][3] - h[b][0]) / (double)(h[b][7] - h[b][6]) * 0.1;
+            c[0] += (double)(h[b][1] - h[b][0]); c[1] += (double)(h[b][2] - h[b][1]); c[2] += (double)(h[b][3] - h[b][2]); c[3] += (double)(h[b][3] - h[b][0]);
+        }
+        s_clk.push_back(clk / nb); s_us.push_back(ms * 1e3 / BATCH);
+        for (int i = 0; i < 4; ++i) s_cyc[i].push_back(c[i] / nb);
+    }
+    smp.stop(name);
+    auto tail = [](const std::vector<double> &v) { double s = 0; size_t a = v.size() / 2; for (size_t i = a; i < v.size(); ++i) s += v[i]; return s / (v.size() - a); };
+    const double us = tail(s_us), clk = tail(s_clk), cyc = tail(s_cyc[3]);
+    printf("  gemm_i8_p16 %-8s M=%lld N=%lld K=%lld: %.2f us/launch -> %.0f TOPS = %.1f %% of 5033; clock %.3f GHz; block %.0f cycles (prologue %.0f + K-loop %.0f + epilogue %.0f), MFMA floor %.1f %%\n",
+           name, (long long)M, (long long)N, (long long)K, us, 2.0 * M * N * K / us / 1e6, 2.0 * M * N * K / us / 1e6 / 50.33, clk, cyc, tail(s_cyc[0]), tail(s_cyc[1]), tail(s_cyc[2]),
+           100.0 * (double)(K / 128) * 2048.0 / cyc);
+}
+
 __global__ void empty_kernel(int *p) { if (p && threadIdx.x == 9999) *p = 1; }
 
 int main(int argc, char **argv)
@@ -507,6 +544,17 @@ int main(int argc, char **argv)
         run_gemm_p4("benchK16k", dxb, dwb, e16, M, N, KL, seconds, smp);
         run_gemm("p8 bench", dxb, dwb, e16, M, N, K, seconds, smp);
         run_gemm_p4("bench", dxb, dwb, e16, M, N, K, seconds, smp);
+    }
+    if (what == "p16") {   // round 3: the 16x16x64 kernel next to the 32x32x32 one, stamped, alternating in one process
+        for (int rep = 0; rep < 2; ++rep) {
+            run_gemm("p8 bench", dxb, dwb, e16, M, N, K, seconds, smp);
+            run_gemm_p16("bench", dxb, dwb, e16, M, N, K, seconds, smp);
+        }
+        run_gemm("p8 unif", dxu, dwu, e16, M, N, K, seconds, smp);
+        run_gemm_p16("uniform", dxu, dwu, e16, M, N, K, seconds, smp);
+        run_gemm_p16("zeros", dz, dz, e16, M, N, K, seconds, smp);
+        run_gemm("p8 K16k", dxb, dwb, e16, M, N, KL, seconds, smp);
+        run_gemm_p16("benchK16k", dxb, dwb, e16, M, N, KL, seconds, smp);
     }
     if (what == "epi") {   // round 3: the pipelined interior epilogue (epilogue_wave_rows); p4 against its round-2 epilogue in one process (for p8 run the previous build's "gemm" arm beside this)
         for (int rep = 0; rep < 2; ++rep) {
