@@ -736,8 +736,12 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
 // 16 x 16 tiles, get(in16, im16) returns 4 registers.  The images, the read side and the stores are the same; a lane writes, for 16-channel tile in16 and
 // 16-token tile im16 = 2 * im + h, the 8 bytes of chunk 2 * in16 + (q >> 1), half q & 1 of row 16 * h + t (16 consecutive lanes = 16 rows, one chunk:
 // conflict-free under the same swizzle).
+// wt (wave-uniform): the stores leave as write-through (sc0 sc1) buffer stores.  A launch whose whole output stays dirty in the XCDs' L2s pays for it at its end --
+// the end-of-kernel release writes it back, 5.5 us between two 4096^3 launches (profiles/r3_clock_probe_p16.txt) -- so callers set it when the output is small enough
+// for that to matter (gemm_i8_p16: <= 128 MiB); large outputs overflow the L2s during the launch anyway and are better off write-back (r3_store_policy_ab.txt).
+// (builtin buffer stores, offset in the VGPR, soffset 0: the hazard recogniser sees them -- an inline-asm store lets the next tile's ds_reads overwrite its data.)
 template <int NTM, int NTN, bool L16 = false, class Epi, class Get>
-__device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, unsigned stage)
+__device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, unsigned stage, bool wt = false)
 {
     static_assert(Epi::kOutBytes == 2, "2-byte outputs");
     static_assert(NTN == 2 || NTN == 4, "wave tile of 64 or 128 channels");
@@ -797,6 +801,8 @@ __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int6
     typedef __attribute__((address_space(1))) v4i *glb_v4i;
     const uint64_t tile = (uint64_t)(uintptr_t)uniform_ptr((const int8_t *)epi.out + (mw0 * epi.N + nw0) * 2);
 
+    const __amdgpu_buffer_rsrc_t wt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)tile, 0, 0x7FFFFFFF, 0x00020000);   // (wt: offsets < 128 * ldb, the caller keeps ldb < 2^24)
+
     using acc4_t = typename Epi::Mma::acc4_t;
     auto pack_tile = [&](int im) {
         if constexpr (L16) {
@@ -832,7 +838,13 @@ __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int6
 #pragma unroll
         for (int i = 0; i < NRD; ++i) {
             const uint64_t rowbase = tile + (uint64_t)(im * 32 + i * RPR) * ldb;   // SGPR pair: two scalar adds per store
-            *(glb_v4i)(uintptr_t)(rowbase + voff[i % NV]) = (v4i){(int)lo[i][0], (int)lo[i][1], (int)up[i][0], (int)up[i][1]};   // global_store_dwordx4 voff, data, s[base]
+            const v4i v = {(int)lo[i][0], (int)lo[i][1], (int)up[i][0], (int)up[i][1]};
+            if (wt) {
+                typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, v), wt_rsrc, (unsigned)(im * 32 + i * RPR) * ldb + voff[i % NV], 0, 17 /* sc0 sc1 */);
+            } else {
+                *(glb_v4i)(uintptr_t)(rowbase + voff[i % NV]) = v;   // global_store_dwordx4 voff, data, s[base]
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }

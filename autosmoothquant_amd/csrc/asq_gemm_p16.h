@@ -26,6 +26,9 @@
 // 2-byte outputs only.
 #pragma once
 
+#ifndef P16_WT_BYTES
+#define P16_WT_BYTES (128ll << 20)   // outputs up to this size leave as write-through stores (epilogue_wave_rows, `wt`); 0: never
+#endif
 #ifndef P16_ORDER
 #define P16_ORDER 1   // issue order inside a quadrant: 0 = the weight fragment stays for 4 instructions, 1 = the activation fragment stays for 2
 #endif
@@ -242,7 +245,8 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
         rows_path = ((((uintptr_t)epi.out) & 15) == 0) && ((epi.N * 2) % 16 == 0) && mw0 + 128 <= M && nw0 + 64 <= N && epi.N < (int64_t(1) << 27);
     if constexpr (Epi::kOutBytes == 2) P8_BAR();  // (block-uniform) every wave's ring reads are done and every wave's (dead) DMAs have landed: the ring becomes staging space
     if (rows_path) {
-        if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<4, 2, true>(epi, get, mw0, nw0, lane, lds0 + wave * 16384);
+        if constexpr (Epi::kOutBytes == 2)
+            epilogue_wave_rows<4, 2, true>(epi, get, mw0, nw0, lane, lds0 + wave * 16384, P16_WT_BYTES > 0 && M * epi.N * 2 <= (int64_t)P16_WT_BYTES && epi.N < (int64_t(1) << 23));
     } else {
         epilogue_wave16(epi, get, mw0, nw0, lane, M, N);
     }
