@@ -738,8 +738,15 @@ __device__ __forceinline__ void epilogue_wave_staged(const Epi &epi, Get get, in
 // conflict-free under the same swizzle).
 // wt (wave-uniform): the stores leave as write-through (sc0 sc1) buffer stores.  A launch whose whole output stays dirty in the XCDs' L2s pays for it at its end --
 // the end-of-kernel release writes it back, 5.5 us between two 4096^3 launches (profiles/r3_clock_probe_p16.txt) -- so callers set it when the output is small enough
-// for that to matter (gemm_i8_p16: <= 128 MiB); large outputs overflow the L2s during the launch anyway and are better off write-back (r3_store_policy_ab.txt).
+// for that to matter (rows_write_through: <= 128 MiB); large outputs overflow the L2s during the launch anyway and are better off write-back (r3_store_policy_ab.txt).
 // (builtin buffer stores, offset in the VGPR, soffset 0: the hazard recogniser sees them -- an inline-asm store lets the next tile's ds_reads overwrite its data.)
+#ifndef ASQ_WT_BYTES
+#define ASQ_WT_BYTES (128ll << 20)   // outputs up to this size leave as write-through stores (`wt` below); 0: never
+#endif
+template <class Epi> __device__ __forceinline__ bool rows_write_through(int64_t M, const Epi &epi)
+{
+    return ASQ_WT_BYTES > 0 && M * epi.N * 2 <= (int64_t)ASQ_WT_BYTES && epi.N < (int64_t(1) << 23);
+}
 template <int NTM, int NTN, bool L16 = false, class Epi, class Get>
 __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, unsigned stage, bool wt = false)
 {

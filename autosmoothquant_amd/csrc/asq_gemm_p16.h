@@ -26,9 +26,6 @@
 // 2-byte outputs only.
 #pragma once
 
-#ifndef P16_WT_BYTES
-#define P16_WT_BYTES (128ll << 20)   // outputs up to this size leave as write-through stores (epilogue_wave_rows, `wt`); 0: never
-#endif
 #ifndef P16_ORDER
 #define P16_ORDER 1   // issue order inside a quadrant: 0 = the weight fragment stays for 4 instructions, 1 = the activation fragment stays for 2
 #endif
@@ -246,7 +243,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
     if constexpr (Epi::kOutBytes == 2) P8_BAR();  // (block-uniform) every wave's ring reads are done and every wave's (dead) DMAs have landed: the ring becomes staging space
     if (rows_path) {
         if constexpr (Epi::kOutBytes == 2)
-            epilogue_wave_rows<4, 2, true>(epi, get, mw0, nw0, lane, lds0 + wave * 16384, P16_WT_BYTES > 0 && M * epi.N * 2 <= (int64_t)P16_WT_BYTES && epi.N < (int64_t(1) << 23));
+            epilogue_wave_rows<4, 2, true>(epi, get, mw0, nw0, lane, lds0 + wave * 16384, rows_write_through(M, epi));
     } else {
         epilogue_wave16(epi, get, mw0, nw0, lane, M, N);
     }

@@ -659,7 +659,7 @@ if constexpr (L16) {
                 bool rows_path = false;
                 if constexpr (Epi::kOutBytes == 2) rows_path = !half && mw0 + 128 <= M && nw0 + 64 <= N && epi.N < (int64_t(1) << 27);
                 if (rows_path) {
-                    if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<4, 2, true>(epi, get16, mw0, nw0, lane, lds0 + wave * 16384);
+                    if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<4, 2, true>(epi, get16, mw0, nw0, lane, lds0 + wave * 16384, rows_write_through(M_all, epi));
                 } else
                     epilogue_wave_staged<4, 0, true>(epi, get16, mw0, nw0, lane, Mw, N, lds0 + wave * 16384);
             }

@@ -267,7 +267,7 @@ if constexpr (L16) {
                 bool rows_path = false;
                 if constexpr (Epi::kOutBytes == 2) rows_path = mw0 + 64 <= M && nw0 + 64 <= N && epi.N < (int64_t(1) << 27);
                 if (rows_path) {
-                    if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<2, 2, true>(epi, get16, mw0, nw0, lane, lds0 + wave * 16384);
+                    if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<2, 2, true>(epi, get16, mw0, nw0, lane, lds0 + wave * 16384, rows_write_through(M, epi));
                 } else
                     epilogue_wave_staged<2, 0, true>(epi, get16, mw0, nw0, lane, M, N, lds0 + wave * 16384);
             }
