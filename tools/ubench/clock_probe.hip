@@ -354,7 +354,7 @@ template <class Epi> static void run_gemm_p16(const char *name, const int8_t *x,
     CK(hipDeviceSynchronize());
     smp.start();
     const auto tstart = std::chrono::steady_clock::now();
-    std::vector<double> s_clk, s_us, s_cyc[4];
+    std::vector<double> s_clk, s_us, s_cyc[4], sk_start, sk_end, sk_span, xcd_end, xcd_dur;
     static unsigned long long h[4096][8];
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count() < seconds) {
         CK(hipEventRecord(e0));
@@ -363,16 +363,30 @@ template <class Epi> static void run_gemm_p16(const char *name, const int8_t *x,
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(p8_blk), sizeof(h)));
         double clk = 0, c[4] = {0, 0, 0, 0};
+        unsigned long long s_min = ~0ull, s_max = 0, e_min = ~0ull, e_max = 0;   // the LAST launch of the batch (s_memrealtime, 10 ns ticks)
         for (int b = 0; b < nb; ++b) {
             clk += (double)(h[b][3] - h[b][0]) / (double)(h[b][7] - h[b][6]) * 0.1;
             c[0] += (double)(h[b][1] - h[b][0]); c[1] += (double)(h[b][2] - h[b][1]); c[2] += (double)(h[b][3] - h[b][2]); c[3] += (double)(h[b][3] - h[b][0]);
+            s_min = h[b][6] < s_min ? h[b][6] : s_min; s_max = h[b][6] > s_max ? h[b][6] : s_max;
+            e_min = h[b][7] < e_min ? h[b][7] : e_min; e_max = h[b][7] > e_max ? h[b][7] : e_max;
         }
         s_clk.push_back(clk / nb); s_us.push_back(ms * 1e3 / BATCH);
         for (int i = 0; i < 4; ++i) s_cyc[i].push_back(c[i] / nb);
+        sk_start.push_back((double)(s_max - s_min) * 0.01); sk_end.push_back((double)(e_max - e_min) * 0.01); sk_span.push_back((double)(e_max - s_min) * 0.01);
+        {   // per XCD (block b runs on XCD b % 8): when its last block ended, and the mean block duration on it
+            unsigned long long xe[8] = {0, 0, 0, 0, 0, 0, 0, 0}; double xd[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int xn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int b = 0; b < nb; ++b) { const int x = b & 7; xe[x] = h[b][7] > xe[x] ? h[b][7] : xe[x]; xd[x] += (double)(h[b][7] - h[b][6]) * 0.01; ++xn[x]; }
+            unsigned long long lo = ~0ull, hi = 0; double dlo = 1e30, dhi = 0;
+            for (int x = 0; x < 8; ++x) { lo = xe[x] < lo ? xe[x] : lo; hi = xe[x] > hi ? xe[x] : hi; const double d = xd[x] / (xn[x] ? xn[x] : 1); dlo = d < dlo ? d : dlo; dhi = d > dhi ? d : dhi; }
+            xcd_end.push_back((double)(hi - lo) * 0.01); xcd_dur.push_back(dhi / dlo);
+        }
     }
     smp.stop(name);
     auto tail = [](const std::vector<double> &v) { double s = 0; size_t a = v.size() / 2; for (size_t i = a; i < v.size(); ++i) s += v[i]; return s / (v.size() - a); };
     const double us = tail(s_us), clk = tail(s_clk), cyc = tail(s_cyc[3]);
+    printf("      one launch on the 100 MHz clock: first block start -> last block start %.2f us, first block end -> last block end %.2f us, first start -> last end %.2f us; "
+           "launch-to-launch minus that span = %.2f us with no block running\n", tail(sk_start), tail(sk_end), tail(sk_span), us - tail(sk_span));
+    printf("      per XCD (blocks b %% 8): last block of the fastest XCD -> last block of the slowest %.2f us; mean block duration slowest / fastest XCD %.3f\n", tail(xcd_end), tail(xcd_dur));
     printf("  gemm_i8_p16 %-8s M=%lld N=%lld K=%lld: %.2f us/launch -> %.0f TOPS = %.1f %% of 5033; clock %.3f GHz; block %.0f cycles (prologue %.0f + K-loop %.0f + epilogue %.0f), MFMA floor %.1f %%\n",
            name, (long long)M, (long long)N, (long long)K, us, 2.0 * M * N * K / us / 1e6, 2.0 * M * N * K / us / 1e6 / 50.33, clk, cyc, tail(s_cyc[0]), tail(s_cyc[1]), tail(s_cyc[2]),
            100.0 * (double)(K / 128) * 2048.0 / cyc);
@@ -555,6 +569,15 @@ int main(int argc, char **argv)
         run_gemm_p16("zeros", dz, dz, e16, M, N, K, seconds, smp);
         run_gemm("p8 K16k", dxb, dwb, e16, M, N, KL, seconds, smp);
         run_gemm_p16("benchK16k", dxb, dwb, e16, M, N, KL, seconds, smp);
+        {   // 1024 tiles = 4 rounds of 256 (M = 16384: the activation rows four times over): how unevenly the statically assigned XCDs finish a many-round launch
+            const int64_t M2 = 4 * M;
+            int8_t *x2; void *o2;
+            CK(hipMalloc(&x2, M2 * K)); CK(hipMalloc(&o2, M2 * N * 2));
+            for (int64_t off = 0; off < M2 * K; off += M * K) CK(hipMemcpy(x2 + off, dxb, M * K, hipMemcpyDeviceToDevice));
+            EpiDequant<ASQ_F16, false, false, false> e2{o2, N, nullptr, nullptr, nullptr, nullptr, 1e-4f, 0, true};
+            run_gemm_p16("4 rounds", x2, dwb, e2, M2, N, K, seconds, smp);
+            CK(hipFree(x2)); CK(hipFree(o2));
+        }
     }
     if (what == "epi") {   // round 3: the pipelined interior epilogue (epilogue_wave_rows); p4 against its round-2 epilogue in one process (for p8 run the previous build's "gemm" arm beside this)
         for (int rep = 0; rep < 2; ++rep) {
