@@ -18,6 +18,7 @@ ap.add_argument("--rounds", type=int, default=12)
 ap.add_argument("--per-token", action="store_true")
 ap.add_argument("--bias", action="store_true")
 ap.add_argument("--per-channel", action="store_true")
+ap.add_argument("--ws", action="store_true", help="pass an initialised workspace (header + 64 KiB): the kernels that need one -- persistent p16, split-K -- become eligible")
 ap.add_argument("--a-kernel", default=None, help="ASQ_GEMM_KERNEL seen by library A (the library reads it once, at its first launch)")
 ap.add_argument("--b-kernel", default=None)
 ap.add_argument("--a-env", default="", help="KEY=VAL[,KEY=VAL] set while library A makes its first launches (the libraries read their switches once)")
@@ -32,6 +33,8 @@ def load(path):
     h.asq_linear_w8a8.restype = cint
     h.asq_linear_w8a8.argtypes = [vp, vp, vp, cint, i64, i64, i64, f32, vp, vp, vp, cint, vp, sz, vp]
     h.asq_last_error.restype = ctypes.c_char_p
+    h.asq_workspace_init.restype = cint
+    h.asq_workspace_init.argtypes = [vp, sz, vp]
     return h
 
 
@@ -60,10 +63,15 @@ for sh in args.shapes.split(","):
     bias = torch.randn(N, device=dev, generator=g) if args.bias else None
     s_col = torch.rand(N, device=dev, generator=g) * 1e-3 + 1e-4 if args.per_channel else None
     outs = {k: torch.empty(M, N, dtype=tdt, device=dev) for k in libs}
+    wss = {}
+    if args.ws:
+        for k in libs:
+            wss[k] = torch.zeros(8192 + 65536, dtype=torch.uint8, device=dev)
+            assert libs[k].asq_workspace_init(wss[k].data_ptr(), wss[k].numel(), stream) == 0
 
     def call(k):
         rc = libs[k].asq_linear_w8a8(x.data_ptr(), w.data_ptr(), outs[k].data_ptr(), DT, M, N, K, 1.25e-4, s_row.data_ptr() if s_row is not None else None, s_col.data_ptr() if s_col is not None else None,
-                                     bias.data_ptr() if bias is not None else None, 0, None, 0, stream)
+                                     bias.data_ptr() if bias is not None else None, 0, wss[k].data_ptr() if args.ws else None, wss[k].numel() if args.ws else 0, stream)
         if rc != 0:
             raise RuntimeError(libs[k].asq_last_error().decode())
 
