@@ -11,6 +11,7 @@ ASQ_ACT_ROUND, ASQ_ACT_DIV, ASQ_ACT_PER_TOKEN = 0, 1, 2
 ASQ_EPI_SCALE_FIRST, ASQ_EPI_ACC_FIRST = 0, 1
 ASQ_FP8_PER_TOKEN, ASQ_FP8_PER_TENSOR, ASQ_FP8_STATIC = 0, 1, 2
 
+ASQ_VERSION = 110   # include/asq_hip.h: the C-ABI this loader was written against
 _lock = threading.Lock()
 _lib = None
 
@@ -37,6 +38,11 @@ SIGNATURES = {
     "asq_linear_w8a8_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "asq_linear_w8a8_forward": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _int, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "asq_gemm_kernel_name": (ctypes.c_char_p, [_i64, _i64, _i64]),
+    "asq_weight_offset_image": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "asq_quantize_act_off": (_int, [_vp, _int, _int, _f32, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "asq_linear_w8a8_off": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
+    "asq_offsets_supported": (_int, [_i64, _i64, _i64, _int]),
+    "asq_linear_w8a8_forward_off": (_int, [_vp, _int, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "asq_quantize_act_fp8": (_int, [_vp, _int, _int, _f32, _vp, _vp, _i64, _i64, _vp]),
     "asq_linear_fp8": (_int, [_vp, _vp, _int, _vp, _int, _i64, _i64, _i64, _vp, _int, _f32, _f32, _vp, _vp]),
     "asq_linear_fp8_grouped": (_int, [_vp, _vp, _vp, _int, _vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
@@ -60,6 +66,8 @@ def lib():
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(h, name)  # AttributeError if the .so lacks a declared symbol
                     fn.restype, fn.argtypes = res, args
+                if h.asq_version() != ASQ_VERSION:   # a stale build: argument lists and the workspace contract may differ
+                    raise RuntimeError(f"{LIB_PATH} reports C-ABI version {h.asq_version()}, this package needs {ASQ_VERSION}: rebuild it (make -C autosmoothquant_amd/csrc)")
                 _lib = h
     return _lib
 

@@ -38,7 +38,7 @@ static inline size_t forward_gemm_part(int64_t M, int64_t N, int64_t K)
 extern "C" size_t asq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K)
 {
     if (M < 0 || K < 0 || N < 0) return 0;
-    return forward_gemm_part(M, N, K) + round_up((size_t)M * (size_t)K, 256) + round_up((size_t)M * 4, 256);
+    return forward_gemm_part(M, N, K) + round_up((size_t)M * (size_t)K, 256) + round_up((size_t)M * 4, 256) + round_up((size_t)M * 8, 256);   // (last: row offsets of asq_linear_w8a8_forward_off)
 }
 
 extern "C" int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t *w, void *out, int64_t M, int64_t N, int64_t K,
@@ -61,4 +61,28 @@ extern "C" int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t 
     if (rc) return rc;
     return asq_linear_w8a8(xq, w, out, x_dtype, M, N, K, s_scalar, act_mode == ASQ_ACT_PER_TOKEN ? s_row : nullptr, s_col, bias,
                            ASQ_EPI_SCALE_FIRST, with_gemm_ws ? workspace : nullptr, with_gemm_ws ? gbytes : 0, stream);
+}
+
+// The same forward on OFFSET operand images (include/asq_hip.h): when the caller passes the weight's image and the shape is one the dispatcher gives to the
+// 256 x 256 kernel, the quantiser emits x + cx[m] and the GEMM starts its accumulators at the correction terms; every other call is the plain forward.
+extern "C" int asq_linear_w8a8_forward_off(const void *x, int x_dtype, const int8_t *w, const int8_t *w_off, const int32_t *col_off, void *out, int64_t M, int64_t N,
+                                           int64_t K, int act_mode, float quant_scale, float s_scalar, const float *s_col, const float *bias, void *workspace,
+                                           size_t workspace_bytes, void *stream)
+{
+    ASQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, ASQ_ERR_DIM, "asq_linear_w8a8_forward_off: bad dims");
+    if (M == 0 || N == 0) return ASQ_OK;
+    const size_t plain = round_up((size_t)M * (size_t)K, 256) + round_up((size_t)M * 4, 256), need = plain + round_up((size_t)M * 8, 256);
+    const size_t gbytes = forward_gemm_part(M, N, K);
+    const bool use = w_off != nullptr && col_off != nullptr && workspace != nullptr && workspace_bytes >= gbytes + need && (((uintptr_t)x | (uintptr_t)w_off) & 15) == 0 &&
+                     (((uintptr_t)col_off) & 15) == 0 && asq_offsets_supported(M, N, K, x_dtype);
+    if (!use) return asq_linear_w8a8_forward(x, x_dtype, w, out, M, N, K, act_mode, quant_scale, s_scalar, s_col, bias, workspace, workspace_bytes, stream);
+    ASQ_REQUIRE(((uintptr_t)workspace & 255) == 0, ASQ_ERR_ALIGN, "asq_linear_w8a8_forward_off: workspace must be 256-B aligned");
+    char *base = (char *)workspace + gbytes;
+    int8_t *xq = (int8_t *)base;
+    float *s_row = (float *)(base + round_up((size_t)M * (size_t)K, 256));
+    int32_t *row_off = (int32_t *)(base + plain);
+    int rc = asq_quantize_act_off(x, x_dtype, act_mode, quant_scale, xq, s_row, row_off, M, K, stream);
+    if (rc) return rc;
+    return asq_linear_w8a8_off(xq, w_off, out, x_dtype, M, N, K, s_scalar, act_mode == ASQ_ACT_PER_TOKEN ? s_row : nullptr, s_col, bias, ASQ_EPI_SCALE_FIRST, row_off,
+                               col_off, stream);
 }

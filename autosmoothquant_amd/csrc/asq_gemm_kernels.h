@@ -919,6 +919,20 @@ constexpr int WS_HEADER_BYTES = 8192;
 constexpr unsigned long long WS_MAGIC = 0x4153515753763031ull;  // "ASQWSv01"
 constexpr int WS_MAX_GROUPS = (WS_HEADER_BYTES - 16) / 4;
 
+// OFFSET operands (asq_linear_w8a8_off; include/asq_hip.h "offset operand images").  Under the socket power limit the 256 x 256 GEMM's time is its
+// energy, and most of the matrix cores' data-dependent energy is two's-complement sign extension (profiles/r2_clock_power_evidence.md section 3,
+// profiles/r4_operand_offsets.md): weights around 0 and activations around 0 flip the high bits of operands, products and partial sums all the time.
+// The int8 MFMA is signed x signed only, but an offset per ROW is exact and never clamps when it is chosen from the row's own extremes:
+//     x'[m,k] = x[m,k] + cx[m],  w'[n,k] = w[n,k] + cw[n]
+//     sum_k x[m,k] w[n,k] = sum_k x'[m,k] w'[n,k]  -  cx[m] * sum_k w[n,k]  -  cw[n] * sum_k x'[m,k]
+// The kernel multiplies the primed matrices and starts its accumulators at the two (rank-1) correction terms: K loop and epilogue are unchanged and the
+// int32 result is bit-identical to the plain product (two's-complement wrap-around everywhere, also inside v_mfma_i32_*: tools/ubench/mfma_bias_power).
+struct OffsetArgs {
+    const int32_t *row = nullptr;  // [M][2]: {cx[m], sum_k x'[m,k]}       (written by the activation quantiser, asq_quantize_act_off)
+    const int32_t *col = nullptr;  // [N][2]: {cw[n], sum_k w[n,k]}        (sum of the ORIGINAL weight row; asq_weight_offset_image)
+};
+constexpr int64_t OFFSET_MAX_K = 65536;   // the start values are formed with 24-bit multiplies: |sum_k| <= 128 K < 2^23 + 1
+
 }  // namespace asq
 
 #include "asq_gemm_p8.h"
@@ -1015,6 +1029,13 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
         return KERN_P16;
     }
     return KERN_GENERIC;
+}
+
+// shapes gemm_i8_p16 can run with offset operands (whether it SHOULD is offsets_profitable: the dispatcher's own choice of p16)
+static inline bool offsets_shape_ok(const void *x, const void *w, int64_t M, int64_t N, int64_t K)
+{
+    const bool aligned = ((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0;
+    return aligned && K % 128 == 0 && K >= 128 && K <= OFFSET_MAX_K && N % 4 == 0 && N >= 4 && M >= 1;
 }
 
 static inline int forced_ksplit()  // env ASQ_KSPLIT=n forces a split count (development / tuning aid)
@@ -1274,7 +1295,8 @@ template <class Epi> struct HasColView<Epi, std::enable_if_t<Epi::kColView>> : s
 // `ws` below is the scratch part (split-K slabs), `ws_hdr` the whole thing (null when the caller's buffer is too small to hold a header).
 template <class Epi>
 int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, Epi epi, hipStream_t s, const char *what, void *ws_hdr, void *ws,
-                     size_t ws_bytes, const int *goffs = nullptr, int ngroups = 0, int peel_role = 0 /* 0 top level, 1 main part, 2 remainder (128 x 128 tiles) */)
+                     size_t ws_bytes, const int *goffs = nullptr, int ngroups = 0, int peel_role = 0 /* 0 top level, 1 main part, 2 remainder (128 x 128 tiles) */,
+                     OffsetArgs off = OffsetArgs{})
 {
     if (M == 0 || N == 0) return ASQ_OK;
     if constexpr (!IsGroupable<Epi>::value) {
@@ -1306,8 +1328,12 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
     }
     constexpr bool kInt = Epi::Mma::kIsInt;
     GemmKernel kern = peel_role == 2 ? KERN_P8Q : pick_kernel(x, w, M, N, K);
+    if (off.row != nullptr) {   // offset operands: gemm_i8_p16 only (the entry point has checked the shape: offsets_supported)
+        ASQ_REQUIRE(kInt && Epi::kOutBytes == 2 && offsets_shape_ok(x, w, M, N, K), ASQ_ERR_DIM, "%s: offset operands need the 256 x 256 kernel (2-byte output, K %% 128 == 0, K <= 65536, N %% 4 == 0, aligned operands)", what);
+        kern = KERN_P16;
+    }
     if constexpr (kInt && HasColView<Epi>::value) {
-        if (peel_role == 0 && (N * Epi::kOutBytes) % 16 == 0) {
+        if (off.row == nullptr && peel_role == 0 && (N * Epi::kOutBytes) % 16 == 0) {
             const TailPeel tp = plan_tail_peel(kern, M, N, K);
             if (tp.n_main > 0) {
                 const int rc = launch_gemm_impl(x, w, M, tp.n_main, K, epi, s, what, nullptr, nullptr, 0, nullptr, 0, 1);
@@ -1359,14 +1385,15 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
         const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
         ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
         auto kfn = gemm_i8_p16<Epi>;
-        hipError_t e = ensure_dynamic_lds((const void *)kfn, P8_LDS_BYTES);
+        hipError_t e = ensure_dynamic_lds((const void *)kfn, P16_LDS_BYTES);
         if (e != hipSuccess) {
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
             return (int)e;
         }
-        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, epi);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), off.row ? P16_LDS_BYTES : P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, epi, off);
         return asq_after_launch(s, what);
     }
+    ASQ_REQUIRE(off.row == nullptr, ASQ_ERR_DIM, "%s: offset operands: no kernel", what);
     if (kern == KERN_P8) {
         const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
         ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
@@ -1466,11 +1493,11 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
 
 template <class Epi>
 int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, Epi epi, hipStream_t s, const char *what, void *ws = nullptr,
-                size_t ws_bytes = 0, const int *goffs = nullptr, int ngroups = 0)
+                size_t ws_bytes = 0, const int *goffs = nullptr, int ngroups = 0, OffsetArgs off = OffsetArgs{})
 {
     const bool has = ws != nullptr && ws_bytes >= (size_t)WS_HEADER_BYTES && (((uintptr_t)ws) & 15) == 0;
     return launch_gemm_impl(x, w, M, N, K, epi, s, what, has ? ws : nullptr, has ? (char *)ws + WS_HEADER_BYTES : nullptr, has ? ws_bytes - WS_HEADER_BYTES : 0, goffs,
-                            ngroups, 0);
+                            ngroups, 0, off);
 }
 
 // per-dtype instantiation units (asq_gemm_inst_*.hip)
@@ -1487,6 +1514,7 @@ struct DequantArgs {
     const float *s_group = nullptr;  // grouped launch (asq_linear_w8a8_grouped)
     const int *goffs = nullptr;
     int ngroups = 0;
+    OffsetArgs off;                  // offset operands (asq_linear_w8a8_off)
 };
 template <int DT> int launch_dequant(const DequantArgs &a, hipStream_t s);
 struct DequantQArgs {
@@ -1506,7 +1534,7 @@ template <int DT> static inline int launch_dequant_q_impl(const DequantQArgs &q,
 template <int DT, bool R, bool C, bool B> static inline int launch_dequant_one(const DequantArgs &a, hipStream_t s)
 {
     return launch_gemm(a.xq, a.w, a.M, a.N, a.K, EpiDequant<DT, R, C, B>{a.out, a.N, a.s_row, a.s_col, a.bias, a.s_group, a.s_scalar, a.order, a.vec_ok},
-                       s, "asq_linear_w8a8", a.ws, a.ws_bytes, a.goffs, a.ngroups);
+                       s, "asq_linear_w8a8", a.ws, a.ws_bytes, a.goffs, a.ngroups, a.off);
 }
 
 // The 8 epilogue variants of one output dtype are compiled in TWO translation units (with / without per-token row scales: asq_gemm_inst_<dt>.hip,

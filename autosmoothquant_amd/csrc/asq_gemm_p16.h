@@ -34,7 +34,7 @@ namespace asq {
 
 template <class Epi, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
-                                                      int tiles_m, int tiles_n, Epi epi_in)
+                                                      int tiles_m, int tiles_n, Epi epi_in, OffsetArgs off)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -54,6 +54,24 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
     const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
     const int tile_m = first_m + in_group % gm, tile_n = in_group / gm;
     const int64_t m0 = (int64_t)tile_m * 256, n0 = (int64_t)tile_n * 256;
+
+    // OFFSET operands (OffsetArgs, asq_gemm_kernels.h): x and w hold X + cx[m] and W + cw[n]; the K loop is the plain one on them and the exact product is
+    // recovered in front of the epilogue: acc -= cx[m] * wsum[n] + cw[n] * xsum'[m] (int32 arithmetic wraps, in the matrix cores too), two v_mad_i32_i24 per
+    // element.  The tile's 256 {cx, xsum'} and 256 {cw, wsum} pairs are fetched by ONE 8-byte load per thread, first thing in the kernel (inline asm, like the
+    // DMAs: hipcc counts neither; the prologue's vmcnt(4) covers it -- in-order return), and parked in the 3 KiB of LDS behind the ring until the K loop is done.
+    // (Round-4 measurements, tools/ubench/clock_probe off.  The same correction as the accumulators' START values costs 1.75-2.0 k cycles of prologue whatever the
+    // form -- 16 per-lane loads per wave or one load per thread staged through LDS, 256 or 144 VALU operations: the first data of a launch arrives ~2.5 k cycles
+    // after its start whatever is asked for, so nothing that waits for global data is covered by the first K-tile's latency -- and the large start values cost the
+    // K loop ~1.5 % of clock.  As plain C loads in the prologue the compiler's own vmcnt(7..0), counted without the 8 younger DMAs, held the start values
+    // back until the whole first K-tile had landed; split over two conditional regions they even leaked vmcnt(0) into the K loop: 48 -> 55 us.)
+    const bool offs = off.row != nullptr;   // (block-uniform)
+    v2i opair = {0, 0};
+    if (offs) {
+        const int i = tid & 255;
+        const int64_t idx = tid < 256 ? (m0 + i < M ? m0 + i : M - 1) : (n0 + i < N ? n0 + i : N - 1);
+        const int32_t *src = (tid < 256 ? off.row : off.col) + 2 * idx;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(opair) : "v"(src) : "memory");
+    }
 
     // ---- DMA sources (as p8): this wave fills row-groups 2*wave, 2*wave+1 (8 rows each) of every unit
     const int nt = (int)(K / 128);
@@ -92,6 +110,20 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
             asm volatile("" : "+v"(xb[s][kk]), "+v"(wbp[s][kk]));
         }
 
+    const int klast = (nt - 1) * 128;
+    auto issue = [&](int kind, int stage, int k0) {
+        const int8_t *b = ((kind == 0 || kind == 3) ? xbase : wbase) + k0;  // SALU
+#pragma unroll
+        for (int i = 0; i < 2; ++i) p8_dma16(b, voff[kind][i], dma_dst + stage * P8_STAGE + kind * P8_UNIT + i * 1024);
+    };
+
+    // Accumulators.  Plain launches start at 0.  OFFSET operands (OffsetArgs, asq_gemm_kernels.h): x and w hold X + cx[m] and W + cw[n]; the two rank-1
+    // correction terms go into the accumulators' START values, so the K loop and the epilogue are the plain ones and the result is the exact X . W^T
+    // (int32 arithmetic wraps, in the matrix cores too).  The vectors are requested BEFORE the first K-tile's DMAs (in-order return: the compiler's
+    // vmcnt for them never waits for a DMA) and the 128 start values are formed while that tile is in flight.
+    // ---- prologue: K-tile 0 entirely (units 0..3), wait for the two units P1 reads
+#pragma unroll
+    for (int kind = 0; kind < 4; ++kind) issue(kind, 0, 0);
     v4i acc[2][2][4][2];  // [m-half][n-half][token tile][channel tile]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -101,18 +133,16 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int d = 0; d < 2; ++d) acc[a][b][c][d] = (v4i){0, 0, 0, 0};
-
-    const int klast = (nt - 1) * 128;
-    auto issue = [&](int kind, int stage, int k0) {
-        const int8_t *b = ((kind == 0 || kind == 3) ? xbase : wbase) + k0;  // SALU
-#pragma unroll
-        for (int i = 0; i < 2; ++i) p8_dma16(b, voff[kind][i], dma_dst + stage * P8_STAGE + kind * P8_UNIT + i * 1024);
-    };
-
-    // ---- prologue: K-tile 0 entirely (units 0..3), wait for the two units P1 reads
-#pragma unroll
-    for (int kind = 0; kind < 4; ++kind) issue(kind, 0, 0);
     P8_WAIT_VM(4);
+    typedef __attribute__((address_space(3))) v2i *lds_v2i;
+    typedef __attribute__((address_space(3))) v4i *lds_v4i_;
+    typedef __attribute__((address_space(3))) int *lds_i32;
+    const unsigned obase = lds0 + P8_LDS_BYTES;   // [256 row words: (-cx) << 24 | (-xsum') & 0xFFFFFF][256 column pairs {cw, wsum}]
+    if (offs) {
+        asm volatile("" : "+v"(opair));   // (keeps every use of the loaded pair behind the wait above)
+        if (tid < 256) *(lds_i32)(uintptr_t)(obase + tid * 4) = (int)(((unsigned)(-opair[0]) << 24) | ((unsigned)(-opair[1]) & 0xFFFFFFu));   // |cx| <= 64, |xsum'| < 2^23
+        else *(lds_v2i)(uintptr_t)(obase + 1024 + (tid - 256) * 8) = opair;
+    }
     P8_BAR();
     if (wm == 1) P8_BAR();  // stagger: the wm=1 group runs one barrier behind
     P8_BLK(1);
@@ -240,8 +270,36 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
     bool rows_path = false;
     if constexpr (Epi::kOutBytes == 2)
         rows_path = ((((uintptr_t)epi.out) & 15) == 0) && ((epi.N * 2) % 16 == 0) && mw0 + 128 <= M && nw0 + 64 <= N && epi.N < (int64_t(1) << 27);
-    if constexpr (Epi::kOutBytes == 2) P8_BAR();  // (block-uniform) every wave's ring reads are done and every wave's (dead) DMAs have landed: the ring becomes staging space
-    if (rows_path) {
+    if constexpr (Epi::kOutBytes == 2) P8_BAR();  // (block-uniform) every wave's ring reads are done and every wave's (dead) DMAs have landed: the ring becomes staging space; the staged pairs are visible
+    if (offs) {
+        // this lane's 16 channels {cw, wsum} (32 registers) and its 8 tokens' packed words (8): two v_mad_i32_i24 per element (v_mul_i32_i24 semantics: the low 24 bits
+        // of either factor, sign-extended -- the packed word IS -xsum' there) + one shift per accumulator tile for -cx
+        const int t16i = lane & 15, q16i = lane >> 4;
+        int cw[4][4], ws[4][4], rw[8];
+#pragma unroll
+        for (int in16 = 0; in16 < 4; ++in16) {
+            const unsigned ca = obase + 1024 + (wn * 64 + in16 * 16 + 4 * q16i) * 8;
+            const v4i p0 = *(lds_v4i_)(uintptr_t)ca, p1 = *(lds_v4i_)(uintptr_t)(ca + 16);   // channels n, n+1 | n+2, n+3
+            cw[in16][0] = p0[0], cw[in16][1] = p0[2], cw[in16][2] = p1[0], cw[in16][3] = p1[2];
+            ws[in16][0] = p0[1], ws[in16][1] = p0[3], ws[in16][2] = p1[1], ws[in16][3] = p1[3];
+        }
+#pragma unroll
+        for (int im16 = 0; im16 < 8; ++im16) rw[im16] = *(lds_i32)(uintptr_t)(obase + (wm * 128 + im16 * 16 + t16i) * 4);
+        auto getc = [&](int in16, int im16) -> v4i {
+            const v4i &a = acc[im16 >> 2][in16 >> 1][im16 & 3][in16 & 1];
+            const int ncx = rw[im16] >> 24;
+            v4i o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = __mul24(cw[in16][e], rw[im16]) + (__mul24(ncx, ws[in16][e]) + a[e]);
+            return o;
+        };
+        if (rows_path) {
+            if constexpr (Epi::kOutBytes == 2)
+                epilogue_wave_rows<4, 2, true>(epi, getc, mw0, nw0, lane, lds0 + wave * 16384, rows_write_through(M, epi));
+        } else {
+            epilogue_wave16(epi, getc, mw0, nw0, lane, M, N);
+        }
+    } else if (rows_path) {
         if constexpr (Epi::kOutBytes == 2)
             epilogue_wave_rows<4, 2, true>(epi, get, mw0, nw0, lane, lds0 + wave * 16384, rows_write_through(M, epi));
     } else {

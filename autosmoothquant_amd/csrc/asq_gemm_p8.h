@@ -46,6 +46,7 @@ namespace asq {
 constexpr int P8_UNIT = 128 * 128;        // 16 KiB
 constexpr int P8_STAGE = 4 * P8_UNIT;     // one K-tile: 64 KiB
 constexpr int P8_LDS_BYTES = 2 * P8_STAGE;
+constexpr int P16_LDS_BYTES = P8_LDS_BYTES + 4096;   // gemm_i8_p16 on offset operands: + the tile's 256 row and 256 column pairs behind the ring
 // grouped launches (the scheduler at the top of gemm_i8_p8)
 constexpr int P8_GROUPED_SCAN_MAX = 64;     // groups a block may scan twice (tile total, then its own tile)
 constexpr int P8_CUS_PER_XCD = 32;          // MI355X: 256 CUs in 8 XCDs; one 128-KiB-LDS block per CU

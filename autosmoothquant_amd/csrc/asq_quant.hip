@@ -253,6 +253,208 @@ template <int DT> int quantize_dt(const void *x, int mode, float quant_scale, in
     }
 }
 
+// ---------------------------------------------------------------------------------
+// OFFSET operand images (asq_gemm_kernels.h: OffsetArgs; include/asq_hip.h).  The quantisers below emit x'[m,k] = xq[m,k] + cx[m] and the row vector
+// {cx[m], sum_k x'[m,k]}; asq_weight_offset_image does the same once per weight.  The offsets come from the row's own extremes, so nothing clamps:
+//     activations  cx = +C if max_k xq <= 127 - C, else -C if min_k xq >= -128 + C, else 0         (C = 3: the bulk of a SmoothQuant-style row is within +-3)
+//     weights      cw = min(CW, 127 - max_k w)                                                     (CW = 64)
+// (profiles/r4_operand_offsets.md: what the matrix cores sustain for which offsets; oracle/offsets.py restates both rules.)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(v2us, a), __builtin_bit_cast(v2us, b)));
+}
+// running max / min / sum of packed int8 words, carried on the bytes biased by +128 (0..255) as pairs of 16-bit lanes: no unpacking
+struct RowStats {
+    uint32_t mx = 0, mn = 0x00FF00FFu, sum = 0;   // (sum: two 16-bit partial sums of biased bytes -- at most 2 * 160 words * 255 per thread)
+    int n = 0;                                    // bytes added
+    __device__ __forceinline__ void add(uint32_t packed)
+    {
+        const uint32_t u = packed ^ 0x80808080u, a = u & 0x00FF00FFu, b = (u >> 8) & 0x00FF00FFu;
+        mx = pk_max_u16(mx, pk_max_u16(a, b));
+        mn = pk_min_u16(mn, pk_min_u16(a, b));
+        sum += a + b;
+        n += 4;
+    }
+};
+// block-wide (256 threads) max / min / sum of the quantised row; red: 12 ints of shared memory
+__device__ __forceinline__ void block_row_stats(const RowStats &st, int *red, int &rmax, int &rmin, int &rsum)
+{
+    int mx = (int)umax32(st.mx & 0xFFFFu, st.mx >> 16) - 128, mn = (int)(((st.mn & 0xFFFFu) < (st.mn >> 16)) ? (st.mn & 0xFFFFu) : (st.mn >> 16)) - 128;
+    int sm = (int)((st.sum & 0xFFFFu) + (st.sum >> 16)) - 128 * st.n;
+    if (st.n == 0) { mx = -128; mn = 127; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int omx = __shfl_xor(mx, off, 64), omn = __shfl_xor(mn, off, 64);
+        mx = mx > omx ? mx : omx;
+        mn = mn < omn ? mn : omn;
+        sm += __shfl_xor(sm, off, 64);
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();   // (red may still be read by a previous reduction)
+    if ((threadIdx.x & 63) == 0) { red[wave] = mx; red[4 + wave] = mn; red[8 + wave] = sm; }
+    __syncthreads();
+    const int a = red[0] > red[1] ? red[0] : red[1], b = red[2] > red[3] ? red[2] : red[3];
+    const int c = red[4] < red[5] ? red[4] : red[5], d = red[6] < red[7] ? red[6] : red[7];
+    rmax = a > b ? a : b;
+    rmin = c < d ? c : d;
+    rsum = (red[8] + red[9]) + (red[10] + red[11]);
+}
+__device__ __forceinline__ int pick_row_offset(int rmax, int rmin, int C)
+{
+    return rmax <= 127 - C ? C : (rmin >= -128 + C ? -C : 0);
+}
+// four packed int8 + the same small constant each, no carries between the bytes (the caller guarantees every sum stays in [-128, 127])
+__device__ __forceinline__ uint32_t pk_add_i8(uint32_t a, uint32_t c4)
+{
+    return ((a & 0x7F7F7F7Fu) + (c4 & 0x7F7F7F7Fu)) ^ ((a ^ c4) & 0x80808080u);
+}
+
+// any of the three activation quantisers with row offsets: one 256-thread block per row, the row in registers (as quant_per_token_cached), the
+// quantised row kept PACKED in registers between the statistics and the store.  K % VEC == 0, K <= 256 * VEC * NV, 16-byte aligned rows.
+template <int DT, int NV, class Q, bool PER_TOKEN>
+__global__ void __launch_bounds__(256) quant_rows_off(const void *__restrict__ xv, int8_t *__restrict__ xq, float *__restrict__ s_row,
+                                                      int32_t *__restrict__ row_off, int K, Q q_in, int C)
+{
+    constexpr int VEC = ElemT<DT>::VEC;
+    __shared__ float red[4];
+    __shared__ int redi[12];
+    const int64_t row = blockIdx.x;
+    const char *xrow = (const char *)xv + row * (int64_t)K * (16 / VEC);
+    const int nvec = K / VEC;
+    v4i v[NV];
+    [[maybe_unused]] AbsMax<DT> am;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = i * 256 + threadIdx.x;
+        if (idx < nvec) {
+            v[i] = *(const v4i *)(xrow + (int64_t)idx * 16);
+            if constexpr (PER_TOKEN) am.add(v[i]);
+        }
+    }
+    uint32_t o[NV][2];
+    RowStats st;
+    auto emit = [&](auto q) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = i * 256 + threadIdx.x;
+            if (idx < nvec) {
+                quant_vec<DT>(v[i], q, o[i]);
+                st.add(o[i][0]);
+                if constexpr (DT != ASQ_F32) st.add(o[i][1]);
+            }
+        }
+    };
+    if constexpr (PER_TOKEN) {
+        const float m = block_absmax_256(am.f32bits(), red);
+        const float qs = ElemT<DT>::round(m / 127.0f);
+        if (threadIdx.x == 0) s_row[row] = qs;
+        const RowDivisor d(qs, m);
+        if (d.fast) emit(QRowFast{d.s, d.y});
+        else emit(QDivF32<DT>{qs});
+    } else {
+        emit(q_in);
+    }
+    int rmax, rmin, rsum;
+    block_row_stats(st, redi, rmax, rmin, rsum);
+    const int cx = pick_row_offset(rmax, rmin, C);
+    if (threadIdx.x == 0) *(v2i *)(row_off + 2 * row) = (v2i){cx, rsum + cx * K};
+    const uint32_t c4 = (uint32_t)(cx & 0xFF) * 0x01010101u;
+    int8_t *orow = xq + row * (int64_t)K;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = i * 256 + threadIdx.x;
+        if (idx < nvec) {
+            if constexpr (DT == ASQ_F32) {
+                *(uint32_t *)(orow + (int64_t)idx * 4) = pk_add_i8(o[i][0], c4);
+            } else {
+                *(uint2 *)(orow + (int64_t)idx * 8) = make_uint2(pk_add_i8(o[i][0], c4), pk_add_i8(o[i][1], c4));
+            }
+        }
+    }
+}
+
+template <int DT, class Q, bool PT> int launch_rows_off(const void *x, int8_t *xq, float *s_row, int32_t *row_off, int64_t M, int64_t K, Q q, int C, hipStream_t s)
+{
+    constexpr int VEC = ElemT<DT>::VEC;
+    const int64_t nvec = K / VEC;
+    dim3 grid((unsigned)M), block(256);
+#define ASQ_RO(NV) hipLaunchKernelGGL((quant_rows_off<DT, NV, Q, PT>), grid, block, 0, s, x, xq, s_row, row_off, (int)K, q, C)
+    if (nvec <= 256 * 1) ASQ_RO(1);
+    else if (nvec <= 256 * 2) ASQ_RO(2);
+    else if (nvec <= 256 * 4) ASQ_RO(4);
+    else if (nvec <= 256 * 8) ASQ_RO(8);
+    else ASQ_RO(20);
+#undef ASQ_RO
+    return asq_after_launch(s, "asq_quantize_act_off");
+}
+
+template <int DT> int quantize_off_dt(const void *x, int mode, float quant_scale, int8_t *xq, float *s_row, int32_t *row_off, int64_t M, int64_t K, int C, hipStream_t s)
+{
+    switch (mode) {
+    case ASQ_ACT_ROUND: return launch_rows_off<DT, QRound<DT>, false>(x, xq, s_row, row_off, M, K, QRound<DT>{}, C, s);
+    case ASQ_ACT_DIV:
+        if (quant_scale > 0x1p-60f && quant_scale < 0x1p60f)
+            return launch_rows_off<DT, QDivFast<DT>, false>(x, xq, s_row, row_off, M, K, QDivFast<DT>{quant_scale, 1.0f / quant_scale}, C, s);
+        return launch_rows_off<DT, QDiv<DT>, false>(x, xq, s_row, row_off, M, K, QDiv<DT>{quant_scale}, C, s);
+    default: return launch_rows_off<DT, QRound<DT>, true>(x, xq, s_row, row_off, M, K, QRound<DT>{}, C, s);
+    }
+}
+
+// weights, once per module: w'[n,k] = w[n,k] + cw[n]; col_off[n] = {cw[n], sum_k w[n,k]} (the sum of the ORIGINAL row).  One block per row, two passes
+// (the second one over L2); K % 16 == 0, 16-byte aligned rows.
+__global__ void __launch_bounds__(256) weight_offset_image(const int8_t *__restrict__ w, int8_t *__restrict__ w_off, int32_t *__restrict__ col_off, int64_t N,
+                                                           int K, int CW)
+{
+    __shared__ int redi[12];
+    const int64_t row = blockIdx.x;
+    const uint4 *src = (const uint4 *)(w + row * (int64_t)K);
+    uint4 *dst = (uint4 *)(w_off + row * (int64_t)K);
+    const int nvec = K / 16;
+    int mx = -128, mn = 127, sm = 0;
+    for (int i = threadIdx.x; i < nvec; i += 256) {
+        const uint4 v = src[i];
+        RowStats st;   // (per vector: the packed 16-bit partial sums stay far from overflow)
+        st.add(v.x), st.add(v.y), st.add(v.z), st.add(v.w);
+        const int vmx = (int)umax32(st.mx & 0xFFFFu, st.mx >> 16) - 128;
+        const int vmn = (int)(((st.mn & 0xFFFFu) < (st.mn >> 16)) ? (st.mn & 0xFFFFu) : (st.mn >> 16)) - 128;
+        mx = mx > vmx ? mx : vmx;
+        mn = mn < vmn ? mn : vmn;
+        sm += (int)((st.sum & 0xFFFFu) + (st.sum >> 16)) - 128 * 16;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int omx = __shfl_xor(mx, off, 64);
+        mx = mx > omx ? mx : omx;
+        sm += __shfl_xor(sm, off, 64);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { redi[wave] = mx; redi[8 + wave] = sm; }
+    __syncthreads();
+    const int a = redi[0] > redi[1] ? redi[0] : redi[1], b = redi[2] > redi[3] ? redi[2] : redi[3];
+    const int rmax = a > b ? a : b, rsum = (redi[8] + redi[9]) + (redi[10] + redi[11]);
+    (void)mn;
+    int cw = 127 - rmax;
+    cw = cw < CW ? cw : CW;
+    if (threadIdx.x == 0) *(v2i *)(col_off + 2 * row) = (v2i){cw, rsum};
+    const uint32_t c4 = (uint32_t)(cw & 0xFF) * 0x01010101u;
+    for (int i = threadIdx.x; i < nvec; i += 256) {
+        const uint4 v = src[i];
+        dst[i] = make_uint4(pk_add_i8(v.x, c4), pk_add_i8(v.y, c4), pk_add_i8(v.z, c4), pk_add_i8(v.w, c4));
+    }
+}
+
+// development overrides of the two offset constants (read once): ASQ_OFF_CX (default 3, 0 = no activation offset), ASQ_OFF_CW (default 64, 0 = no weight offset)
+static int offset_const(const char *name, int dflt, int hi)
+{
+    const char *e = getenv(name);
+    if (!e || !e[0]) return dflt;
+    const int v = atoi(e);
+    return v < 0 ? 0 : (v > hi ? hi : v);
+}
+static int offset_cx() { static const int v = offset_const("ASQ_OFF_CX", 3, 64); return v; }
+static int offset_cw() { static const int v = offset_const("ASQ_OFF_CW", 64, 127); return v; }
+
 
 // ---------------------------------------------------------------------------------
 // N1: RMSNorm (or LayerNorm) with the SmoothQuant scale folded into its weight, emitting int8
@@ -621,6 +823,39 @@ extern "C" int asq_quantize_act(const void *x, int x_dtype, int mode, float quan
     case ASQ_F16: return quantize_dt<ASQ_F16>(x, mode, quant_scale, xq, s_row, M, K, s);
     default: return quantize_dt<ASQ_BF16>(x, mode, quant_scale, xq, s_row, M, K, s);
     }
+}
+
+extern "C" int asq_quantize_act_off(const void *x, int x_dtype, int mode, float quant_scale, int8_t *xq, float *s_row, int32_t *row_off,
+                                    int64_t M, int64_t K, void *stream)
+{
+    ASQ_REQUIRE(M >= 0 && K > 0 && M < (1ll << 31), ASQ_ERR_DIM, "asq_quantize_act_off: bad dims M=%lld K=%lld", (long long)M, (long long)K);
+    ASQ_REQUIRE(x_dtype == ASQ_F32 || x_dtype == ASQ_F16 || x_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_quantize_act_off: bad x_dtype %d", x_dtype);
+    ASQ_REQUIRE(mode == ASQ_ACT_ROUND || mode == ASQ_ACT_DIV || mode == ASQ_ACT_PER_TOKEN, ASQ_ERR_DTYPE, "asq_quantize_act_off: bad mode %d", mode);
+    if (M == 0) return ASQ_OK;
+    ASQ_REQUIRE(x != nullptr && xq != nullptr && row_off != nullptr, ASQ_ERR_NULL, "asq_quantize_act_off: NULL x / xq / row_off");
+    ASQ_REQUIRE(mode != ASQ_ACT_PER_TOKEN || s_row != nullptr, ASQ_ERR_NULL, "asq_quantize_act_off: per-token needs s_row");
+    const int vec = x_dtype == ASQ_F32 ? 4 : 8;
+    ASQ_REQUIRE(K % vec == 0 && K / vec <= 256 * 20 && K <= 65536, ASQ_ERR_DIM, "asq_quantize_act_off: K must be a multiple of %d and <= %d", vec, 256 * 20 * vec);
+    ASQ_REQUIRE((((uintptr_t)x & 15) == 0) && (((uintptr_t)xq & (vec - 1)) == 0) && (((uintptr_t)row_off & 7) == 0) && (((uintptr_t)s_row & 3) == 0), ASQ_ERR_ALIGN,
+                "asq_quantize_act_off: x must be 16-B aligned, row_off 8-B aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int C = offset_cx();
+    switch (x_dtype) {
+    case ASQ_F32: return quantize_off_dt<ASQ_F32>(x, mode, quant_scale, xq, s_row, row_off, M, K, C, s);
+    case ASQ_F16: return quantize_off_dt<ASQ_F16>(x, mode, quant_scale, xq, s_row, row_off, M, K, C, s);
+    default: return quantize_off_dt<ASQ_BF16>(x, mode, quant_scale, xq, s_row, row_off, M, K, C, s);
+    }
+}
+
+extern "C" int asq_weight_offset_image(const int8_t *w, int64_t N, int64_t K, int8_t *w_off, int32_t *col_off, void *stream)
+{
+    ASQ_REQUIRE(N >= 0 && K > 0 && N < (1ll << 31) && K <= 65536, ASQ_ERR_DIM, "asq_weight_offset_image: bad dims N=%lld K=%lld (K <= 65536)", (long long)N, (long long)K);
+    if (N == 0) return ASQ_OK;
+    ASQ_REQUIRE(w != nullptr && w_off != nullptr && col_off != nullptr, ASQ_ERR_NULL, "asq_weight_offset_image: NULL pointer");
+    ASQ_REQUIRE(K % 16 == 0 && ((((uintptr_t)w | (uintptr_t)w_off) & 15) == 0) && (((uintptr_t)col_off & 15) == 0) && N % 4 == 0, ASQ_ERR_ALIGN,
+                "asq_weight_offset_image: K %% 16 == 0, N %% 4 == 0 and 16-B aligned pointers required");
+    hipLaunchKernelGGL(weight_offset_image, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, w, w_off, col_off, N, (int)K, offset_cw());
+    return asq_after_launch((hipStream_t)stream, "asq_weight_offset_image");
 }
 
 extern "C" int asq_norm_quantize(const void *x, int x_dtype, const void *weight, const void *bias, float eps, int per_token, int8_t *xq,

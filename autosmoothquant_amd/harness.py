@@ -73,7 +73,7 @@ def shared_input(x, *mods):
     sigs = {m.input_signature() if hasattr(m, "input_signature") else None for m in mods}
     if len(sigs) != 1 or None in sigs:
         return x
-    return mods[0].quantize_input(x)
+    return mods[0].quantize_input(x, consumers=mods)
 
 
 # ---- independent linears of one input on side streams (measured, OFF by default) ----------------------------------------------------------

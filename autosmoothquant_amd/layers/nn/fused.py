@@ -13,11 +13,19 @@ from ... import ops
 
 class QuantizedActivation:
     """int8 activation [.., K] (+ per-token scales) produced by a fused norm; `out_dtype` is the
-    floating dtype the consuming linear should emit (the dtype of the norm's input)."""
-    __slots__ = ("xq", "s_row", "out_dtype", "lead")
+    floating dtype the consuming linear should emit (the dtype of the norm's input).
+    row_off (int32 [M,2] or None): when set, `xq` is the OFFSET image xq + cx[m] and row_off[m] = {cx[m], sum_k image[m,k]} (include/asq_hip.h,
+    "offset operand images"); the consuming linear multiplies it with its weight's image and gets the plain product bit for bit."""
+    __slots__ = ("xq", "s_row", "out_dtype", "lead", "row_off")
 
-    def __init__(self, xq, s_row, out_dtype, lead):
-        self.xq, self.s_row, self.out_dtype, self.lead = xq, s_row, out_dtype, lead
+    def __init__(self, xq, s_row, out_dtype, lead, row_off=None):
+        self.xq, self.s_row, self.out_dtype, self.lead, self.row_off = xq, s_row, out_dtype, lead, row_off
+
+    def plain_xq(self):
+        """the int8 activation without its row offsets (a torch pass; only consumers that cannot take the image need it)"""
+        if self.row_off is None:
+            return self.xq
+        return (self.xq.to(torch.int16) - self.row_off[:, :1].to(torch.int16)).to(torch.int8)
 
     @property
     def shape(self):

@@ -123,12 +123,48 @@ class _W8A8Base(torch.nn.Module):
         mode, qs = self._input_mode()
         return (mode, float(qs))
 
-    def quantize_input(self, x):
+    def quantize_input(self, x, consumers=None):
         """The module's own prologue as a separate, explicit step (one asq_quantize_act launch): the QuantizedActivation it returns is accepted by
-        this module and by every module with the same `input_signature()`.  Bit-identical to what forward(x) computes internally."""
+        this module and by every module with the same `input_signature()`.  Bit-identical to what forward(x) computes internally.
+        consumers: the modules that will read the result (default: this one).  When every one of them runs this many rows on offset operand
+        images (`offset_image`), the activation is emitted as its offset image (asq_quantize_act_off) -- same product, less matrix-core energy."""
         mode, qs = self._input_mode()
-        xq, s_row = ops.quantize_act(self._flatten(x), mode, qs)
+        x2 = self._flatten(x)
+        mods = (self,) if consumers is None else tuple(consumers)
+        if x2.is_cuda and all(isinstance(m, _W8A8Base) and m.offset_image(x2.shape[0], x.dtype) is not None for m in mods):
+            xq, s_row, row_off = ops.quantize_act_off(x2, mode, qs)
+            return QuantizedActivation(xq, s_row, x.dtype, x.shape[:-1], row_off)
+        xq, s_row = ops.quantize_act(x2, mode, qs)
         return QuantizedActivation(xq, s_row, x.dtype, x.shape[:-1])
+
+    # ---- offset operand image of the weight (include/asq_hip.h): built on the first forward whose shape the C-ABI runs on it, kept until the weight changes
+    offsets = True   # class / instance switch (ASQ_OFFSETS=0 in the environment switches the C-ABI side off for the whole process)
+
+    def offset_image(self, M, dtype):
+        """(w_off int8 [N,K], col_off int32 [N,2]) when a forward of M rows with `dtype` outputs runs on offset operand images, else None.
+        The image is a second int8 copy of the weight (only modules that see prefill-sized inputs ever build one); it is keyed on the weight's
+        storage and version counter, so load_state_dict / in-place updates / .to() rebuild it."""
+        w = self._buffers["weight"]
+        if not (self.offsets and w.is_cuda):
+            return None
+        ok = self.__dict__.setdefault("_offset_ok", {})   # (M, dtype) -> bool: one C-ABI query per shape, not per call
+        sup = ok.get((M, dtype))
+        if sup is None:
+            if len(ok) > 64:
+                ok.clear()
+            sup = ok[(M, dtype)] = ops.offsets_supported(int(M), self.out_features, self.in_features, dtype)
+        if not sup:
+            return None
+        try:
+            ver = w._version
+        except RuntimeError:   # an inference tensor has no version counter
+            ver = -1
+        key = (w.data_ptr(), ver, w.device)
+        hit = self.__dict__.get("_offset_cache")
+        if hit is None or hit[0] != key:
+            hit = (key, ops.weight_offset_image(w))
+            self.__dict__["_offset_cache"] = hit
+        return hit[1]
 
     def forward_q(self, x, consumer, act=None):
         """This linear, an optional activation (act = "relu": OPT's fc1 -> ReLU -> fc2, reference models/opt.py:127-128) and the
@@ -141,7 +177,7 @@ class _W8A8Base(torch.nn.Module):
             per_token = self.act_quant == "per-token"
             if per_token != (x.s_row is not None):
                 raise ValueError("QuantizedActivation does not match this module's act_quant")
-            xq, s_row, lead, dt = x.xq, x.s_row, x.lead, x.out_dtype
+            xq, s_row, lead, dt = x.plain_xq(), x.s_row, x.lead, x.out_dtype
         else:
             lead, dt = x.shape[:-1], x.dtype
             mode, qs = self._input_mode()
@@ -160,7 +196,15 @@ def _prequantized_forward(mod, qa, s_scalar, s_col):
         raise ValueError(f"{type(mod).__name__}(act_quant={mod.act_quant!r}) got a {'per-token' if qa.s_row is not None else 'per-tensor'} QuantizedActivation")
     if qa.xq.shape[-1] != mod.in_features:
         raise ValueError(f"expected last dim {mod.in_features}, got {tuple(qa.shape)}")
-    out = ops.linear_w8a8(qa.xq, mod.weight, qa.out_dtype, s_scalar, qa.s_row, s_col, mod._bias_on(qa.xq.device))
+    if qa.row_off is not None:
+        image = mod.offset_image(qa.xq.shape[0], qa.out_dtype)
+        if image is not None:
+            out = ops.linear_w8a8_off(qa.xq, image[0], qa.row_off, image[1], qa.out_dtype, s_scalar, qa.s_row, s_col, mod._bias_on(qa.xq.device))
+            return out.view(*qa.lead, mod.out_features)
+        xq = qa.plain_xq()   # (a consumer the producer was not told about: correct, one extra pass)
+    else:
+        xq = qa.xq
+    out = ops.linear_w8a8(xq, mod.weight, qa.out_dtype, s_scalar, qa.s_row, s_col, mod._bias_on(qa.xq.device))
     return out.view(*qa.lead, mod.out_features)
 
 
@@ -169,7 +213,8 @@ def _module_forward(mod, x, mode, qs, s_scalar, s_col):
     (layers/nn/linear.py:88-96).  Callers that KNOW several modules read one tensor (q/k/v, gate/up) quantise it once,
     explicitly: `qa = mod.quantize_input(x)` and pass `qa` to each (harness.shared_input)."""
     lead = x.shape[:-1]
-    out = ops.linear_w8a8_forward(mod._flatten(x), mod.weight, mode, qs, s_scalar, s_col, mod._bias_on(x.device))
+    x2 = mod._flatten(x)
+    out = ops.linear_w8a8_forward(x2, mod.weight, mode, qs, s_scalar, s_col, mod._bias_on(x.device), mod.offset_image(x2.shape[0], x.dtype))
     return out.view(*lead, mod.out_features)
 
 

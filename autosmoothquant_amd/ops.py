@@ -190,6 +190,69 @@ def quantize_act(x, mode, quant_scale=1.0):
     return xq, s_row
 
 
+def offsets_supported(M, N, K, out_dtype):
+    """True when the C-ABI would run a [M,K] x [N,K]^T linear with `out_dtype` outputs on offset operand images (include/asq_hip.h)."""
+    return out_dtype in (torch.float16, torch.bfloat16) and bool(L.lib().asq_offsets_supported(M, N, K, _DT[out_dtype]))
+
+
+def weight_offset_image(w):
+    """w int8 [N,K] -> (w_off int8 [N,K], col_off int32 [N,2] = {cw[n], sum_k w[n,k]}): the weight's offset operand image (asq_weight_offset_image), built once per weight."""
+    _dev(w, "weight")
+    if w.dtype != torch.int8 or w.dim() != 2:
+        raise ValueError("weight must be int8 [N,K]")
+    N, K = w.shape
+    w_off = torch.empty_like(w)
+    col_off = torch.empty((N, 2), dtype=torch.int32, device=w.device)
+    with _on(w.device):
+        L.check(L.lib().asq_weight_offset_image(w.data_ptr(), N, K, w_off.data_ptr(), col_off.data_ptr(), _stream(w)), "asq_weight_offset_image")
+    return w_off, col_off
+
+
+def quantize_act_off(x, mode, quant_scale=1.0):
+    """quantize_act emitting the offset image: (xq' int8 [M,K], s_row f32 [M] or None, row_off int32 [M,2] = {cx[m], sum_k xq'[m,k]});
+    xq' - cx[:, None] is exactly quantize_act's xq."""
+    _dev(x, "x")
+    if x.dtype not in _DT or x.dim() != 2:
+        raise ValueError("x must be a 2-D float32/float16/bfloat16 tensor")
+    M, K = x.shape
+    xq = torch.empty((M, K), dtype=torch.int8, device=x.device)
+    s_row = torch.empty((M,), dtype=torch.float32, device=x.device) if mode == "per-token" else None
+    row_off = torch.empty((M, 2), dtype=torch.int32, device=x.device)
+    with _on(x.device):
+        L.check(L.lib().asq_quantize_act_off(x.data_ptr(), _DT[x.dtype], _ACT[mode], float(quant_scale), xq.data_ptr(), _ptr(s_row), row_off.data_ptr(),
+                                             M, K, _stream(x)), "asq_quantize_act_off")
+    return xq, s_row, row_off
+
+
+def linear_w8a8_off(xq_off, w_off, row_off, col_off, out_dtype, s_scalar=1.0, s_row=None, s_col=None, bias=None, order="scale_first", out=None):
+    """linear_w8a8 on offset operand images: bit-identical to linear_w8a8 on the plain operands (asq_linear_w8a8_off)."""
+    _dev(xq_off, "xq"), _dev(w_off, "weight"), _dev(row_off, "row_off"), _dev(col_off, "col_off")
+    if xq_off.dtype != torch.int8 or w_off.dtype != torch.int8 or xq_off.dim() != 2 or w_off.dim() != 2 or xq_off.shape[1] != w_off.shape[1]:
+        raise ValueError("xq [M,K] and weight [N,K] must be int8 with equal K")
+    M, K = xq_off.shape
+    N = w_off.shape[0]
+    if row_off.dtype != torch.int32 or row_off.numel() != 2 * M or col_off.dtype != torch.int32 or col_off.numel() != 2 * N:
+        raise ValueError("row_off must be int32 [M,2] and col_off int32 [N,2]")
+    for name, t, n in (("s_row", s_row, M), ("s_col", s_col, N), ("bias", bias, N)):
+        if t is not None:
+            _dev(t, name)
+            if t.dtype != torch.float32 or t.numel() != n:
+                raise ValueError(f"{name} must be float32 with {n} elements")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=xq_off.device)
+    else:
+        _dev(out, "out")
+        if out.dtype != out_dtype or tuple(out.shape) != (M, N):
+            raise ValueError("out has wrong dtype/shape")
+        _bump_version(out)
+    dev = _same_device(xq_off, w_off, out, row_off, col_off, s_row, s_col, bias)
+    with _on(dev):
+        L.check(L.lib().asq_linear_w8a8_off(xq_off.data_ptr(), w_off.data_ptr(), out.data_ptr(), _DT[out_dtype], M, N, K, float(s_scalar),
+                                            _ptr(s_row), _ptr(s_col), _ptr(bias), L.ASQ_EPI_SCALE_FIRST if order == "scale_first" else L.ASQ_EPI_ACC_FIRST,
+                                            row_off.data_ptr(), col_off.data_ptr(), _stream(xq_off)), "asq_linear_w8a8_off")
+    return out
+
+
 def _bump_version(t):
     """A raw C-ABI write into a caller-provided tensor is made visible to torch's version counter (autograd's saved-tensor checks and
     any caller that keys on ._version).  Inference tensors have no counter: nothing to do."""
@@ -342,9 +405,10 @@ def linear_w8a8_grouped(xq, w, group_offsets, s_group, out_dtype, s_row=None, bi
     return out
 
 
-def linear_w8a8_forward(x2d, w, act_mode, quant_scale, s_scalar, s_col=None, bias=None):
+def linear_w8a8_forward(x2d, w, act_mode, quant_scale, s_scalar, s_col=None, bias=None, image=None):
     """Whole module forward on a 2-D activation: quantise -> GEMM + epilogue, one stream,
-    no int32 round trip.  Returns out [M,N] in x's dtype."""
+    no int32 round trip.  Returns out [M,N] in x's dtype.  image = (w_off, col_off) of this weight (weight_offset_image) or None: with it the C-ABI
+    runs the shapes it gives to the 256 x 256 kernel on offset operand images (same bits, less energy)."""
     _dev(x2d, "x"), _dev(w, "weight")
     if x2d.dtype not in _DT:
         raise ValueError(f"unsupported activation dtype {x2d.dtype}")
@@ -365,9 +429,14 @@ def linear_w8a8_forward(x2d, w, act_mode, quant_scale, s_scalar, s_col=None, bia
     stream = _stream(x2d)
     ws, nbytes = _forward_ws(lib, M, N, K, dev, stream)
     with _on(dev):
-        L.check(lib.asq_linear_w8a8_forward(x2d.data_ptr(), _DT[x2d.dtype], w.data_ptr(), out.data_ptr(), M, N, K,
-                                            _ACT[act_mode], float(quant_scale), float(s_scalar), _ptr(s_col), _ptr(bias),
-                                            ws.data_ptr(), nbytes, stream), "asq_linear_w8a8_forward")
+        if image is not None:
+            L.check(lib.asq_linear_w8a8_forward_off(x2d.data_ptr(), _DT[x2d.dtype], w.data_ptr(), image[0].data_ptr(), image[1].data_ptr(), out.data_ptr(), M, N, K,
+                                                    _ACT[act_mode], float(quant_scale), float(s_scalar), _ptr(s_col), _ptr(bias),
+                                                    ws.data_ptr(), nbytes, stream), "asq_linear_w8a8_forward_off")
+        else:
+            L.check(lib.asq_linear_w8a8_forward(x2d.data_ptr(), _DT[x2d.dtype], w.data_ptr(), out.data_ptr(), M, N, K,
+                                                _ACT[act_mode], float(quant_scale), float(s_scalar), _ptr(s_col), _ptr(bias),
+                                                ws.data_ptr(), nbytes, stream), "asq_linear_w8a8_forward")
     return out
 
 

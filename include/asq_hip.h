@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define ASQ_VERSION 100 /* 0.1.0 */
+#define ASQ_VERSION 110 /* 0.1.1: + offset operand images (asq_*_off); workspace sizes include the 8 KiB header (asq_workspace_init is mandatory for a
+                           * workspace handed to a GEMM entry point); asq_silu_mul_quantize's `per_token` is a bit field (bit 0 per-token, ASQ_SILU_FAST) */
 
 /* element types of floating tensors crossing the boundary */
 #define ASQ_F32 0
@@ -200,6 +201,43 @@ int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t *w, void *o
                             int act_mode, float quant_scale,
                             float s_scalar, const float *s_col, const float *bias,
                             void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- OFFSET OPERAND IMAGES: the same W8A8 linear, bit for bit, on operands that cost the matrix cores less energy.
+ * On MI355X the 256 x 256 INT8 GEMM runs against the socket power limit, so its time is its energy, and most of the matrix cores' data-dependent
+ * energy is two's-complement sign extension: weights and SmoothQuant-style activations are centred on 0 (profiles/r4_operand_offsets.md).
+ * The INT8 MFMA is signed x signed only, but an offset per row is exact and never clamps when it is chosen from the row's own extremes:
+ *     x'[m,k] = xq[m,k] + cx[m]      cx[m] = +3 if max_k xq[m,k] <= 124, else -3 if min_k xq[m,k] >= -125, else 0
+ *     w'[n,k] = w[n,k]  + cw[n]      cw[n] = min(64, 127 - max_k w[n,k])
+ *     sum_k xq[m,k] w[n,k] = sum_k x'[m,k] w'[n,k]  -  cx[m] * sum_k w[n,k]  -  cw[n] * sum_k x'[m,k]
+ * The kernel multiplies the primed matrices and starts its int32 accumulators at the two correction terms (two's-complement wrap-around, also
+ * inside v_mfma_i32_*): K loop and epilogue are the plain ones, the result equals asq_linear_w8a8 on (xq, w) in every bit.  There is no reference
+ * counterpart (cuBLASLt sees the raw operands, cublasINT8MMWrapper.cc:224-354); what it replaces is the operand handling in front of
+ * asq_linear_w8a8.  4096^3, fp16 out, bench operands: 48.2 -> 44.0 us (56.7 -> 62.1 % of the INT8 peak).
+ *
+ *   asq_weight_offset_image   once per weight: w [N,K] -> w_off [N,K] (int8) and col_off int32 [N][2] = {cw[n], sum_k w[n,k]}.
+ *                             K % 16 == 0, K <= 65536, N % 4 == 0, 16-B aligned pointers.
+ *   asq_quantize_act_off      asq_quantize_act (same modes, same arithmetic) emitting x' and row_off int32 [M][2] = {cx[m], sum_k x'[m,k]}.
+ *                             K % 8 == 0 (f32: 4), K <= 40960 (f32: 20480), x 16-B aligned, row_off 8-B aligned.
+ *   asq_linear_w8a8_off       asq_linear_w8a8 on (x', w') + the two vectors; out_dtype ASQ_F16 / ASQ_BF16, K % 128 == 0, 128 <= K <= 65536,
+ *                             N % 4 == 0, 16-B aligned operands; always the 256 x 256 kernel, no workspace.
+ *   asq_offsets_supported     1 when the dispatcher itself would run (M, N, K) with 2-byte outputs on that kernel (>= 144 tiles of 256 x 256, no
+ *                             column remainder launch) and the limits above hold; ASQ_OFFSETS=0 in the environment makes it return 0.
+ *   asq_linear_w8a8_forward_off  asq_linear_w8a8_forward with the weight's image: uses the offset path when asq_offsets_supported() and the
+ *                             workspace has asq_linear_w8a8_workspace_bytes(); otherwise it IS asq_linear_w8a8_forward (w_off / col_off may be NULL).
+ * Development overrides (read once): ASQ_OFF_CX (default 3), ASQ_OFF_CW (default 64). */
+int asq_weight_offset_image(const int8_t *w, int64_t N, int64_t K, int8_t *w_off, int32_t *col_off, void *stream);
+int asq_quantize_act_off(const void *x, int x_dtype, int mode, float quant_scale,
+                         int8_t *xq_off, float *s_row, int32_t *row_off, int64_t M, int64_t K, void *stream);
+int asq_linear_w8a8_off(const int8_t *xq_off, const int8_t *w_off, void *out, int out_dtype,
+                        int64_t M, int64_t N, int64_t K,
+                        float s_scalar, const float *s_row, const float *s_col, const float *bias, int epi_order,
+                        const int32_t *row_off, const int32_t *col_off, void *stream);
+int asq_offsets_supported(int64_t M, int64_t N, int64_t K, int out_dtype);
+int asq_linear_w8a8_forward_off(const void *x, int x_dtype, const int8_t *w, const int8_t *w_off, const int32_t *col_off, void *out,
+                                int64_t M, int64_t N, int64_t K,
+                                int act_mode, float quant_scale,
+                                float s_scalar, const float *s_col, const float *bias,
+                                void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- FP8 (OCP e4m3fn) linear path: layers/functional/quantization.py:144-211 (quantisers),
  * layers/nn/linear.py:336-369 easy_fp8_gemm, :373-452 FP8LinearDynamic, :503-580 FP8LinearStatic.

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(h, n), f"libasq_hip.so lacks {n}"
         assert n in _lib.SIGNATURES, f"_lib.SIGNATURES lacks {n}"
     assert sorted(_lib.SIGNATURES) == names
-    assert h.asq_version() == 100
+    assert h.asq_version() == _lib.ASQ_VERSION == 110
 
 
 def test_argument_errors_without_gpu():
@@ -37,7 +37,7 @@ def test_argument_errors_without_gpu():
     assert h.asq_quantize_act(None, 7, 0, 1.0, None, None, 1, 1, None) == -3  # ASQ_ERR_DTYPE
     assert h.asq_linear_w8a8_forward(None, 1, None, None, 4, 4, 4, 0, 1.0, 1.0, None, None, None, 0, None) == -5
     assert h.asq_gemm_i8_i32(None, None, None, 0, 4, 4, None, 0, None) == 0            # empty problem is a no-op
-    assert h.asq_linear_w8a8_workspace_bytes(3, 7, 5) == h.asq_workspace_header_bytes() + 256 + 256   # the header is reserved whatever the shape (offset 0 of a shared buffer)
+    assert h.asq_linear_w8a8_workspace_bytes(3, 7, 5) == h.asq_workspace_header_bytes() + 256 + 256 + 256   # the header is reserved whatever the shape (offset 0 of a shared buffer)
     assert h.asq_gemm_workspace_bytes(4096, 4096, 4096) == 0            # 256 tiles fill the chip: no split-K
     hdr = h.asq_workspace_header_bytes()                                # every non-empty workspace starts with the header asq_workspace_init() writes
     assert hdr == 8192

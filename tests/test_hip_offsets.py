@@ -1,0 +1,178 @@
+"""GPU (-m gpu): the offset operand images (include/asq_hip.h) through the C-ABI.
+
+The claim under test is exactness: the images follow the two stated rules (oracle/offsets.py), and everything computed from them -- int32
+accumulators, fp outputs, module forwards -- equals the plain path (itself pinned to the reference's arithmetic by test_hip_parity.py) in every bit.
+Tolerance: none."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import offsets as OFF, w8a8 as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TDT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+def _edge_rows_i8(a, rng):
+    """rows that exercise every branch of the offset rules"""
+    n = a.shape[0]
+    if n > 0: a[0] = 127
+    if n > 1: a[1] = -128
+    if n > 2: a[2] = 0
+    if n > 3: a[3] = rng.integers(-3, 4, a.shape[1]); a[3, 0] = 127; a[3, 1] = -128      # both extremes: no offset fits
+    if n > 4: a[4] = rng.integers(-3, 4, a.shape[1]); a[4, -1] = 126                      # positive side taken: negative offset
+    if n > 5: a[5] = rng.integers(-3, 4, a.shape[1]); a[5, 0] = -127
+    return a
+
+
+def test_weight_image_equals_oracle():
+    from autosmoothquant_amd import ops
+    rng = np.random.default_rng(0)
+    for (N, K) in ((4, 16), (64, 128), (260, 4096), (1024, 11008), (8, 65536)):
+        w = np.clip(np.rint(rng.standard_normal((N, K)) * 22), -128, 127).astype(np.int8)
+        _edge_rows_i8(w, rng)
+        w_off, col_off = ops.weight_offset_image(torch.from_numpy(w).to(DEV))
+        rw, rc = OFF.weight_image(w)
+        assert np.array_equal(w_off.cpu().numpy(), rw), (N, K)
+        assert np.array_equal(col_off.cpu().numpy(), rc), (N, K)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("mode", ["per-tensor-round", "per-tensor-div", "per-token"])
+def test_quantize_act_off_is_quantize_act_plus_row_offsets(dt, mode):
+    from autosmoothquant_amd import ops
+    rng = np.random.default_rng(7)
+    for (M, K) in ((1, 128), (9, 1024), (67, 4096), (5, 11008), (3, 20480), (2, 40960)):
+        if dt == "f32" and K > 20480:
+            continue
+        x = rng.standard_normal((M, K)).astype(np.float32) * (1.4 if mode != "per-tensor-div" else 0.05)
+        x[:, rng.random(K) < 0.01] *= 20.0
+        if M > 2:
+            x[1, 3] = 500.0; x[2, 5] = -500.0        # rows that clamp / carry the row maximum on either side
+        if M > 4:
+            x[4] = 0.0
+        xt = torch.from_numpy(O.round_to(x, dt)).to(DEV).to(TDT[dt])
+        qs = 0.0371 if mode == "per-tensor-div" else 1.0
+        xq, s_row = ops.quantize_act(xt, mode, qs)
+        xo, s_row2, row_off = ops.quantize_act_off(xt, mode, qs)
+        rx, rr = OFF.act_image(xq.cpu().numpy())
+        assert np.array_equal(xo.cpu().numpy(), rx), (M, K)
+        assert np.array_equal(row_off.cpu().numpy(), rr), (M, K)
+        if mode == "per-token":
+            assert torch.equal(s_row, s_row2)
+
+
+def _operands(rng, M, N, K, kind):
+    if kind == "bench":
+        x = np.clip(np.rint(rng.standard_normal((M, K)) * 1.41), -128, 127)
+        oc = rng.random(K) < 0.01
+        x[:, oc] = np.clip(np.rint(rng.standard_normal((M, int(oc.sum()))) * 28), -128, 127)
+        w = np.clip(np.rint(rng.standard_normal((N, K)) * 22), -128, 127)
+    elif kind == "uniform":
+        x = rng.integers(-128, 128, (M, K))
+        w = rng.integers(-128, 128, (N, K))
+    else:   # extremes: every accumulator at the int32 edge of what int8 x int8 can reach
+        x = np.full((M, K), -128)
+        w = np.full((N, K), -128)
+        w[1::2] = 127
+        x[1::3] = 127
+    return _edge_rows_i8(x.astype(np.int8), rng), _edge_rows_i8(w.astype(np.int8), rng)
+
+
+@pytest.mark.parametrize("kind", ["bench", "uniform", "extremes"])
+def test_linear_off_equals_plain_linear_bit_for_bit(kind):
+    from autosmoothquant_amd import ops
+    rng = np.random.default_rng(11)
+    shapes = [(256, 256, 128), (300, 260, 256), (1, 4, 128), (513, 1028, 1024), (2304, 4096, 256), (700, 516, 4096)]
+    if kind == "extremes":
+        shapes.append((256, 256, 65536))   # |acc| = 2^30: start values and sums wrap
+    for si, (M, N, K) in enumerate(shapes):
+        x, w = _operands(rng, M, N, K, kind)
+        xt, wt = torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV)
+        xo, ro = OFF.act_image(x)
+        w_off, col_off = ops.weight_offset_image(wt)
+        s_row = torch.from_numpy(rng.random(M).astype(np.float32) * 0.01 + 1e-3).to(DEV)
+        s_col = torch.from_numpy(rng.random(N).astype(np.float32) * 1e-3 + 1e-4).to(DEV)
+        bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(DEV)
+        for dt in (torch.float16, torch.bfloat16):
+            for (sr, sc, b) in ((None, None, None), (s_row, None, None), (None, s_col, bias), (s_row, s_col, bias)):
+                for order in ("scale_first", "acc_first"):
+                    ref = ops.linear_w8a8(xt, wt, dt, 1.25e-4, sr, sc, b, order)
+                    got = ops.linear_w8a8_off(torch.from_numpy(xo).to(DEV), w_off, torch.from_numpy(ro).to(DEV), col_off, dt, 1.25e-4, sr, sc, b, order)
+                    assert torch.equal(ref.view(torch.int16), got.view(torch.int16)), (kind, M, N, K, dt, order)
+        # and the int32 accumulators themselves, through a unit-scale fp path that is exact for small sums: compare with the oracle's integer product
+        if K <= 256 and kind != "extremes":
+            acc = OFF.product_from_images(xo, ro, *OFF.weight_image(w))
+            assert np.array_equal(acc, O.igemm(x, w))
+
+
+def test_offsets_argument_errors():
+    from autosmoothquant_amd import _lib
+    h = _lib.lib()
+    assert h.asq_linear_w8a8_off(256, 256, 256, 0, 4, 4, 128, 1.0, None, None, None, 0, 256, 256, None) == -3      # fp32 outputs: not on this kernel
+    assert h.asq_linear_w8a8_off(256, 256, 256, 1, 4, 4, 128, 1.0, None, None, None, 0, None, 256, None) == -1     # NULL row_off
+    assert h.asq_linear_w8a8_off(256, 256, 256, 1, 4, 6, 128, 1.0, None, None, None, 0, 256, 256, None) == -2      # N % 4
+    assert h.asq_linear_w8a8_off(256, 256, 256, 1, 4, 4, 131072, 1.0, None, None, None, 0, 256, 256, None) == -2   # K > 65536
+    assert h.asq_offsets_supported(4096, 4096, 4096, 1) == 1 and h.asq_offsets_supported(4096, 4096, 4096, 0) == 0
+    assert h.asq_offsets_supported(64, 4096, 4096, 1) == 0 and h.asq_offsets_supported(4096, 4096, 131072, 1) == 0
+
+
+@pytest.mark.parametrize("cls_name,aq", [("W8A8BFP32OFP32Linear", "per-tensor"), ("W8A8BFP32OFP32Linear", "per-token"),
+                                         ("W8A8BFP32OFP32LinearWithQuantScale", "per-tensor"), ("W8A8BFP32OFP32LinearWithQuantScale", "per-token")])
+def test_module_forward_with_and_without_images_is_identical(cls_name, aq):
+    """4096 rows on a 4096 x 4096 weight: the shape the offset path exists for.  The module with images (default) == the same module with
+    `offsets = False` == the oracle on sampled rows."""
+    import autosmoothquant_amd.layers.nn.linear as LN
+    cls = getattr(LN, cls_name)
+    g = torch.Generator().manual_seed(5)
+    K = N = 4096
+    M = 4096
+    lin = torch.nn.Linear(K, N, bias=True)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(N, K, generator=g) * 0.02)
+        lin.bias.copy_(torch.randn(N, generator=g) * 0.1)
+    x = torch.randn(M, K, generator=g)
+    x[:, torch.rand(K, generator=g) < 0.01] *= 20.0
+    input_scale = float(x.abs().max()) / 127.0
+    m = cls.from_float(lin, input_scale, act_quant=aq).to(DEV)
+    xin = (x / input_scale if (aq == "per-tensor" and cls_name == "W8A8BFP32OFP32Linear") else x).half().to(DEV)
+    assert m.offset_image(M, torch.float16) is not None
+    y_img = m(xin)
+    qa = m.quantize_input(xin)
+    assert qa.row_off is not None
+    y_shared = m(qa)
+    m.offsets = False
+    assert m.offset_image(M, torch.float16) is None
+    y_plain = m(xin)
+    assert m.quantize_input(xin).row_off is None
+    assert torch.equal(y_img, y_plain) and torch.equal(y_shared, y_plain)
+    rows = [0, 1, 777, 4095]
+    w = m.weight.cpu().numpy()
+    xs = xin[rows].float().cpu().numpy()
+    ds = float(m.dequant_scale)
+    if cls_name == "W8A8BFP32OFP32Linear":
+        ref = O.linear_forward(xs, "f16", w, ds, m.bias.cpu().numpy(), aq)
+    else:
+        ref = O.linear_with_quant_scale_forward(xs, "f16", w, ds, float(m.quant_scale) if aq == "per-tensor" else None, m.bias.cpu().numpy(), aq)
+    assert np.array_equal(y_img[rows].float().cpu().numpy(), ref)
+
+
+def test_image_follows_the_weight():
+    """the cached image is keyed on the weight's storage and version: an in-place update or load_state_dict rebuilds it"""
+    from autosmoothquant_amd.layers.nn.linear import W8A8BFP32OFP32Linear
+    g = torch.Generator().manual_seed(9)
+    m = W8A8BFP32OFP32Linear(4096, 4096, False, "per-tensor")
+    m.weight = torch.randint(-100, 100, (4096, 4096), generator=g, dtype=torch.int8)
+    m.dequant_scale = torch.tensor(1e-4)
+    m = m.to(DEV)
+    x = torch.randint(-3, 4, (2304, 4096), generator=g).half().to(DEV)
+    y0 = m(x)
+    img0 = m.offset_image(2304, torch.float16)
+    assert img0 is m.offset_image(2304, torch.float16)
+    w2 = torch.randint(-100, 100, (4096, 4096), generator=g, dtype=torch.int8)
+    m.load_state_dict({"weight": w2, "dequant_scale": torch.tensor(1e-4)})
+    y1 = m(x)
+    assert m.offset_image(2304, torch.float16) is not img0
+    m.offsets = False
+    assert torch.equal(y1, m(x)) and not torch.equal(y0, y1)

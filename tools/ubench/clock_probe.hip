@@ -342,14 +342,14 @@ template <class Epi, int PB = 1> static void run_gemm_p4(const char *name, const
 }
 
 // the default 256 x 256 kernel (gemm_i8_p16: p8's schedule on v_mfma_i32_16x16x64_i8) with the same stamps
-template <class Epi> static void run_gemm_p16(const char *name, const int8_t *x, const int8_t *w, Epi epi, int64_t M, int64_t N, int64_t K, double seconds, Sampler &smp)
+template <class Epi> static void run_gemm_p16(const char *name, const int8_t *x, const int8_t *w, Epi epi, int64_t M, int64_t N, int64_t K, double seconds, Sampler &smp, OffsetArgs off = OffsetArgs{})
 {
     auto kfn = gemm_i8_p16<Epi, 128>;
-    CK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES));
+    CK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P16_LDS_BYTES));
     const int tm = (int)((M + 255) / 256), tn = (int)((N + 255) / 256), nb = tm * tn < 4096 ? tm * tn : 4096;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int BATCH = 50;
-    auto launch = [&]() { hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8_LDS_BYTES, 0, x, w, M, N, K, tm, tn, epi); };
+    auto launch = [&]() { hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P16_LDS_BYTES, 0, x, w, M, N, K, tm, tn, epi, off); };
     for (int i = 0; i < 5; ++i) launch();
     CK(hipDeviceSynchronize());
     smp.start();
@@ -559,6 +559,42 @@ int main(int argc, char **argv)
         run_gemm("p8 bench", dxb, dwb, e16, M, N, K, seconds, smp);
         run_gemm_p4("bench", dxb, dwb, e16, M, N, K, seconds, smp);
     }
+    if (what == "off") {   // round 4: offset operand images (asq_gemm_kernels.h: OffsetArgs) -- where do the cycles and the clock go?
+        std::vector<int8_t> wi(N * K), xi(M * K);
+        std::vector<int32_t> col(2 * N), row(2 * M), zc(2 * N, 0), zr(2 * M, 0);
+        for (int64_t n = 0; n < N; ++n) {
+            int mx = -128; long long sm = 0;
+            for (int64_t k = 0; k < K; ++k) { const int v = wb[n * K + k]; mx = v > mx ? v : mx; sm += v; }
+            const int cw = std::min(64, 127 - mx);
+            col[2 * n] = cw; col[2 * n + 1] = (int32_t)sm;
+            for (int64_t k = 0; k < K; ++k) wi[n * K + k] = (int8_t)(wb[n * K + k] + cw);
+        }
+        for (int64_t m = 0; m < M; ++m) {
+            int mx = -128, mn = 127; long long sm = 0;
+            for (int64_t k = 0; k < K; ++k) { const int v = xb[m * K + k]; mx = v > mx ? v : mx; mn = v < mn ? v : mn; sm += v; }
+            const int cx = mx <= 124 ? 3 : (mn >= -125 ? -3 : 0);
+            row[2 * m] = cx; row[2 * m + 1] = (int32_t)(sm + cx * K);
+            for (int64_t k = 0; k < K; ++k) xi[m * K + k] = (int8_t)(xb[m * K + k] + cx);
+        }
+        int8_t *dwi, *dxi; int32_t *dcol, *drow, *dzc, *dzr;
+        CK(hipMalloc(&dwi, N * K)); CK(hipMalloc(&dxi, M * K)); CK(hipMalloc(&dcol, 8 * N)); CK(hipMalloc(&drow, 8 * M)); CK(hipMalloc(&dzc, 8 * N)); CK(hipMalloc(&dzr, 8 * M));
+        CK(hipMemcpy(dwi, wi.data(), N * K, hipMemcpyHostToDevice)); CK(hipMemcpy(dxi, xi.data(), M * K, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dcol, col.data(), 8 * N, hipMemcpyHostToDevice)); CK(hipMemcpy(drow, row.data(), 8 * M, hipMemcpyHostToDevice));
+        CK(hipMemset(dzc, 0, 8 * N)); CK(hipMemset(dzr, 0, 8 * M));
+        // (the first M * K / N * K bytes of the K = 16384 buffers are what run_gemm_p16 multiplies at K = 4096: rows contiguous at the K it is given)
+        std::vector<int8_t> w4(wb.begin(), wb.begin() + N * K), x4(xb.begin(), xb.begin() + M * K);
+        CK(hipMemcpy(dwb, w4.data(), N * K, hipMemcpyHostToDevice)); CK(hipMemcpy(dxb, x4.data(), M * K, hipMemcpyHostToDevice));
+        Sampler smp;
+        for (int rep = 0; rep < 2; ++rep) {
+            run_gemm_p16("plain", dxb, dwb, e16, M, N, K, seconds, smp);
+            run_gemm_p16("images, plain launch (timing only)", dxi, dwi, e16, M, N, K, seconds, smp);
+            run_gemm_p16("images + start values (exact)", dxi, dwi, e16, M, N, K, seconds, smp, OffsetArgs{drow, dcol});
+            run_gemm_p16("images + zero vectors (timing only)", dxi, dwi, e16, M, N, K, seconds, smp, OffsetArgs{dzr, dzc});
+            run_gemm_p16("plain operands + zero vectors", dxb, dwb, e16, M, N, K, seconds, smp, OffsetArgs{dzr, dzc});
+        }
+        return 0;
+    }
+
     if (what == "p16") {   // round 3: the 16x16x64 kernel next to the 32x32x32 one, stamped, alternating in one process
         for (int rep = 0; rep < 2; ++rep) {
             run_gemm("p8 bench", dxb, dwb, e16, M, N, K, seconds, smp);
