@@ -221,10 +221,12 @@ template <int DT, class Q> int launch_flat(const void *x, int8_t *xq, int64_t n,
     return asq_after_launch(s, "asq_quantize_act(per-tensor)");
 }
 
+template <int DT> bool launch_per_token_wave(const void *x, int8_t *xq, float *s_row, int64_t M, int64_t K, hipStream_t s);   // (one wave per row: defined below)
 template <int DT> int launch_per_token(const void *x, int8_t *xq, float *s_row, int64_t M, int64_t K, hipStream_t s)
 {
     constexpr int VEC = ElemT<DT>::VEC;
     const bool vec_ok = (K % VEC == 0) && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)xq) & (VEC - 1)) == 0);
+    if (vec_ok && K > 0 && launch_per_token_wave<DT>(x, xq, s_row, M, K, s)) return asq_after_launch(s, "asq_quantize_act(per-token)");
     const int64_t nvec = K / VEC;
     dim3 grid((unsigned)M), block(256);
 #define ASQ_PT(NV)                                                                                          \
@@ -374,10 +376,122 @@ __global__ void __launch_bounds__(256) quant_rows_off(const void *__restrict__ x
     }
 }
 
+// ---- one WAVE per row (round 4): the row-wise quantisers above spend their time in two block-wide reductions (LDS + __syncthreads) on 4096 tiny blocks --
+// 15.1 / 17.4 us for 4096 x 4096 fp16 (3.3 / 2.9 TB/s) against 12.5 us for the flat per-tensor kernel.  Here a wave owns a row: NV 16-byte loads per lane in flight
+// (non-temporal: the activation is read once), every reduction a wave butterfly, no LDS, no barrier; 4 rows per 256-thread block.  K <= 64 * VEC * NV.
+// OFF = false is the plain per-token quantiser (same arithmetic as quant_per_token_cached), OFF = true emits the offset image + row_off.
+__device__ __forceinline__ v4i load16_nt(const void *p)
+{
+    return __builtin_nontemporal_load((const v4i *)p);
+}
+template <int DT, int NV, class Q, bool PER_TOKEN, bool OFF>
+__global__ void __launch_bounds__(256) quant_rows_wave(const void *__restrict__ xv, int8_t *__restrict__ xq, float *__restrict__ s_row,
+                                                       int32_t *__restrict__ row_off, int M, int K, Q q_in, int C)
+{
+    constexpr int VEC = ElemT<DT>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;   // (wave-uniform; nothing below synchronises across waves)
+    const char *xrow = (const char *)xv + row * (int64_t)K * (16 / VEC);
+    const int nvec = K / VEC;
+    v4i v[NV];
+    [[maybe_unused]] AbsMax<DT> am;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = i * 64 + lane;
+        if (idx < nvec) {
+            v[i] = load16_nt(xrow + (int64_t)idx * 16);
+            if constexpr (PER_TOKEN) am.add(v[i]);
+        }
+    }
+    uint32_t o[NV][2];
+    [[maybe_unused]] RowStats st;
+    auto emit = [&](auto q) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = i * 64 + lane;
+            if (idx < nvec) {
+                quant_vec<DT>(v[i], q, o[i]);
+                if constexpr (OFF) {
+                    st.add(o[i][0]);
+                    if constexpr (DT != ASQ_F32) st.add(o[i][1]);
+                }
+            }
+        }
+    };
+    if constexpr (PER_TOKEN) {
+        uint32_t mb = am.f32bits();
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mb = umax32(mb, (uint32_t)__shfl_xor((int)mb, off, 64));
+        const float m = __uint_as_float(mb);
+        const float qs = ElemT<DT>::round(m / 127.0f);
+        if (lane == 0) s_row[row] = qs;
+        const RowDivisor d(qs, m);
+        if (d.fast) emit(QRowFast{d.s, d.y});
+        else emit(QDivF32<DT>{qs});
+    } else {
+        emit(q_in);
+    }
+    uint32_t c4 = 0;
+    if constexpr (OFF) {
+        int mx = (int)umax32(st.mx & 0xFFFFu, st.mx >> 16) - 128, mn = (int)(((st.mn & 0xFFFFu) < (st.mn >> 16)) ? (st.mn & 0xFFFFu) : (st.mn >> 16)) - 128;
+        int sm = (int)((st.sum & 0xFFFFu) + (st.sum >> 16)) - 128 * st.n;
+        if (st.n == 0) { mx = -128; mn = 127; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int omx = __shfl_xor(mx, off, 64), omn = __shfl_xor(mn, off, 64);
+            mx = mx > omx ? mx : omx;
+            mn = mn < omn ? mn : omn;
+            sm += __shfl_xor(sm, off, 64);
+        }
+        const int cx = pick_row_offset(mx, mn, C);
+        if (lane == 0) *(v2i *)(row_off + 2 * row) = (v2i){cx, sm + cx * K};
+        c4 = (uint32_t)(cx & 0xFF) * 0x01010101u;
+    }
+    int8_t *orow = xq + row * (int64_t)K;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = i * 64 + lane;
+        if (idx < nvec) {
+            if constexpr (DT == ASQ_F32) {
+                *(uint32_t *)(orow + (int64_t)idx * 4) = OFF ? pk_add_i8(o[i][0], c4) : o[i][0];
+            } else {
+                *(uint2 *)(orow + (int64_t)idx * 8) = OFF ? make_uint2(pk_add_i8(o[i][0], c4), pk_add_i8(o[i][1], c4)) : make_uint2(o[i][0], o[i][1]);
+            }
+        }
+    }
+}
+
+// true when a launch was made (rows of up to 64 * VEC * 24 elements)
+template <int DT, class Q, bool PT, bool OFF>
+bool launch_rows_wave(const void *x, int8_t *xq, float *s_row, int32_t *row_off, int64_t M, int64_t K, Q q, int C, hipStream_t s)
+{
+    constexpr int VEC = ElemT<DT>::VEC;
+    const int64_t nvec = K / VEC;
+    if (nvec > 64 * 24 || M >= (1ll << 31)) return false;
+    dim3 grid((unsigned)((M + 3) / 4)), block(256);
+#define ASQ_RW(NV) hipLaunchKernelGGL((quant_rows_wave<DT, NV, Q, PT, OFF>), grid, block, 0, s, x, xq, s_row, row_off, (int)M, (int)K, q, C)
+    if (nvec <= 64 * 1) ASQ_RW(1);
+    else if (nvec <= 64 * 2) ASQ_RW(2);
+    else if (nvec <= 64 * 4) ASQ_RW(4);
+    else if (nvec <= 64 * 8) ASQ_RW(8);
+    else if (nvec <= 64 * 12) ASQ_RW(12);
+    else if (nvec <= 64 * 16) ASQ_RW(16);
+    else ASQ_RW(24);
+#undef ASQ_RW
+    return true;
+}
+
+template <int DT> bool launch_per_token_wave(const void *x, int8_t *xq, float *s_row, int64_t M, int64_t K, hipStream_t s)
+{
+    return launch_rows_wave<DT, QRound<DT>, true, false>(x, xq, s_row, nullptr, M, K, QRound<DT>{}, 0, s);
+}
+
 template <int DT, class Q, bool PT> int launch_rows_off(const void *x, int8_t *xq, float *s_row, int32_t *row_off, int64_t M, int64_t K, Q q, int C, hipStream_t s)
 {
     constexpr int VEC = ElemT<DT>::VEC;
     const int64_t nvec = K / VEC;
+    if (launch_rows_wave<DT, Q, PT, true>(x, xq, s_row, row_off, M, K, q, C, s)) return asq_after_launch(s, "asq_quantize_act_off");
     dim3 grid((unsigned)M), block(256);
 #define ASQ_RO(NV) hipLaunchKernelGGL((quant_rows_off<DT, NV, Q, PT>), grid, block, 0, s, x, xq, s_row, row_off, (int)K, q, C)
     if (nvec <= 256 * 1) ASQ_RO(1);
@@ -572,7 +686,7 @@ template <int DT, int NV, bool LAYERNORM, bool PER_TOKEN, bool ADD>
 // restrict pointer is undefined behaviour even though every thread loads a vector before it stores the same one)
 __global__ void __launch_bounds__(256) norm_quant_cached(const void *xv, const void *resv, void *hout,
                                                          const void *__restrict__ wv, const void *__restrict__ bv, float eps,
-                                                         int8_t *__restrict__ xq, float *__restrict__ s_row, int K)
+                                                         int8_t *__restrict__ xq, float *__restrict__ s_row, int K, int32_t *__restrict__ row_off, int C)
 {
     constexpr int VEC = ElemT<DT>::VEC;
     __shared__ float red[4];
@@ -648,6 +762,40 @@ __global__ void __launch_bounds__(256) norm_quant_cached(const void *xv, const v
     const RowDivisor d(qs, rowmax);
     const QRowFast qf{d.s, d.y};
     int8_t *orow = xq + row * (int64_t)K;
+    if (row_off != nullptr) {   // (block-uniform) offset image: the quantised row stays packed in registers between its statistics and the store (quant_rows_off)
+        __shared__ int redi[12];
+        uint32_t o[NV][2];
+        RowStats st;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = i * 256 + threadIdx.x;
+            if (idx < nvec) {
+                int q[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) q[j] = PER_TOKEN ? quant_i8(d.fast ? qf.div(f[i][j]) : f[i][j] / qs) : quant_i8(f[i][j]);
+                o[i][0] = pack4(q[0], q[1], q[2], q[3]);
+                st.add(o[i][0]);
+                if constexpr (DT != ASQ_F32) {
+                    o[i][1] = pack4(q[4], q[5], q[6], q[7]);
+                    st.add(o[i][1]);
+                }
+            }
+        }
+        int rmax, rmin, rsum;
+        block_row_stats(st, redi, rmax, rmin, rsum);
+        const int cx = pick_row_offset(rmax, rmin, C);
+        if (threadIdx.x == 0) *(v2i *)(row_off + 2 * row) = (v2i){cx, rsum + cx * K};
+        const uint32_t c4 = (uint32_t)(cx & 0xFF) * 0x01010101u;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = i * 256 + threadIdx.x;
+            if (idx < nvec) {
+                if constexpr (DT == ASQ_F32) *(uint32_t *)(orow + (int64_t)idx * 4) = pk_add_i8(o[i][0], c4);
+                else *(uint2 *)(orow + (int64_t)idx * 8) = make_uint2(pk_add_i8(o[i][0], c4), pk_add_i8(o[i][1], c4));
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = i * 256 + threadIdx.x;
@@ -666,12 +814,12 @@ __global__ void __launch_bounds__(256) norm_quant_cached(const void *xv, const v
 
 template <int DT, bool LN, bool PT, bool ADD = false>
 int launch_norm_quant(const void *x, const void *w, const void *b, float eps, int8_t *xq, float *s_row, int64_t M, int64_t K, hipStream_t s,
-                      const void *res = nullptr, void *hout = nullptr)
+                      const void *res = nullptr, void *hout = nullptr, int32_t *row_off = nullptr, int C = 0)
 {
     constexpr int VEC = ElemT<DT>::VEC;
     const int64_t nvec = K / VEC;
     dim3 grid((unsigned)M), block(256);
-#define ASQ_NQ(NV) hipLaunchKernelGGL((norm_quant_cached<DT, NV, LN, PT, ADD>), grid, block, 0, s, x, res, hout, w, b, eps, xq, s_row, (int)K)
+#define ASQ_NQ(NV) hipLaunchKernelGGL((norm_quant_cached<DT, NV, LN, PT, ADD>), grid, block, 0, s, x, res, hout, w, b, eps, xq, s_row, (int)K, row_off, C)
     if (nvec <= 256 * 1) ASQ_NQ(1);
     else if (nvec <= 256 * 2) ASQ_NQ(2);
     else if (nvec <= 256 * 4) ASQ_NQ(4);
@@ -693,7 +841,7 @@ int launch_norm_quant(const void *x, const void *w, const void *b, float eps, in
 // at most +-1 (bf16: +-2 on < 1e-4 of the elements), where silu(g) * up lies within an fp16 / bf16 ulp of a rounding boundary (tests/test_hip_n1.py).
 template <int DT, int NV, bool PER_TOKEN, bool FAST = false>
 __global__ void __launch_bounds__(256) silu_mul_quant_cached(const void *__restrict__ gv, const void *__restrict__ uv, float quant_scale,
-                                                             int8_t *__restrict__ xq, float *__restrict__ s_row, int K)
+                                                             int8_t *__restrict__ xq, float *__restrict__ s_row, int K, int32_t *__restrict__ row_off, int C)
 {
     constexpr int VEC = ElemT<DT>::VEC;
     // fp16: the product of two fp16 values is exact in fp32, so dt(fp32(sl) * fp32(u)) IS the IEEE fp16 product: one v_pk_mul_f16 per
@@ -752,34 +900,70 @@ __global__ void __launch_bounds__(256) silu_mul_quant_cached(const void *__restr
     const RowDivisor d(qs, rowmax);  // per-tensor rows have no known maximum: plain division
     const QRowFast qf{d.s, d.y};
     int8_t *orow = xq + row * (int64_t)K;
+    auto quant_one = [&](int i, int (&q)[VEC]) {
+#pragma unroll
+        for (int j = 0; j < VEC; j += 2) {
+            v2f av;
+            if constexpr (H) {
+                const v2h hh = __builtin_bit_cast(v2h, ah[i][j / 2]);
+                av = (v2f){(float)hh[0], (float)hh[1]};
+            } else {
+                av = (v2f){a[i][j], a[i][j + 1]};
+            }
+            if constexpr (PER_TOKEN) {
+                if (d.fast) {
+                    const v2f t = qf.div2(av);
+                    q[j] = quant_i8(t[0]);
+                    q[j + 1] = quant_i8(t[1]);
+                } else {
+                    q[j] = quant_i8(av[0] / qs);
+                    q[j + 1] = quant_i8(av[1] / qs);
+                }
+            } else {
+                q[j] = quant_i8(ElemT<DT>::round(av[0] / qs));
+                q[j + 1] = quant_i8(ElemT<DT>::round(av[1] / qs));
+            }
+        }
+    };
+    if (row_off != nullptr) {   // (block-uniform) offset image, as quant_rows_off
+        __shared__ int redi[12];
+        uint32_t o[NV][2];
+        RowStats st;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = i * 256 + threadIdx.x;
+            if (idx < nvec) {
+                int q[VEC];
+                quant_one(i, q);
+                o[i][0] = pack4(q[0], q[1], q[2], q[3]);
+                st.add(o[i][0]);
+                if constexpr (DT != ASQ_F32) {
+                    o[i][1] = pack4(q[4], q[5], q[6], q[7]);
+                    st.add(o[i][1]);
+                }
+            }
+        }
+        int rmax, rmin, rsum;
+        block_row_stats(st, redi, rmax, rmin, rsum);
+        const int cx = pick_row_offset(rmax, rmin, C);
+        if (threadIdx.x == 0) *(v2i *)(row_off + 2 * row) = (v2i){cx, rsum + cx * K};
+        const uint32_t c4 = (uint32_t)(cx & 0xFF) * 0x01010101u;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = i * 256 + threadIdx.x;
+            if (idx < nvec) {
+                if constexpr (DT == ASQ_F32) *(uint32_t *)(orow + (int64_t)idx * 4) = pk_add_i8(o[i][0], c4);
+                else *(uint2 *)(orow + (int64_t)idx * 8) = make_uint2(pk_add_i8(o[i][0], c4), pk_add_i8(o[i][1], c4));
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = i * 256 + threadIdx.x;
         if (idx < nvec) {
             int q[VEC];
-#pragma unroll
-            for (int j = 0; j < VEC; j += 2) {
-                v2f av;
-                if constexpr (H) {
-                    const v2h hh = __builtin_bit_cast(v2h, ah[i][j / 2]);
-                    av = (v2f){(float)hh[0], (float)hh[1]};
-                } else {
-                    av = (v2f){a[i][j], a[i][j + 1]};
-                }
-                if constexpr (PER_TOKEN) {
-                    if (d.fast) {
-                        const v2f t = qf.div2(av);
-                        q[j] = quant_i8(t[0]);
-                        q[j + 1] = quant_i8(t[1]);
-                    } else {
-                        q[j] = quant_i8(av[0] / qs);
-                        q[j + 1] = quant_i8(av[1] / qs);
-                    }
-                } else {
-                    q[j] = quant_i8(ElemT<DT>::round(av[0] / qs));
-                    q[j + 1] = quant_i8(ElemT<DT>::round(av[1] / qs));
-                }
-            }
+            quant_one(i, q);
             if constexpr (DT == ASQ_F32) {
                 *(uint32_t *)(orow + (int64_t)idx * 4) = pack4(q[0], q[1], q[2], q[3]);
             } else {
@@ -790,12 +974,12 @@ __global__ void __launch_bounds__(256) silu_mul_quant_cached(const void *__restr
 }
 
 template <int DT, bool PT, bool FAST = false>
-int launch_silu_mul_quant(const void *g, const void *u, float qs, int8_t *xq, float *s_row, int64_t M, int64_t K, hipStream_t s)
+int launch_silu_mul_quant(const void *g, const void *u, float qs, int8_t *xq, float *s_row, int64_t M, int64_t K, hipStream_t s, int32_t *row_off = nullptr, int C = 0)
 {
     constexpr int VEC = ElemT<DT>::VEC;
     const int64_t nvec = K / VEC;
     dim3 grid((unsigned)M), block(256);
-#define ASQ_SM(NV) hipLaunchKernelGGL((silu_mul_quant_cached<DT, NV, PT, FAST>), grid, block, 0, s, g, u, qs, xq, s_row, (int)K)
+#define ASQ_SM(NV) hipLaunchKernelGGL((silu_mul_quant_cached<DT, NV, PT, FAST>), grid, block, 0, s, g, u, qs, xq, s_row, (int)K, row_off, C)
     if (nvec <= 256 * 2) ASQ_SM(2);
     else if (nvec <= 256 * 4) ASQ_SM(4);
     else if (nvec <= 256 * 6) ASQ_SM(6);
@@ -858,8 +1042,8 @@ extern "C" int asq_weight_offset_image(const int8_t *w, int64_t N, int64_t K, in
     return asq_after_launch((hipStream_t)stream, "asq_weight_offset_image");
 }
 
-extern "C" int asq_norm_quantize(const void *x, int x_dtype, const void *weight, const void *bias, float eps, int per_token, int8_t *xq,
-                                 float *s_row, int64_t M, int64_t K, void *stream)
+static int norm_quantize_impl(const void *x, int x_dtype, const void *weight, const void *bias, float eps, int per_token, int8_t *xq,
+                              float *s_row, int32_t *row_off, int64_t M, int64_t K, void *stream)
 {
     ASQ_REQUIRE(M >= 0 && K > 0 && M < (1ll << 31), ASQ_ERR_DIM, "asq_norm_quantize: bad dims");
     ASQ_REQUIRE(x_dtype == ASQ_F32 || x_dtype == ASQ_F16 || x_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_norm_quantize: bad x_dtype %d", x_dtype);
@@ -870,11 +1054,12 @@ extern "C" int asq_norm_quantize(const void *x, int x_dtype, const void *weight,
     ASQ_REQUIRE(((((uintptr_t)x | (uintptr_t)weight | (uintptr_t)bias) & 15) == 0) && (((uintptr_t)xq & (vec - 1)) == 0), ASQ_ERR_ALIGN,
                 "asq_norm_quantize: x / weight / bias must be 16-B aligned");
     hipStream_t s = (hipStream_t)stream;
+    const int C = offset_cx();
 #define ASQ_NQD(DT_)                                                                                                           \
-    (bias ? (per_token ? launch_norm_quant<DT_, true, true>(x, weight, bias, eps, xq, s_row, M, K, s)                          \
-                       : launch_norm_quant<DT_, true, false>(x, weight, bias, eps, xq, s_row, M, K, s))                         \
-          : (per_token ? launch_norm_quant<DT_, false, true>(x, weight, bias, eps, xq, s_row, M, K, s)                         \
-                       : launch_norm_quant<DT_, false, false>(x, weight, bias, eps, xq, s_row, M, K, s)))
+    (bias ? (per_token ? launch_norm_quant<DT_, true, true>(x, weight, bias, eps, xq, s_row, M, K, s, nullptr, nullptr, row_off, C)                          \
+                       : launch_norm_quant<DT_, true, false>(x, weight, bias, eps, xq, s_row, M, K, s, nullptr, nullptr, row_off, C))                         \
+          : (per_token ? launch_norm_quant<DT_, false, true>(x, weight, bias, eps, xq, s_row, M, K, s, nullptr, nullptr, row_off, C)                         \
+                       : launch_norm_quant<DT_, false, false>(x, weight, bias, eps, xq, s_row, M, K, s, nullptr, nullptr, row_off, C)))
     switch (x_dtype) {
     case ASQ_F32: return ASQ_NQD(ASQ_F32);
     case ASQ_F16: return ASQ_NQD(ASQ_F16);
@@ -882,9 +1067,21 @@ extern "C" int asq_norm_quantize(const void *x, int x_dtype, const void *weight,
     }
 #undef ASQ_NQD
 }
+extern "C" int asq_norm_quantize(const void *x, int x_dtype, const void *weight, const void *bias, float eps, int per_token, int8_t *xq,
+                                 float *s_row, int64_t M, int64_t K, void *stream)
+{
+    return norm_quantize_impl(x, x_dtype, weight, bias, eps, per_token, xq, s_row, nullptr, M, K, stream);
+}
+extern "C" int asq_norm_quantize_off(const void *x, int x_dtype, const void *weight, const void *bias, float eps, int per_token, int8_t *xq,
+                                     float *s_row, int32_t *row_off, int64_t M, int64_t K, void *stream)
+{
+    ASQ_REQUIRE(M == 0 || (row_off != nullptr && ((uintptr_t)row_off & 7) == 0), ASQ_ERR_NULL, "asq_norm_quantize_off: row_off NULL or not 8-B aligned");
+    ASQ_REQUIRE(K <= 65536, ASQ_ERR_DIM, "asq_norm_quantize_off: K <= 65536");
+    return norm_quantize_impl(x, x_dtype, weight, bias, eps, per_token, xq, s_row, row_off, M, K, stream);
+}
 
-extern "C" int asq_add_norm_quantize(const void *x, const void *residual, void *h_out, int x_dtype, const void *weight, const void *bias, float eps,
-                                     int per_token, int8_t *xq, float *s_row, int64_t M, int64_t K, void *stream)
+static int add_norm_quantize_impl(const void *x, const void *residual, void *h_out, int x_dtype, const void *weight, const void *bias, float eps,
+                                  int per_token, int8_t *xq, float *s_row, int32_t *row_off, int64_t M, int64_t K, void *stream)
 {
     ASQ_REQUIRE(M >= 0 && K > 0 && M < (1ll << 31), ASQ_ERR_DIM, "asq_add_norm_quantize: bad dims");
     ASQ_REQUIRE(x_dtype == ASQ_F32 || x_dtype == ASQ_F16 || x_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_add_norm_quantize: bad x_dtype %d", x_dtype);
@@ -895,11 +1092,12 @@ extern "C" int asq_add_norm_quantize(const void *x, const void *residual, void *
     ASQ_REQUIRE(((((uintptr_t)x | (uintptr_t)residual | (uintptr_t)h_out | (uintptr_t)weight | (uintptr_t)bias) & 15) == 0) && (((uintptr_t)xq & (vec - 1)) == 0),
                 ASQ_ERR_ALIGN, "asq_add_norm_quantize: x / residual / h_out / weight / bias must be 16-B aligned");
     hipStream_t s = (hipStream_t)stream;
+    const int C = offset_cx();
 #define ASQ_ANQ(DT_)                                                                                                                       \
-    (bias ? (per_token ? launch_norm_quant<DT_, true, true, true>(x, weight, bias, eps, xq, s_row, M, K, s, residual, h_out)               \
-                       : launch_norm_quant<DT_, true, false, true>(x, weight, bias, eps, xq, s_row, M, K, s, residual, h_out))             \
-          : (per_token ? launch_norm_quant<DT_, false, true, true>(x, weight, bias, eps, xq, s_row, M, K, s, residual, h_out)              \
-                       : launch_norm_quant<DT_, false, false, true>(x, weight, bias, eps, xq, s_row, M, K, s, residual, h_out)))
+    (bias ? (per_token ? launch_norm_quant<DT_, true, true, true>(x, weight, bias, eps, xq, s_row, M, K, s, residual, h_out, row_off, C)               \
+                       : launch_norm_quant<DT_, true, false, true>(x, weight, bias, eps, xq, s_row, M, K, s, residual, h_out, row_off, C))             \
+          : (per_token ? launch_norm_quant<DT_, false, true, true>(x, weight, bias, eps, xq, s_row, M, K, s, residual, h_out, row_off, C)              \
+                       : launch_norm_quant<DT_, false, false, true>(x, weight, bias, eps, xq, s_row, M, K, s, residual, h_out, row_off, C)))
     switch (x_dtype) {
     case ASQ_F32: return ASQ_ANQ(ASQ_F32);
     case ASQ_F16: return ASQ_ANQ(ASQ_F16);
@@ -907,10 +1105,23 @@ extern "C" int asq_add_norm_quantize(const void *x, const void *residual, void *
     }
 #undef ASQ_ANQ
 }
-
-extern "C" int asq_silu_mul_quantize(const void *gate, const void *up, int x_dtype, int per_token, float quant_scale, int8_t *xq, float *s_row,
-                                     int64_t M, int64_t K, void *stream)
+extern "C" int asq_add_norm_quantize(const void *x, const void *residual, void *h_out, int x_dtype, const void *weight, const void *bias, float eps,
+                                     int per_token, int8_t *xq, float *s_row, int64_t M, int64_t K, void *stream)
 {
+    return add_norm_quantize_impl(x, residual, h_out, x_dtype, weight, bias, eps, per_token, xq, s_row, nullptr, M, K, stream);
+}
+extern "C" int asq_add_norm_quantize_off(const void *x, const void *residual, void *h_out, int x_dtype, const void *weight, const void *bias, float eps,
+                                         int per_token, int8_t *xq, float *s_row, int32_t *row_off, int64_t M, int64_t K, void *stream)
+{
+    ASQ_REQUIRE(M == 0 || (row_off != nullptr && ((uintptr_t)row_off & 7) == 0), ASQ_ERR_NULL, "asq_add_norm_quantize_off: row_off NULL or not 8-B aligned");
+    ASQ_REQUIRE(K <= 65536, ASQ_ERR_DIM, "asq_add_norm_quantize_off: K <= 65536");
+    return add_norm_quantize_impl(x, residual, h_out, x_dtype, weight, bias, eps, per_token, xq, s_row, row_off, M, K, stream);
+}
+
+static int silu_mul_quantize_impl(const void *gate, const void *up, int x_dtype, int per_token, float quant_scale, int8_t *xq, float *s_row, int32_t *row_off,
+                                  int64_t M, int64_t K, void *stream)
+{
+    ASQ_REQUIRE((per_token & ~3) == 0, ASQ_ERR_DTYPE, "asq_silu_mul_quantize: per_token is a bit field (bit 0 per-token, bit 1 ASQ_SILU_FAST), got %d", per_token);
     ASQ_REQUIRE(M >= 0 && K > 0 && M < (1ll << 31), ASQ_ERR_DIM, "asq_silu_mul_quantize: bad dims");
     ASQ_REQUIRE(x_dtype == ASQ_F32 || x_dtype == ASQ_F16 || x_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_silu_mul_quantize: bad x_dtype %d", x_dtype);
     if (M == 0) return ASQ_OK;
@@ -922,15 +1133,28 @@ extern "C" int asq_silu_mul_quantize(const void *gate, const void *up, int x_dty
     hipStream_t s = (hipStream_t)stream;
     const bool fast = (per_token & ASQ_SILU_FAST) != 0;
     per_token &= 1;
+    const int C = offset_cx();
 #define ASQ_SMD(DT_)                                                                                                                              \
-    (fast ? (per_token ? launch_silu_mul_quant<DT_, true, true>(gate, up, quant_scale, xq, s_row, M, K, s)                                        \
-                       : launch_silu_mul_quant<DT_, false, true>(gate, up, quant_scale, xq, s_row, M, K, s))                                     \
-          : (per_token ? launch_silu_mul_quant<DT_, true>(gate, up, quant_scale, xq, s_row, M, K, s)                                              \
-                       : launch_silu_mul_quant<DT_, false>(gate, up, quant_scale, xq, s_row, M, K, s)))
+    (fast ? (per_token ? launch_silu_mul_quant<DT_, true, true>(gate, up, quant_scale, xq, s_row, M, K, s, row_off, C)                                        \
+                       : launch_silu_mul_quant<DT_, false, true>(gate, up, quant_scale, xq, s_row, M, K, s, row_off, C))                                     \
+          : (per_token ? launch_silu_mul_quant<DT_, true>(gate, up, quant_scale, xq, s_row, M, K, s, row_off, C)                                              \
+                       : launch_silu_mul_quant<DT_, false>(gate, up, quant_scale, xq, s_row, M, K, s, row_off, C)))
     switch (x_dtype) {
     case ASQ_F32: return ASQ_SMD(ASQ_F32);
     case ASQ_F16: return ASQ_SMD(ASQ_F16);
     default: return ASQ_SMD(ASQ_BF16);
     }
 #undef ASQ_SMD
+}
+extern "C" int asq_silu_mul_quantize(const void *gate, const void *up, int x_dtype, int per_token, float quant_scale, int8_t *xq, float *s_row,
+                                     int64_t M, int64_t K, void *stream)
+{
+    return silu_mul_quantize_impl(gate, up, x_dtype, per_token, quant_scale, xq, s_row, nullptr, M, K, stream);
+}
+extern "C" int asq_silu_mul_quantize_off(const void *gate, const void *up, int x_dtype, int per_token, float quant_scale, int8_t *xq, float *s_row,
+                                         int32_t *row_off, int64_t M, int64_t K, void *stream)
+{
+    ASQ_REQUIRE(M == 0 || (row_off != nullptr && ((uintptr_t)row_off & 7) == 0), ASQ_ERR_NULL, "asq_silu_mul_quantize_off: row_off NULL or not 8-B aligned");
+    ASQ_REQUIRE(K <= 65536, ASQ_ERR_DIM, "asq_silu_mul_quantize_off: K <= 65536");
+    return silu_mul_quantize_impl(gate, up, x_dtype, per_token, quant_scale, xq, s_row, row_off, M, K, stream);
 }

@@ -134,17 +134,19 @@ class LlamaLayer(torch.nn.Module):
         B, S, _ = (h.base if isinstance(h, DeferredResidual) else h).shape
         alt = getattr(self, "use_fused", False)   # to_w8a8(both=True): the fused (N1) modules sit beside the reference composition
         norm = self.input_layernorm_q if alt else self.input_layernorm
+        one_qkv = getattr(self, "qkv_proj", None) is not None and (alt or getattr(self, "q_proj", None) is None)
+        readers = (self.qkv_proj,) if one_qkv else (self.q_proj, self.k_proj, self.v_proj)   # (a fused norm emits the activation's offset image when all of them take it)
         if isinstance(h, DeferredResidual):       # the previous layer left its residual add to this layer's input norm
             if hasattr(norm, "add_forward"):
-                h, x = norm.add_forward(h.delta, h.base)
+                h, x = norm.add_forward(h.delta, h.base, consumers=readers)
             else:
                 h = h.materialize()
                 x = norm(h)
         else:
-            x = norm(h)   # a float tensor, or a QuantizedActivation when the norm is fused (N1)
+            x = norm(h, consumers=readers) if hasattr(norm, "add_forward") else norm(h)   # a float tensor, or a QuantizedActivation when the norm is fused (N1)
         if record is not None:
             record["attn_in"] = x
-        if getattr(self, "qkv_proj", None) is not None and (alt or getattr(self, "q_proj", None) is None):   # one GEMM over [q;k;v] (the reference's QKVLinear, as its Baichuan W_pack)
+        if one_qkv:   # one GEMM over [q;k;v] (the reference's QKVLinear, as its Baichuan W_pack)
             nq, nkv = self.heads * self.hd, self.kv_heads * self.hd
             q, k, v = self.qkv_proj(x).split([nq, nkv, nkv], dim=-1)
         else:
@@ -168,14 +170,15 @@ class LlamaLayer(torch.nn.Module):
     def mlp(self, h, record=None):
         alt = getattr(self, "use_fused", False)
         norm = self.post_attention_layernorm_q if alt else self.post_attention_layernorm
+        readers = (self.gate_proj, self.up_proj)
         if isinstance(h, DeferredResidual):
             if hasattr(norm, "add_forward"):
-                h, x = norm.add_forward(h.delta, h.base)
+                h, x = norm.add_forward(h.delta, h.base, consumers=readers)
             else:
                 h = h.materialize()
                 x = norm(h)
         else:
-            x = norm(h)
+            x = norm(h, consumers=readers) if hasattr(norm, "add_forward") else norm(h)
         if record is not None:
             record["mlp_in"] = x
         xi = shared_input(x, self.gate_proj, self.up_proj)
@@ -401,7 +404,9 @@ class OptLayer(torch.nn.Module):
     def forward(self, h, record=None):
         B, S, _ = h.shape
         res = h
-        x = self.self_attn_layer_norm(h) if self.pre_ln else h   # a QuantizedActivation when the norm is a LayerNormQ (N1)
+        ln = self.self_attn_layer_norm
+        fusedq = hasattr(ln, "add_forward")                       # a LayerNormQ (N1): returns a QuantizedActivation -- the offset image when q/k/v all take it
+        x = (ln(h, consumers=(self.q_proj, self.k_proj, self.v_proj)) if fusedq else ln(h)) if self.pre_ln else h
         if record is not None:
             record["attn_in"] = x
         xi = shared_input(x, self.q_proj, self.k_proj, self.v_proj)
@@ -415,10 +420,12 @@ class OptLayer(torch.nn.Module):
         if not self.pre_ln:
             h = self.self_attn_layer_norm(h)
         res = h
-        x = self.final_layer_norm(h) if self.pre_ln else h
+        one_launch = record is None and hasattr(self.fc1, "forward_q") and getattr(self.fc2, "act_quant", None) == "per-tensor"
+        fl = self.final_layer_norm
+        x = ((fl(h, consumers=() if one_launch else (self.fc1,)) if hasattr(fl, "add_forward") else fl(h))) if self.pre_ln else h   # (forward_q's int8-out GEMM takes plain operands)
         if record is not None:
             record["fc1_in"] = x
-        if record is None and hasattr(self.fc1, "forward_q") and getattr(self.fc2, "act_quant", None) == "per-tensor":
+        if one_launch:
             y = self.fc2(self.fc1.forward_q(x, self.fc2, act="relu"))   # fc1 + ReLU + fc2's prologue in ONE launch (asq_linear_w8a8_q8): bit-identical
         else:
             g = F.relu(self.fc1(x))

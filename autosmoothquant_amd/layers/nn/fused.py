@@ -32,6 +32,13 @@ class QuantizedActivation:
         return (*self.lead, self.xq.shape[-1])
 
 
+def wants_offsets(consumers, M, dtype):
+    """True when every consumer is a W8A8 linear that runs M rows (outputs of `dtype`) on offset operand images."""
+    if not consumers:
+        return False
+    return all(hasattr(m, "offset_image") and m.offset_image(M, dtype) is not None for m in consumers)
+
+
 class _NormQ(torch.nn.Module):
     def __init__(self, dim, eps, per_token, with_bias):
         super().__init__()
@@ -43,18 +50,20 @@ class _NormQ(torch.nn.Module):
             self.bias = None
 
     @torch.no_grad()
-    def forward(self, x):
+    def forward(self, x, consumers=None):
+        """consumers: the W8A8 linears that will read the result.  When every one of them runs this many rows on offset operand images
+        (module.offset_image), the int8 activation is emitted as its offset image (row_off set) -- same product, less matrix-core energy."""
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
         w = self.weight if self.weight.dtype == x.dtype else self.weight.to(x.dtype)
         b = None if self.bias is None else (self.bias if self.bias.dtype == x.dtype else self.bias.to(x.dtype))
-        xq, s_row = ops.norm_quantize(x2, w, b, self.eps, self.per_token)
-        return QuantizedActivation(xq, s_row, x.dtype, lead)
+        r = ops.norm_quantize(x2, w, b, self.eps, self.per_token, offsets=wants_offsets(consumers, x2.shape[0], x.dtype))
+        return QuantizedActivation(r[0], r[1], x.dtype, lead, r[2] if len(r) > 2 else None)
 
 
     @torch.no_grad()
-    def add_forward(self, x, residual):
+    def add_forward(self, x, residual, consumers=None):
         """The residual-add form (reference dq_add_layernorm_q, csrc/kernels/fused.cu:5-25): h = residual + x is written once
         and normalised + quantised in the same pass.  Returns (h, QuantizedActivation of norm(h))."""
         lead = residual.shape[:-1]
@@ -63,8 +72,8 @@ class _NormQ(torch.nn.Module):
         r2 = r2 if r2.is_contiguous() else r2.contiguous()
         w = self.weight if self.weight.dtype == x.dtype else self.weight.to(x.dtype)
         b = None if self.bias is None else (self.bias if self.bias.dtype == x.dtype else self.bias.to(x.dtype))
-        h, xq, s_row = ops.add_norm_quantize(x2, r2, w, b, self.eps, self.per_token)
-        return h.view(residual.shape), QuantizedActivation(xq, s_row, x.dtype, lead)
+        r = ops.add_norm_quantize(x2, r2, w, b, self.eps, self.per_token, offsets=wants_offsets(consumers, x2.shape[0], x.dtype))
+        return r[0].view(residual.shape), QuantizedActivation(r[1], r[2], x.dtype, lead, r[3] if len(r) > 3 else None)
 
 
 class DeferredResidual:
@@ -123,5 +132,5 @@ def silu_mul_q(gate, up, consumer, fast=False):
     u2 = u2 if u2.is_contiguous() else u2.contiguous()
     per_token = consumer.act_quant == "per-token"
     qs = 1.0 if per_token else float(consumer.quant_scale)
-    xq, s_row = ops.silu_mul_quantize(g2, u2, per_token, qs, fast)
-    return QuantizedActivation(xq, s_row, gate.dtype, lead)
+    r = ops.silu_mul_quantize(g2, u2, per_token, qs, fast, offsets=wants_offsets((consumer,), g2.shape[0], gate.dtype))
+    return QuantizedActivation(r[0], r[1], gate.dtype, lead, r[2] if len(r) > 2 else None)

@@ -262,9 +262,10 @@ def _bump_version(t):
         pass
 
 
-def norm_quantize(x, weight, bias=None, eps=1e-5, per_token=False):
+def norm_quantize(x, weight, bias=None, eps=1e-5, per_token=False, offsets=False):
     """Fused (scale-folded) RMSNorm / LayerNorm -> int8 activation.  x [M,K]; weight (and bias for
-    LayerNorm) [K] in x's dtype.  Returns (xq int8 [M,K], s_row f32 [M] or None)."""
+    LayerNorm) [K] in x's dtype.  Returns (xq int8 [M,K], s_row f32 [M] or None); offsets=True emits the offset image
+    (asq_norm_quantize_off) and returns (xq', s_row, row_off int32 [M,2])."""
     _dev(x, "x"), _dev(weight, "weight")
     if x.dtype not in _DT or x.dim() != 2 or weight.dtype != x.dtype or weight.numel() != x.shape[1]:
         raise ValueError("x must be 2-D float and weight a [K] tensor of the same dtype")
@@ -275,16 +276,21 @@ def norm_quantize(x, weight, bias=None, eps=1e-5, per_token=False):
     M, K = x.shape
     xq = torch.empty((M, K), dtype=torch.int8, device=x.device)
     s_row = torch.empty((M,), dtype=torch.float32, device=x.device) if per_token else None
+    row_off = torch.empty((M, 2), dtype=torch.int32, device=x.device) if offsets else None
     with _on(x.device):
-        L.check(L.lib().asq_norm_quantize(x.data_ptr(), _DT[x.dtype], weight.data_ptr(), _ptr(bias), float(eps), 1 if per_token else 0,
-                                          xq.data_ptr(), _ptr(s_row), M, K, _stream(x)), "asq_norm_quantize")
-    return xq, s_row
+        if offsets:
+            L.check(L.lib().asq_norm_quantize_off(x.data_ptr(), _DT[x.dtype], weight.data_ptr(), _ptr(bias), float(eps), 1 if per_token else 0,
+                                                  xq.data_ptr(), _ptr(s_row), row_off.data_ptr(), M, K, _stream(x)), "asq_norm_quantize_off")
+        else:
+            L.check(L.lib().asq_norm_quantize(x.data_ptr(), _DT[x.dtype], weight.data_ptr(), _ptr(bias), float(eps), 1 if per_token else 0,
+                                              xq.data_ptr(), _ptr(s_row), M, K, _stream(x)), "asq_norm_quantize")
+    return (xq, s_row, row_off) if offsets else (xq, s_row)
 
 
-def add_norm_quantize(x, residual, weight, bias=None, eps=1e-5, per_token=False, out=None):
+def add_norm_quantize(x, residual, weight, bias=None, eps=1e-5, per_token=False, out=None, offsets=False):
     """h = residual + x (in x's dtype) and the fused norm -> int8 of h in one pass (the reference's dq_add_layernorm_q,
-    csrc/kernels/fused.cu:5-25, on a floating x).  Returns (h [M,K], xq int8 [M,K], s_row f32 [M] or None); `out`
-    may be `residual` itself (the residual stream is updated in place)."""
+    csrc/kernels/fused.cu:5-25, on a floating x).  Returns (h [M,K], xq int8 [M,K], s_row f32 [M] or None) -- with offsets=True (h, xq', s_row, row_off int32 [M,2]); `out`
+    may be `residual` itself (the residual stream is updated in place).  offsets=True: xq is the offset image (asq_add_norm_quantize_off)."""
     _dev(x, "x"), _dev(residual, "residual"), _dev(weight, "weight")
     if x.dtype not in _DT or x.dim() != 2 or residual.shape != x.shape or residual.dtype != x.dtype:
         raise ValueError("x and residual must be 2-D float tensors of equal shape and dtype")
@@ -302,14 +308,19 @@ def add_norm_quantize(x, residual, weight, bias=None, eps=1e-5, per_token=False,
         _bump_version(out)
     xq = torch.empty((M, K), dtype=torch.int8, device=x.device)
     s_row = torch.empty((M,), dtype=torch.float32, device=x.device) if per_token else None
+    row_off = torch.empty((M, 2), dtype=torch.int32, device=x.device) if offsets else None
     with _on(x.device):
-        L.check(L.lib().asq_add_norm_quantize(x.data_ptr(), residual.data_ptr(), h.data_ptr(), _DT[x.dtype], weight.data_ptr(), _ptr(bias), float(eps),
-                                              1 if per_token else 0, xq.data_ptr(), _ptr(s_row), M, K, _stream(x)), "asq_add_norm_quantize")
-    return h, xq, s_row
+        if offsets:
+            L.check(L.lib().asq_add_norm_quantize_off(x.data_ptr(), residual.data_ptr(), h.data_ptr(), _DT[x.dtype], weight.data_ptr(), _ptr(bias), float(eps),
+                                                      1 if per_token else 0, xq.data_ptr(), _ptr(s_row), row_off.data_ptr(), M, K, _stream(x)), "asq_add_norm_quantize_off")
+        else:
+            L.check(L.lib().asq_add_norm_quantize(x.data_ptr(), residual.data_ptr(), h.data_ptr(), _DT[x.dtype], weight.data_ptr(), _ptr(bias), float(eps),
+                                                  1 if per_token else 0, xq.data_ptr(), _ptr(s_row), M, K, _stream(x)), "asq_add_norm_quantize")
+    return (h, xq, s_row, row_off) if offsets else (h, xq, s_row)
 
 
-def silu_mul_quantize(gate, up, per_token=True, quant_scale=1.0, fast=False):
-    """int8(quantise(silu(gate) * up)) in one pass; returns (xq int8 [M,K], s_row f32 [M] or None).  fast=True (opt-in): silu from the hardware
+def silu_mul_quantize(gate, up, per_token=True, quant_scale=1.0, fast=False, offsets=False):
+    """int8(quantise(silu(gate) * up)) in one pass; returns (xq int8 [M,K], s_row f32 [M] or None); offsets=True: (xq', s_row, row_off int32 [M,2]) with xq' the offset image.  fast=True (opt-in): silu from the hardware
     transcendentals instead of the bit-reproducible sequence (ASQ_SILU_FAST: at most +-1 int8 against the exact kernel, ~1.3x the throughput)."""
     _dev(gate, "gate"), _dev(up, "up")
     if gate.dtype not in _DT or gate.dim() != 2 or up.dtype != gate.dtype or up.shape != gate.shape:
@@ -317,10 +328,15 @@ def silu_mul_quantize(gate, up, per_token=True, quant_scale=1.0, fast=False):
     M, K = gate.shape
     xq = torch.empty((M, K), dtype=torch.int8, device=gate.device)
     s_row = torch.empty((M,), dtype=torch.float32, device=gate.device) if per_token else None
+    row_off = torch.empty((M, 2), dtype=torch.int32, device=gate.device) if offsets else None
     with _on(gate.device):
-        L.check(L.lib().asq_silu_mul_quantize(gate.data_ptr(), up.data_ptr(), _DT[gate.dtype], (1 if per_token else 0) | (2 if fast else 0), float(quant_scale),
-                                              xq.data_ptr(), _ptr(s_row), M, K, _stream(gate)), "asq_silu_mul_quantize")
-    return xq, s_row
+        if offsets:
+            L.check(L.lib().asq_silu_mul_quantize_off(gate.data_ptr(), up.data_ptr(), _DT[gate.dtype], (1 if per_token else 0) | (2 if fast else 0), float(quant_scale),
+                                                      xq.data_ptr(), _ptr(s_row), row_off.data_ptr(), M, K, _stream(gate)), "asq_silu_mul_quantize_off")
+        else:
+            L.check(L.lib().asq_silu_mul_quantize(gate.data_ptr(), up.data_ptr(), _DT[gate.dtype], (1 if per_token else 0) | (2 if fast else 0), float(quant_scale),
+                                                  xq.data_ptr(), _ptr(s_row), M, K, _stream(gate)), "asq_silu_mul_quantize")
+    return (xq, s_row, row_off) if offsets else (xq, s_row)
 
 
 def linear_w8a8(xq, w, out_dtype, s_scalar=1.0, s_row=None, s_col=None, bias=None, order="scale_first", out=None):

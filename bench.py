@@ -336,21 +336,31 @@ def measure_dominant_kernel(mod, x, iters=10, batch=20, warm=200):
             ops.linear_w8a8_off(xq, image[0], qa.row_off, image[1], x.dtype, ds, s_row, None, bias, out=out)
         else:
             ops.linear_w8a8(xq, w, x.dtype, ds, s_row, None, bias, out=out)
-    for _ in range(warm):
-        launch()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(iters):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(batch):
-            launch()
-        b.record()
-        b.synchronize()
-        ts.append(a.elapsed_time(b) / batch)
-    ts.sort()
+    def timed(fn):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(iters):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(batch):
+                fn()
+            b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b) / batch)
+        ts.sort()
+        return ts
+
+    plain_ms = None
+    if image is not None:   # the same GEMM on the plain operands, same process, same minute: what the images buy on this box
+        xq_plain = qa.plain_xq()
+        tp = timed(lambda: ops.linear_w8a8(xq_plain, w, x.dtype, ds, s_row, None, bias, out=out))
+        plain_ms = sum(tp) / len(tp)
+        del xq_plain
+    ts = timed(launch)
     M, K = x.shape
-    return sum(ts) / len(ts), ts[0], ops.gemm_kernel_name(M, w.shape[0], K), image is not None
+    return sum(ts) / len(ts), ts[0], ops.gemm_kernel_name(M, w.shape[0], K), plain_ms
 
 
 def pmc_traffic(kernel_key, M, N, K):
@@ -713,13 +723,13 @@ def main():
             eb.synchronize()
             avg_ms = min_ms = ea.elapsed_time(eb) / 10
             kname, lbl, kind, K, N, aq, bias, M_k = "p8", "w1 grouped x8", "linear", 4096, 14336, "per-tensor", False, M
-            on_images = False
+            plain_ms = None
         elif layer_mode:
             xin = (torch.randn(min(M, 8192), K, device=device) * 40).to(tdt)
-            avg_ms, min_ms, kname, on_images = measure_dominant_kernel(getattr(mods[0], lbl + "_proj"), xin)
+            avg_ms, min_ms, kname, plain_ms = measure_dominant_kernel(getattr(mods[0], lbl + "_proj"), xin)
             M_k = xin.shape[0]
         else:
-            avg_ms, min_ms, kname, on_images = measure_dominant_kernel(mods[lbl], xs[(K, aq, kind)])
+            avg_ms, min_ms, kname, plain_ms = measure_dominant_kernel(mods[lbl], xs[(K, aq, kind)])
             M_k = M
         ops_k = 2.0 * M_k * N * K
         esz = {"f16": 2, "bf16": 2, "f32": 4}[args.dtype]
@@ -744,7 +754,8 @@ def main():
                          "traffic": pmc_traffic(f"gemm_i8_{kname}<asq::EpiDequant<{ {'f32': 0, 'f16': 1, 'bf16': 2}[args.dtype] }, {'true' if aq == 'per-token' else 'false'}, false, {'true' if bias else 'false'}>", M_k, N, K),
                          "kernel": f"gemm_i8_{kname}<{'EpiFp8' if (moe_mode and args.fp8) else 'EpiDequant'} {args.dtype}> [{lbl}] M={M_k} N={N} K={K}",
                          "avg_us": round(avg_ms * 1e3, 2), "min_us": round(min_ms * 1e3, 2),
-                         "operands": "offset images (x + cx[m], w + cw[n]; accumulators start at the exact correction: same int32 result, include/asq_hip.h)" if on_images else "plain int8",
+                         "operands": "offset images (x + cx[m], w + cw[n]; the exact rank-1 correction precedes the epilogue: same int32 result, include/asq_hip.h)" if plain_ms else "plain int8",
+                         "plain_operands_avg_us": round(plain_ms * 1e3, 2) if plain_ms else None,
                          "algorithmic_ops": ops_k, "algorithmic_bytes": bytes_k,
                          "tops": round(ops_k / (avg_ms * 1e-3) / 1e12, 1),
                          "frac_of_ubench_ceiling_4404": round(achieved / 4404.0, 4) if bound == "mfma" else None,

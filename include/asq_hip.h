@@ -224,6 +224,8 @@ int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t *w, void *o
  *                             column remainder launch) and the limits above hold; ASQ_OFFSETS=0 in the environment makes it return 0.
  *   asq_linear_w8a8_forward_off  asq_linear_w8a8_forward with the weight's image: uses the offset path when asq_offsets_supported() and the
  *                             workspace has asq_linear_w8a8_workspace_bytes(); otherwise it IS asq_linear_w8a8_forward (w_off / col_off may be NULL).
+ *   asq_norm_quantize_off / asq_add_norm_quantize_off / asq_silu_mul_quantize_off   the N1 fusions (same arithmetic, same arguments + row_off) emitting
+ *                             the offset image of their int8 result: xq' - cx[m] is exactly what asq_norm_quantize / ... write.
  * Development overrides (read once): ASQ_OFF_CX (default 3), ASQ_OFF_CW (default 64). */
 int asq_weight_offset_image(const int8_t *w, int64_t N, int64_t K, int8_t *w_off, int32_t *col_off, void *stream);
 int asq_quantize_act_off(const void *x, int x_dtype, int mode, float quant_scale,
@@ -233,6 +235,12 @@ int asq_linear_w8a8_off(const int8_t *xq_off, const int8_t *w_off, void *out, in
                         float s_scalar, const float *s_row, const float *s_col, const float *bias, int epi_order,
                         const int32_t *row_off, const int32_t *col_off, void *stream);
 int asq_offsets_supported(int64_t M, int64_t N, int64_t K, int out_dtype);
+int asq_norm_quantize_off(const void *x, int x_dtype, const void *weight, const void *bias, float eps, int per_token,
+                          int8_t *xq_off, float *s_row, int32_t *row_off, int64_t M, int64_t K, void *stream);
+int asq_add_norm_quantize_off(const void *x, const void *residual, void *h_out, int x_dtype, const void *weight, const void *bias,
+                              float eps, int per_token, int8_t *xq_off, float *s_row, int32_t *row_off, int64_t M, int64_t K, void *stream);
+int asq_silu_mul_quantize_off(const void *gate, const void *up, int x_dtype, int per_token, float quant_scale,
+                              int8_t *xq_off, float *s_row, int32_t *row_off, int64_t M, int64_t K, void *stream);
 int asq_linear_w8a8_forward_off(const void *x, int x_dtype, const int8_t *w, const int8_t *w_off, const int32_t *col_off, void *out,
                                 int64_t M, int64_t N, int64_t K,
                                 int act_mode, float quant_scale,

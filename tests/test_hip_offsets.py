@@ -176,3 +176,58 @@ def test_image_follows_the_weight():
     assert m.offset_image(2304, torch.float16) is not img0
     m.offsets = False
     assert torch.equal(y1, m(x)) and not torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("per_token", [False, True])
+def test_n1_quantisers_emit_the_offset_image(dt, per_token):
+    """asq_norm_quantize_off / asq_add_norm_quantize_off / asq_silu_mul_quantize_off: the image of exactly what the plain entry points write"""
+    from autosmoothquant_amd import ops
+    rng = np.random.default_rng(21)
+    for (M, K) in ((3, 64), (33, 4096), (9, 8192), (130, 1024)):
+        if dt == "f32" and K > 4096:
+            continue
+        x = O.round_to(rng.standard_normal((M, K)).astype(np.float32) * 3.0, dt)
+        x[:, 5 % K] *= 12.0
+        res = O.round_to(rng.standard_normal((M, K)).astype(np.float32), dt)
+        w = O.round_to((rng.standard_normal(K).astype(np.float32) * 0.1 + 1.0) / 0.04, dt)
+        b = O.round_to(rng.standard_normal(K).astype(np.float32) * 3.0, dt)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(TDT[dt])
+        for bias in (None, b):
+            xq, s = ops.norm_quantize(t(x), t(w), None if bias is None else t(bias), 1e-5, per_token)
+            xo, s2, ro = ops.norm_quantize(t(x), t(w), None if bias is None else t(bias), 1e-5, per_token, offsets=True)
+            rx, rr = OFF.act_image(xq.cpu().numpy())
+            assert np.array_equal(xo.cpu().numpy(), rx) and np.array_equal(ro.cpu().numpy(), rr), ("norm", M, K)
+            assert (s is None and s2 is None) or torch.equal(s, s2)
+            h, xq, s = ops.add_norm_quantize(t(x), t(res), t(w), None if bias is None else t(bias), 1e-5, per_token)
+            h2, xo, s2, ro = ops.add_norm_quantize(t(x), t(res), t(w), None if bias is None else t(bias), 1e-5, per_token, offsets=True)
+            rx, rr = OFF.act_image(xq.cpu().numpy())
+            assert torch.equal(h, h2) and np.array_equal(xo.cpu().numpy(), rx) and np.array_equal(ro.cpu().numpy(), rr), ("add_norm", M, K)
+        g = O.round_to(rng.standard_normal((M, K)).astype(np.float32) * 2.0, dt)
+        u = O.round_to(rng.standard_normal((M, K)).astype(np.float32) * 2.0, dt)
+        for fast in (False, True):
+            xq, s = ops.silu_mul_quantize(t(g), t(u), per_token, 0.05, fast)
+            xo, s2, ro = ops.silu_mul_quantize(t(g), t(u), per_token, 0.05, fast, offsets=True)
+            rx, rr = OFF.act_image(xq.cpu().numpy())
+            assert np.array_equal(xo.cpu().numpy(), rx) and np.array_equal(ro.cpu().numpy(), rr), ("silu", M, K, fast)
+
+
+def test_fused_llama_layer_with_and_without_images_is_identical():
+    """the N1-fused layer at a prefill size (the norms and SiLU*up emit offset images, q/k/v/gate/up/down consume them) == the same layer with offsets off"""
+    from autosmoothquant_amd import harness as H
+    import autosmoothquant_amd.layers.nn.linear as LN
+    torch.manual_seed(0)
+    layer = H.init_llama_layer(H.LlamaLayer(hidden=1024, inter=2816, heads=8), seed=3).to(DEV)
+    x = torch.randn(2, 2048, 1024, device=DEV)
+    scales = H.calibrate(layer.float(), x[:, :128].float())
+    q = H.to_w8a8(layer.half(), scales, both=True)
+    q.use_fused = True
+    xin = x.half()
+    y_img = q(xin)
+    seen = [m for m in q.modules() if isinstance(m, LN._W8A8Base) and m.__dict__.get("_offset_cache") is not None]
+    for m in q.modules():
+        if isinstance(m, LN._W8A8Base):
+            m.offsets = False
+    y_plain = q(xin)
+    assert torch.equal(y_img, y_plain)
+    assert len(seen) > 0   # (4096 rows on 1024-wide weights: 64 x 4 = 64 tiles of 256 x 256 for the 1024-wide projections, 176 for gate / up of 256 x 256 -- whether the dispatcher takes the 256 x 256 kernel decides; asserted so the test cannot pass vacuously)

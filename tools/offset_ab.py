@@ -22,6 +22,7 @@ ap.add_argument("--cx", type=int, default=3)
 ap.add_argument("--batch", type=int, default=50)
 ap.add_argument("--rounds", type=int, default=8)
 ap.add_argument("--kernel", default=None)
+ap.add_argument("--per-token", action="store_true", help="per-token quantised activations (every row reaches +-127) and the row-scale epilogue")
 ap.add_argument("--arms", default=None, help="comma-separated subset of the arms")
 args = ap.parse_args()
 if args.kernel:
@@ -41,12 +42,22 @@ for sh in args.shapes.split(","):
     xf = torch.randn(M, K, device=dev, generator=g)
     ch = torch.rand(K, device=dev, generator=g) < 0.01
     xf[:, ch] *= 20.0
-    x = (xf / (xf.abs().max() / 127.0)).round().clamp(-128, 127).to(torch.int8)
+    if args.per_token:
+        rs = xf.abs().max(dim=1, keepdim=True).values / 127.0
+        x = (xf / rs).round().clamp(-128, 127).to(torch.int8)
+        s_row_t = rs.flatten().float().contiguous()
+    else:
+        x = (xf / (xf.abs().max() / 127.0)).round().clamp(-128, 127).to(torch.int8)
+        s_row_t = None
     wf = torch.randn(N, K, device=dev, generator=g) * 0.02
     w = (wf / (wf.abs().max() / 127.0)).round().clamp(-128, 127).to(torch.int8)
     del xf, wf
     cw = (127 - w.max(dim=1).values.int()).clamp(max=args.cap)
-    if args.cx >= 0:
+    if args.per_token:   # the library's rule: +C if it fits, else -C, else 0
+        rmax, rmin = x.max(dim=1).values.int(), x.min(dim=1).values.int()
+        C = abs(args.cx)
+        cx = torch.where(rmax <= 127 - C, torch.full_like(rmax, C), torch.where(rmin >= -128 + C, torch.full_like(rmax, -C), torch.zeros_like(rmax)))
+    elif args.cx >= 0:
         cx = (127 - x.max(dim=1).values.int()).clamp(max=args.cx)
     else:
         cx = (-128 - x.min(dim=1).values.int()).clamp(min=args.cx)   # negative offsets: products and partial sums mostly negative, start values positive
@@ -68,20 +79,22 @@ for sh in args.shapes.split(","):
     zr, zc = torch.zeros_like(row_off), torch.zeros_like(col_off)
     row_off = row_off.contiguous(); col_off = col_off.contiguous()
     ref = torch.empty_like(out)
-    assert h.asq_linear_w8a8(x.data_ptr(), w.data_ptr(), ref.data_ptr(), 1, M, N, K, 1.25e-4, None, None, None, 0, None, 0, stream) == 0
-    got = ops.linear_w8a8_off(x_img, w_img, row_off, col_off, torch.float16, 1.25e-4)
+    assert h.asq_linear_w8a8(x.data_ptr(), w.data_ptr(), ref.data_ptr(), 1, M, N, K, 1.25e-4, s_row_t.data_ptr() if s_row_t is not None else None, None, None, 0, None, 0, stream) == 0
+    got = ops.linear_w8a8_off(x_img, w_img, row_off, col_off, torch.float16, 1.25e-4, s_row_t)
     print("  asq_linear_w8a8_off == asq_linear_w8a8:", torch.equal(ref, got), flush=True)
     off_arms = {"off_exact": (w_img, x_img, row_off, col_off), "off_start0": (w_img, x_img, zr, zc), "off_plainops": (w, x, zr, zc)}
     for a in off_arms:
         arms[a] = None
 
+    sr = s_row_t.data_ptr() if s_row_t is not None else None
+
     def call(a):
         if a in off_arms:
             ww, xx, ro, co = off_arms[a]
-            rc = h.asq_linear_w8a8_off(xx.data_ptr(), ww.data_ptr(), out.data_ptr(), 1, M, N, K, 1.25e-4, None, None, None, 0, ro.data_ptr(), co.data_ptr(), stream)
+            rc = h.asq_linear_w8a8_off(xx.data_ptr(), ww.data_ptr(), out.data_ptr(), 1, M, N, K, 1.25e-4, sr, None, None, 0, ro.data_ptr(), co.data_ptr(), stream)
         else:
             ww, xx = arms[a]
-            rc = h.asq_linear_w8a8(xx.data_ptr(), ww.data_ptr(), out.data_ptr(), 1, M, N, K, 1.25e-4, None, None, None, 0, None, 0, stream)
+            rc = h.asq_linear_w8a8(xx.data_ptr(), ww.data_ptr(), out.data_ptr(), 1, M, N, K, 1.25e-4, sr, None, None, 0, None, 0, stream)
         assert rc == 0, h.asq_last_error()
 
     if args.arms:
@@ -101,11 +114,11 @@ for sh in args.shapes.split(","):
             e1.synchronize()
             if r >= 1:
                 ts[a].append(e0.elapsed_time(e1) / args.batch * 1e3)
-    ops = 2.0 * M * N * K
+    nops = 2.0 * M * N * K
     base = sorted(ts["base"])[len(ts["base"]) // 2]
     for a in names:
         t = sorted(ts[a])
         med = t[len(t) // 2]
         if os.environ.get("AB_SAMPLES"):
             print("      samples:", " ".join(f"{v:.1f}" for v in ts[a]))
-        print(f"  {a:12s} median {med:7.2f} us (min {t[0]:7.2f}) = {ops / med / 1e6:6.0f} TOPS = {ops / med / 1e6 / 50.33:5.1f} % of 5033   vs base {med / base:.4f}", flush=True)
+        print(f"  {a:12s} median {med:7.2f} us (min {t[0]:7.2f}) = {nops / med / 1e6:6.0f} TOPS = {nops / med / 1e6 / 50.33:5.1f} % of 5033   vs base {med / base:.4f}", flush=True)
