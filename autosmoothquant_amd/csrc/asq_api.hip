@@ -51,10 +51,14 @@ extern "C" int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t 
     ASQ_REQUIRE(workspace != nullptr && workspace_bytes >= need, ASQ_ERR_WORKSPACE,
                 "asq_linear_w8a8_forward: workspace %zu B < required %zu B", workspace_bytes, need);
     ASQ_REQUIRE(((uintptr_t)workspace & 255) == 0, ASQ_ERR_ALIGN, "asq_linear_w8a8_forward: workspace must be 256-B aligned");
-    const size_t gbytes = forward_gemm_part(M, N, K);
-    const bool full = workspace_bytes >= gbytes + need;  // a smaller buffer is [ xq | s_row ] only: no header, no GEMM scratch
+    // Layout by size (never put activations over a header other calls rely on):
+    //   >= gemm part + need : [ header + GEMM scratch | xq | s_row ]   (the full layout)
+    //   >= header + need    : [ header | xq | s_row ], the GEMM runs without scratch -- the header of a shared, initialised buffer stays intact
+    //   >= need             : [ xq | s_row ] from offset 0: a private scratch buffer without a header (first-generation kernels only)
+    const size_t gbytes = forward_gemm_part(M, N, K), hdr = round_up(asq_workspace_header_bytes(), 256);
+    const bool full = workspace_bytes >= gbytes + need;
     const bool with_gemm_ws = full && asq_gemm_workspace_bytes(M, N, K) > 0;
-    char *base = (char *)workspace + (full ? gbytes : 0);
+    char *base = (char *)workspace + (full ? gbytes : (workspace_bytes >= hdr + need ? hdr : 0));
     int8_t *xq = (int8_t *)base;
     float *s_row = (float *)(base + round_up((size_t)M * (size_t)K, 256));
     int rc = asq_quantize_act(x, x_dtype, act_mode, quant_scale, xq, s_row, M, K, stream);

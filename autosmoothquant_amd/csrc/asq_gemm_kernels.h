@@ -1496,6 +1496,12 @@ int launch_gemm(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t 
                 size_t ws_bytes = 0, const int *goffs = nullptr, int ngroups = 0, OffsetArgs off = OffsetArgs{})
 {
     const bool has = ws != nullptr && ws_bytes >= (size_t)WS_HEADER_BYTES && (((uintptr_t)ws) & 15) == 0;
+    if (has && asq_debug_sync()) {   // ASQ_DEBUG_SYNC=1: an uninitialised workspace is an error code here instead of a device trap in the kernels that use its tickets
+        unsigned long long magic = 0;
+        hipError_t e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = hipMemcpy(&magic, ws, sizeof(magic), hipMemcpyDeviceToHost);
+        ASQ_REQUIRE(e == hipSuccess && magic == WS_MAGIC, ASQ_ERR_WORKSPACE, "%s: workspace header not initialised (asq_workspace_init)", what);
+    }
     return launch_gemm_impl(x, w, M, N, K, epi, s, what, has ? ws : nullptr, has ? (char *)ws + WS_HEADER_BYTES : nullptr, has ? ws_bytes - WS_HEADER_BYTES : 0, goffs,
                             ngroups, 0, off);
 }

@@ -529,9 +529,26 @@ class MixtralLayer(LlamaLayer):
             st = torch.stack([m.weight for m in mods]).contiguous()
             for i, m in enumerate(mods):
                 m._buffers["weight"] = st[i]
+            host = [float(m._buffers["dequant_scale"]) for m in mods]
             setattr(self, f"_{name}_stack", st)
-            setattr(self, f"_{name}_scale", torch.tensor([float(m._buffers["dequant_scale"]) for m in mods], dtype=torch.float32, device=st.device))
+            setattr(self, f"_{name}_scale", torch.tensor(host, dtype=torch.float32, device=st.device))
+            self.__dict__[f"_{name}_scale_host"] = host
         return self
+
+    def _stacks_current(self):
+        """The per-expert modules stay the source of truth (state_dict, load_state_dict, .to(), replica.broadcast_quantized all act on THEIR buffers): the
+        stacks are current iff every expert's `weight` is still the stack's own row block and its dequant scale the recorded one.  Anything that re-homes
+        a buffer (QuantArena.pack, Module.to) or rewrites a scale leaves a mismatch here, and moe() restacks before the grouped launch."""
+        for name in ("w1", "w3", "w2"):
+            st, host = getattr(self, f"_{name}_stack", None), self.__dict__.get(f"_{name}_scale_host")
+            if st is None or host is None or st.shape[0] != len(self.experts):
+                return False
+            for i, e in enumerate(self.experts):
+                m = getattr(e, name)
+                w = m._buffers["weight"]
+                if w.device != st.device or w.data_ptr() != st[i].data_ptr() or float(m._buffers["dequant_scale"]) != host[i]:
+                    return False
+        return True
 
     def moe(self, x):
         B, S, H = x.shape
@@ -541,6 +558,8 @@ class MixtralLayer(LlamaLayer):
         ex = self.experts
         grouped = (hasattr(self, "_w1_stack") and ex[0].w2.act_quant == "per-token" and xs.is_cuda
                    and H % 128 == 0 and self._w2_stack.shape[-1] % 128 == 0)   # (the grouped launch runs on the tiled kernel: K % 128 == 0)
+        if grouped and not self._stacks_current():   # a buffer was re-homed or a scale rewritten since stack_experts(): rebuild from the per-expert modules
+            self.stack_experts()
         if grouped:
             from . import ops
             offs = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int32)

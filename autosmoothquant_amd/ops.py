@@ -104,6 +104,16 @@ def _workspace(lib, size_fn, M, N, K, dev, stream):
     return res
 
 
+def release_workspaces():
+    """Drop this thread's cached workspaces (per-stream GEMM slots, retired slots, the 64 MiB grouped-launch buffers).  They are otherwise kept for the life of
+    the thread: a captured hipGraph may replay launches that point at them.  Call it only when no captured graph that used this thread's ops will be replayed
+    again and the streams are idle; the next call re-creates (and re-initialises) what it needs.
+    Graph note: a graph captured on stream A bakes A's slot into its launches -- replay it serialised with A (same stream, or ordered by events); replayed
+    concurrently with eager calls or another graph on A it shares one ticket header with them, which the kernels answer with a trap."""
+    _ws_tls.__dict__.pop("c", None)
+    _ws_tls.__dict__.pop("retired", None)
+
+
 def _grouped_ws(lib, M, N, K, G, dev, stream):
     """workspace of a grouped launch (asq_grouped_workspace_bytes: header + 64 MiB of K-piece images, one size for every shape that uses it):
     one persistent, initialised buffer per (thread, device, stream), separate from the GEMM slot; under stream capture without a warmed-up

@@ -42,9 +42,6 @@ def _quant_modules(root):
     return [m for m in root.modules() if isinstance(m, (_W8A8Base, _FP8Base))]
 
 
-_w8a8_modules = _quant_modules  # (old name)
-
-
 def _pad(n, a=_ALIGN):
     return (n + a - 1) // a * a
 

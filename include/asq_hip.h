@@ -192,9 +192,9 @@ int asq_linear_w8a8_grouped_ws(const int8_t *xq, const int8_t *w, void *out, int
 /* ---- whole module forward: W8A8BFP32OFP32Linear / ...QKVLinear / ...LinearWithQuantScale .forward
  * (linear.py:83-106, :158-208, :278-302) = asq_quantize_act + asq_linear_w8a8 on `stream`.
  * out has x's dtype.  workspace: asq_linear_w8a8_workspace_bytes(M,N,K) bytes = [ header + GEMM scratch | int8 activations | row scales ],
- * 256-B aligned; the header part is reserved for EVERY shape, so an initialised buffer can be shared by calls of any shape.  A buffer
- * smaller than that (>= the activation + scale part) is used as [ activations | scales ] from offset 0 and the GEMM runs without scratch:
- * never pass a truncated size for a buffer whose header other calls rely on. */
+ * 256-B aligned; the header part is reserved for EVERY shape, so an initialised buffer can be shared by calls of any shape.  Smaller buffers: with room for
+ * header + activations + scales the layout is [ header | activations | scales ] and the GEMM runs without scratch (a shared buffer's header stays intact);
+ * only a buffer smaller than that is used as [ activations | scales ] from offset 0 -- a private scratch buffer that never had a header. */
 size_t asq_linear_w8a8_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t *w, void *out,
                             int64_t M, int64_t N, int64_t K,
