@@ -150,3 +150,85 @@ def parse_quant_config(config_path):
     if bad:
         raise ValueError(f"quant_config: unknown act_quant values {bad}")
     return cfg
+
+
+# ---- the reference's dataset / tokenizer entry points (quantize/calibration.py:44-88, :185-244, :292-339): thin adapters over the collectors above -----------
+def dataset_batches(tokenizer, dataset_path, num_samples, seq_len, device=None):
+    """The model inputs the reference's calibration loops build: `load_dataset("json", data_files=dataset_path, split="train").shuffle(seed=42)`, the first
+    num_samples texts through `tokenizer(text, return_tensors="pt", max_length=seq_len, truncation=True).input_ids` (calibration.py:73-85)."""
+    from datasets import load_dataset
+    dataset = load_dataset("json", data_files=dataset_path, split="train").shuffle(seed=42)
+    for i in range(num_samples):
+        ids = tokenizer(dataset[i]["text"], return_tensors="pt", max_length=seq_len, truncation=True).input_ids
+        yield ids.to(device) if device is not None else ids
+
+
+def _model_device(model):
+    p = next(model.parameters(), None)
+    return p.device if p is not None else None
+
+
+def get_act_scales_from_dataset(model, tokenizer, dataset_path, num_samples=512, seq_len=512):
+    """`get_act_scales(model, tokenizer, dataset_path, num_samples, seq_len)` with the reference's signature (calibration.py:44)."""
+    return get_act_scales(model, dataset_batches(tokenizer, dataset_path, num_samples, seq_len, _model_device(model)))
+
+
+def get_static_decoder_layer_scales_from_dataset(model, tokenizer, dataset_path, num_samples=512, seq_len=512, model_type="transformers"):
+    """The reference's `get_static_decoder_layer_scales(model, tokenizer, dataset_path, num_samples, seq_len, model_type)` (calibration.py:185-244):
+    num_layers and num_local_experts come from model.config as there."""
+    cfg = model.config
+    return get_static_decoder_layer_scales(model, dataset_batches(tokenizer, dataset_path, num_samples, seq_len, _model_device(model)), cfg.num_hidden_layers,
+                                           model_type, getattr(cfg, "num_local_experts", 0))
+
+
+def replace_module(model, name, new_module):
+    """setattr on the parent of the dotted module path `name` (reference calibration.py:247-256)."""
+    if "." in name:
+        parent_name, child_name = name.rsplit(".", 1)
+        parent = model.get_submodule(parent_name)
+    else:
+        parent, child_name = model, name
+    setattr(parent, child_name, new_module)
+
+
+def get_layers_to_ignore(model, ignore_patterns):
+    """Names of the nn.Linear modules matched by the patterns: "re:<regex>" -> re.search on the name, anything else an exact name
+    (reference calibration.py:259-279)."""
+    import re
+    ignored = set()
+    for name, linear in model.named_modules():
+        if not isinstance(linear, torch.nn.Linear):
+            continue
+        for pat in ignore_patterns:
+            if pat.startswith("re:"):
+                if re.search(pat[3:], name):
+                    ignored.add(name)
+            elif pat == name:
+                ignored.add(name)
+    return list(ignored)
+
+
+@torch.no_grad()
+def quantize_activations_fp8(model, tokenizer=None, calibration_path=None, ignore_patterns=(), num_samples=None, batches=None):
+    """fp8 (e4m3) STATIC activation calibration, the reference's function of the same name (calibration.py:292-339): every nn.Linear that no pattern
+    ignores becomes an FP8StaticLinearQuantizer over its per-tensor-quantised weight (weight_scale = absmax / 448), then the calibration inputs run
+    through the model and each quantizer keeps the running maximum of its dynamic per-tensor input scale.  Afterwards FP8LinearStatic.from_float(quantizer)
+    freezes a module.  Inputs: the reference's (tokenizer, calibration_path, num_samples) -- max_length 1024 as there -- or `batches`, any iterable of
+    model inputs.  The model must live on the HIP device: the quantizers run the library's fp8 quantiser and GEMM."""
+    import copy
+    from ..layers.nn.linear import FP8StaticLinearQuantizer
+    from ..layers.functional.quantization import per_tensor_quantize_fp8
+    ignored = set(get_layers_to_ignore(model, list(ignore_patterns)))
+    for name, linear in list(model.named_modules()):
+        if not isinstance(linear, torch.nn.Linear) or name in ignored:
+            continue
+        qw, ws = per_tensor_quantize_fp8(linear.weight)
+        bias = copy.deepcopy(linear.bias) if linear.bias is not None else None
+        replace_module(model, name, FP8StaticLinearQuantizer(linear.in_features, linear.out_features, weight=qw.to(linear.weight.device), weight_scale=ws, bias=bias,
+                                                             quantize_output=False))
+    if batches is None:
+        if tokenizer is None or calibration_path is None or num_samples is None:
+            raise ValueError("quantize_activations_fp8: pass (tokenizer, calibration_path, num_samples) or batches")
+        batches = dataset_batches(tokenizer, calibration_path, num_samples, 1024, _model_device(model))
+    _run(model, batches)
+    return model

@@ -36,3 +36,50 @@ def smooth_ln_fcs(ln, fcs, act_scales, model_type="transformers", alpha=0.5):
     for fc in fcs:
         fc.weight.mul_(s.view(1, -1))
     return s
+
+
+def _layer_kind(m):
+    """Which decoder-layer family a module is, by the attribute names the reference's isinstance checks stand for (quantize/smooth.py:42-93 tests
+    OPTDecoderLayer / LlamaDecoderLayer / BaichuanLayer / MixtralDecoderLayer of a pinned transformers version)."""
+    attn = getattr(m, "self_attn", None)
+    if attn is None:
+        return None
+    if hasattr(m, "self_attn_layer_norm") and hasattr(m, "fc1") and hasattr(attn, "q_proj"):
+        return "transformers"
+    if hasattr(m, "input_layernorm") and hasattr(m, "post_attention_layernorm"):
+        if hasattr(m, "block_sparse_moe"):
+            return "mixtral"
+        if hasattr(attn, "W_pack"):
+            return "baichuan"
+        if hasattr(getattr(m, "mlp", None), "gate_proj") and hasattr(attn, "q_proj"):
+            return "llama"
+    return None
+
+
+@torch.no_grad()
+def smooth_lm(model, scales, alpha=0.5):
+    """The reference's per-architecture walk (quantize/smooth.py:42-93): for every decoder layer, migrate the activation outliers of the attention input into
+    q/k/v (or W_pack) and of the MLP input into fc1 / gate+up / the router and every expert's w1, w3.  scales: get_act_scales' dict
+    {linear module name: per-channel absmax}.  Returns the number of layers smoothed."""
+    n = 0
+    for name, m in model.named_modules():
+        kind = _layer_kind(m)
+        if kind == "transformers":
+            smooth_ln_fcs(m.self_attn_layer_norm, [m.self_attn.q_proj, m.self_attn.k_proj, m.self_attn.v_proj], scales[name + ".self_attn.q_proj"], kind, alpha)
+            smooth_ln_fcs(m.final_layer_norm, m.fc1, scales[name + ".fc1"], kind, alpha)
+        elif kind == "llama":
+            smooth_ln_fcs(m.input_layernorm, [m.self_attn.q_proj, m.self_attn.k_proj, m.self_attn.v_proj], scales[name + ".self_attn.q_proj"], kind, alpha)
+            smooth_ln_fcs(m.post_attention_layernorm, [m.mlp.gate_proj, m.mlp.up_proj], scales[name + ".mlp.gate_proj"], kind, alpha)
+        elif kind == "baichuan":
+            smooth_ln_fcs(m.input_layernorm, m.self_attn.W_pack, scales[name + ".self_attn.W_pack"], kind, alpha)
+            smooth_ln_fcs(m.post_attention_layernorm, [m.mlp.gate_proj, m.mlp.up_proj], scales[name + ".mlp.gate_proj"], kind, alpha)
+        elif kind == "mixtral":
+            smooth_ln_fcs(m.input_layernorm, [m.self_attn.q_proj, m.self_attn.k_proj, m.self_attn.v_proj], scales[name + ".self_attn.q_proj"], kind, alpha)
+            fcs = [m.block_sparse_moe.gate]
+            for e in m.block_sparse_moe.experts:
+                fcs += [e.w1, e.w3]
+            smooth_ln_fcs(m.post_attention_layernorm, fcs, scales[name + ".block_sparse_moe.gate"], kind, alpha)
+        else:
+            continue
+        n += 1
+    return n

@@ -387,19 +387,87 @@ def pmc_traffic(kernel_key, M, N, K):
     return best
 
 
-def cpu_baseline(spec, M_sample, dtype_tag, budget_s=8.0, mods=None, xs=None):
-    """The oracle's module forwards on the host cores, on the first M_sample rows of the SAME workload -- the step's own quantised
-    weights, scales and activations copied from the device when `mods` / `xs` are given (synthetic stand-ins of the same shapes
-    otherwise).  Deterministic legs (round 2 picked the backend from one probe timing and two boxes disagreed):
-      primary   torch._int_mm, all host threads  (~budget_s of CPU work after one untimed pass)   -> `value`
-      secondary torch._int_mm, 1 thread;  the plain-C OpenMP GEMM (oracle/igemm_ref.c), all threads  (~budget_s / 3 each)
+def host_topology():
+    """(sockets, physical cores, hardware threads) of this host from /sys (lscpu's numbers); falls back to os.cpu_count()."""
+    import glob
+    cores, pkgs, n = set(), set(), 0
+    for d in glob.glob("/sys/devices/system/cpu/cpu[0-9]*/topology"):
+        try:
+            pk, co = open(d + "/physical_package_id").read().strip(), open(d + "/core_id").read().strip()
+        except OSError:
+            continue
+        n += 1
+        pkgs.add(pk)
+        cores.add((pk, co))
+    if not n:
+        n = os.cpu_count() or 1
+        return 1, n, n
+    return max(len(pkgs), 1), max(len(cores), 1), n
+
+
+def cpu_leg(path, backend, threads, budget_s):
+    """One leg of the CPU baseline, run in its OWN process (bench.py --cpu-leg): the OpenMP runtime reads OMP_NUM_THREADS / OMP_PLACES / OMP_PROC_BIND once, at
+    start-up, so pinning needs a fresh process.  Loads the operands the parent saved, times whole-oracle passes for ~budget_s, prints one JSON line."""
+    import numpy as np
+    from oracle import w8a8 as O
+    z = np.load(path, allow_pickle=False)
+    n = int(z["n"])
+    data = []
+    for i in range(n):
+        kind, aq = str(z[f"kind{i}"]), str(z[f"aq{i}"])
+        b = z[f"b{i}"] if f"b{i}" in z.files else None
+        data.append((kind, aq, z[f"w{i}"], z[f"x{i}"].astype(np.float32), b, float(z[f"ds{i}"]), float(z[f"qs{i}"])))
+    dtype_tag = str(z["dtype"])
+    O.set_igemm_backend(backend)
+    torch.set_num_threads(threads)
+
+    def one_pass():
+        t0 = time.perf_counter()
+        for kind, aq, wq, x, b, ds, qs in data:
+            if kind == "linear":
+                O.linear_forward(x, dtype_tag, wq, ds, b, aq)
+            else:
+                O.linear_with_quant_scale_forward(x, dtype_tag, wq, ds, qs, b, aq)
+        return time.perf_counter() - t0
+
+    one_pass()   # untimed: page-in, thread pool start
+    ts = []
+    while sum(ts) < budget_s and len(ts) < 2000:
+        ts.append(one_pass())
+    ts.sort()
+    ops_pass = sum(2.0 * x.shape[0] * wq.shape[0] * wq.shape[1] for (_k, _a, wq, x, *_r) in data)
+    med = ts[len(ts) // 2]
+    # the integer GEMM alone (the oracle's quantise / dequantise around it is single-threaded NumPy): what the host cores do on the matrix product itself
+    gt = []
+    for kind, aq, wq, x, b, ds, qs in data:
+        xq = O.act_quant_per_token(x, dtype_tag)[0] if aq == "per-token" else (O.act_quant_round(x, dtype_tag) if kind == "linear" else O.act_quant_div(x, dtype_tag, qs))
+        O.igemm(xq, wq)
+        reps = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.igemm(xq, wq)
+            reps.append(time.perf_counter() - t0)
+        gt.append(min(reps))
+    print(json.dumps({"backend": backend, "threads": threads, "reps": len(ts), "TOPS_median": round(ops_pass / med / 1e12, 5), "TOPS_mean": round(ops_pass * len(ts) / sum(ts) / 1e12, 5),
+                      "gemm_only_TOPS": round(ops_pass / sum(gt) / 1e12, 5),
+                      "tokens_per_s": round(data[0][3].shape[0] / med, 1), "s_total": round(sum(ts), 2), "omp_places": os.environ.get("OMP_PLACES"), "omp_proc_bind": os.environ.get("OMP_PROC_BIND")}), flush=True)
+
+
+def cpu_baseline(spec, M_sample, dtype_tag, budget_s=20.0, mods=None, xs=None):
+    """The oracle's module forwards on the host cores at the step's FULL row count (M_sample = M) -- the step's own quantised weights, scales and activations
+    copied from the device when `mods` / `xs` are given (synthetic stand-ins of the same shapes otherwise).  Fixed legs, each in its own pinned process
+    (OMP_PLACES=cores, OMP_PROC_BIND=close; VERDICT r3 item 6: an all-thread leg that is 10x slower than one thread is mis-configured, not measured):
+        torch._int_mm on {the physical cores of one socket, all physical cores, all hardware threads}   -> the best is `value`, `cores` its thread count
+        torch._int_mm on 1 thread; the plain-C OpenMP GEMM (oracle/igemm_ref.c) on all physical cores    (secondary)
     All backends are bit-identical exact integer GEMMs; the quantise / dequantise around them is the NumPy restatement."""
+    import subprocess
+    import tempfile
     import numpy as np
     from oracle import w8a8 as O
     rng = np.random.default_rng(0)
-    data = []
     real = mods is not None and xs is not None and all(l in mods for (l, *_r) in spec)
-    for label, kind, K, N, aq, bias in spec:
+    arrs = {"n": np.int64(len(spec)), "dtype": np.str_(dtype_tag)}
+    for i, (label, kind, K, N, aq, bias) in enumerate(spec):
         if real:
             m = mods[label]
             wq = m.weight.detach().cpu().numpy()
@@ -412,47 +480,34 @@ def cpu_baseline(spec, M_sample, dtype_tag, budget_s=8.0, mods=None, xs=None):
             x = O.round_to((rng.standard_normal((M_sample, K)) * 40).astype(np.float32), dtype_tag)
             b = rng.standard_normal(N).astype(np.float32) if bias else None
             ds, qs = 1e-4, 0.5
-        data.append((kind, K, N, aq, wq, x, b, ds, qs))
-
-    def one_pass():
-        t0 = time.perf_counter()
-        for kind, K, N, aq, wq, x, b, ds, qs in data:
-            if kind == "linear":
-                O.linear_forward(x, dtype_tag, wq, ds, b, aq)
-            else:
-                O.linear_with_quant_scale_forward(x, dtype_tag, wq, ds, qs, b, aq)
-        return time.perf_counter() - t0
-
-    ops_pass = sum(2.0 * M_sample * N * K for (_k, K, N, *_r) in data)
-    ncpu = os.cpu_count() or 1
-
-    def leg(backend, threads, budget):
-        try:
-            O.set_igemm_backend(backend)
-            prev = torch.get_num_threads()
-            torch.set_num_threads(threads)
-            os.environ["OMP_NUM_THREADS"] = str(threads)
+        arrs[f"kind{i}"], arrs[f"aq{i}"], arrs[f"w{i}"], arrs[f"ds{i}"], arrs[f"qs{i}"] = np.str_(kind), np.str_(aq), wq, np.float64(ds), np.float64(qs)
+        arrs[f"x{i}"] = x.astype(np.float16) if dtype_tag == "f16" else x    # (fp16 values are exact in fp16: half the file)
+        if b is not None:
+            arrs[f"b{i}"] = b
+    sockets, cores, threads = host_topology()
+    plan = []   # (backend, threads, places, share of the budget)
+    for n, places in ((max(cores // sockets, 1), "cores"), (cores, "cores"), (threads, "threads")):
+        if all(n != p[1] for p in plan):
+            plan.append(("torch", n, places, 0.22))
+    plan.append(("torch", 1, "cores", 0.2))
+    plan.append(("c", cores, "cores", 0.14))
+    legs = []
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "cpu_baseline_operands.npz")
+        np.savez(path, **arrs)
+        for backend, n, places, share in plan:
+            env = dict(os.environ, OMP_NUM_THREADS=str(n), OMP_PLACES=places, OMP_PROC_BIND="close", MKL_NUM_THREADS=str(n), CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
             try:
-                one_pass()   # untimed: page-in, thread pool start
-                ts = []
-                while sum(ts) < budget and len(ts) < 20000:
-                    ts.append(one_pass())
-            finally:
-                torch.set_num_threads(prev)
-        except Exception as e:   # e.g. oracle/libasq_oracle.so not built on this box
-            return {"backend": backend, "threads": threads, "error": str(e)[:120]}
-        ts.sort()
-        med = ts[len(ts) // 2]
-        return {"backend": backend, "threads": threads, "reps": len(ts), "TOPS_median": round(ops_pass / med / 1e12, 5), "TOPS_mean": round(ops_pass * len(ts) / sum(ts) / 1e12, 5),
-                "tokens_per_s": round(M_sample / med, 1), "s_total": round(sum(ts), 2)}
-
-    # every leg runs on every box (no auto-pick); `value` is the best of them, named in `sample`.  On a 256-thread host the all-threads oneDNN GEMM of
-    # a 256-row sample is oversubscribed (0.07 TOPS against 0.67 on ONE thread), hence the quarter-of-the-threads leg
-    legs = [leg("torch", ncpu, budget_s / 2), leg("torch", max(1, ncpu // 4), budget_s / 4), leg("torch", 1, budget_s / 4), leg("c", ncpu, budget_s / 4)]
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", json.dumps([path, backend, n, budget_s * share])], env=env, capture_output=True,
+                                   text=True, timeout=max(120.0, 20 * budget_s))
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                legs.append(json.loads(line[-1]) if (r.returncode == 0 and line) else {"backend": backend, "threads": n, "error": (r.stderr or r.stdout)[-200:]})
+            except Exception as e:   # e.g. oracle/libasq_oracle.so not built on this box, a timeout
+                legs.append({"backend": backend, "threads": n, "error": str(e)[:200]})
     ok = [l for l in legs if "TOPS_median" in l]
-    primary = max(ok, key=lambda l: l["TOPS_median"]) if ok else legs[0]
+    multi = [l for l in ok if l["backend"] == "torch" and l["threads"] > 1]
+    primary = max(multi or ok, key=lambda l: l["TOPS_median"]) if ok else legs[0]
     secondary = [l for l in legs if l is not primary]
-    O.set_igemm_backend("numpy")
     cpu_model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -463,10 +518,11 @@ def cpu_baseline(spec, M_sample, dtype_tag, budget_s=8.0, mods=None, xs=None):
         pass
     return {"value": primary.get("TOPS_median"), "unit": "TOPS", "cores": primary.get("threads"), "kind": "port",
             "tokens_per_s": primary.get("tokens_per_s"),
-            "sample": f"oracle/w8a8.py module forwards (exact int GEMM backend {primary.get('backend')!r}, {primary.get('threads')} of {ncpu} host threads: the fastest of the fixed legs, "
-                      f"median of {primary.get('reps')} passes) on the first {M_sample} rows of the "
-                      f"{'step' + chr(39) + 's own quantised weights and activations' if real else 'same shapes (synthetic operands)'}, {len(spec)} linears, {primary.get('s_total')} s",
-            "primary": primary, "secondary": secondary, "cpu_model": cpu_model, "os_cpu_count": ncpu, "torch": torch.__version__}
+            "sample": f"oracle/w8a8.py module forwards (exact int GEMM backend {primary.get('backend')!r}) on {primary.get('threads')} pinned threads "
+                      f"(host: {sockets} socket(s), {cores} physical cores, {threads} hardware threads; OMP_PLACES={primary.get('omp_places')}, OMP_PROC_BIND=close; the best of the "
+                      f"multi-thread legs, median of {primary.get('reps')} passes, {primary.get('s_total')} s) on all {M_sample} rows of the "
+                      f"{'step' + chr(39) + 's own quantised weights and activations' if real else 'same shapes (synthetic operands)'}, {len(spec)} linears",
+            "primary": primary, "secondary": secondary, "cpu_model": cpu_model, "host_sockets": sockets, "host_physical_cores": cores, "os_cpu_count": threads, "torch": torch.__version__}
 
 
 def self_launch(n, argv):
@@ -506,7 +562,11 @@ def main():
                          "(arena broadcast, fingerprints, barriers, max-over-ranks timing) can be rehearsed on a box with fewer GPUs than ranks: ranks then share "
                          "device LOCAL_RANK %% device_count and the line is marked rehearsal=true (not a scaling measurement)")
     ap.add_argument("--no-cfg3", action="store_true", help="default workload only: skip the LLaMA-2-7B 32-layer decoder forward (BASELINE configs[2]) that is timed after the main step")
+    ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)   # internal: one pinned leg of cpu_baseline() in its own process
     args = ap.parse_args()
+    if args.cpu_leg:
+        cpu_leg(*json.loads(args.cpu_leg))
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -787,7 +847,7 @@ def main():
             out["config"]["layers"] = nlayers
             out["config"]["norm"] = "fused RMSNorm->int8 (N1)" if args.fuse_norm else "torch RMSNorm (weight/input_scale) + per-linear quantise"
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec, min(M, 256), args.dtype, mods=None if (layer_mode or moe_mode) else mods, xs=None if (layer_mode or moe_mode) else xs)
+            out["cpu_baseline"] = cpu_baseline(spec, min(M, 4096), args.dtype, mods=None if (layer_mode or moe_mode) else mods, xs=None if (layer_mode or moe_mode) else xs)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

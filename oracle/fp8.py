@@ -176,3 +176,30 @@ def fp8_linear_static_forward(x, dt, wq, w_scale, input_scale, output_scale, bia
         qo = static_per_tensor_quantize_fp8(out, dt, output_scale)
         out = round_to(e4m3fn_to_f32(qo) * np.float32(output_scale), dt)
     return out.reshape(*lead, -1)
+
+
+class StaticQuantizerState:
+    """Running state of the reference's calibration-time FP8StaticLinearQuantizer (layers/nn/linear.py:455-500): the maxima of the dynamic per-tensor
+    input (and, with quantize_output, output) scales seen so far."""
+
+    def __init__(self, quantize_output=False):
+        self.input_scale, self.output_scale, self.quantize_output = None, None, quantize_output
+
+
+def fp8_static_quantizer_forward(state, x, dt, wq, w_scale, bias):
+    """One calibration forward (linear.py:474-499): quantise x per tensor, keep the running MAXIMUM of the scale, and -- as the reference does --
+    dequantise this batch's codes with the RUNNING scale (not this batch's own) in the GEMM; optionally the same for the output."""
+    q, s = per_tensor_quantize_fp8(x, dt)
+    s = np.float32(s)
+    if state.input_scale is None or s > state.input_scale:
+        state.input_scale = s
+    out = easy_fp8_gemm(q, state.input_scale, wq, w_scale, bias, dt)
+    if state.quantize_output:
+        qo, so = per_tensor_quantize_fp8(out, dt)
+        so = np.float32(so)
+        if state.output_scale is None or so > state.output_scale:
+            state.output_scale = so
+        # qoutput.to(output.dtype) * output_scale (linear.py:497): this batch's codes times THIS batch's scale, in the activation dtype
+        from .w8a8 import round_to
+        out = round_to(round_to(e4m3fn_to_f32(qo), dt) * round_to(np.float32(so), dt), dt)
+    return out
