@@ -195,9 +195,30 @@ extern "C" int asq_linear_w8a8_grouped(const int8_t *xq, const int8_t *w, void *
     return asq_linear_w8a8_grouped_ws(xq, w, out, out_dtype, group_offsets, ngroups, M, N, K, s_group, s_row, bias, nullptr, 0, stream);
 }
 
+static int grouped_impl(const int8_t *xq, const int8_t *w, void *out, int out_dtype, const int32_t *group_offsets, int ngroups, int64_t M, int64_t N, int64_t K,
+                        const float *s_group, const float *s_row, const float *bias, const int32_t *row_off, const int32_t *col_off, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
 extern "C" int asq_linear_w8a8_grouped_ws(const int8_t *xq, const int8_t *w, void *out, int out_dtype, const int32_t *group_offsets, int ngroups,
                                           int64_t M, int64_t N, int64_t K, const float *s_group, const float *s_row, const float *bias,
                                           void *workspace, size_t workspace_bytes, void *stream)
+{
+    return grouped_impl(xq, w, out, out_dtype, group_offsets, ngroups, M, N, K, s_group, s_row, bias, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int asq_linear_w8a8_grouped_off(const int8_t *xq_off, const int8_t *w_off, void *out, int out_dtype, const int32_t *group_offsets, int ngroups,
+                                           int64_t M, int64_t N, int64_t K, const float *s_group, const float *s_row, const float *bias,
+                                           const int32_t *row_off, const int32_t *col_off, void *workspace, size_t workspace_bytes, void *stream)
+{
+    ASQ_REQUIRE(M == 0 || N == 0 || (row_off != nullptr && col_off != nullptr), ASQ_ERR_NULL, "asq_linear_w8a8_grouped_off: NULL row_off / col_off");
+    ASQ_REQUIRE(out_dtype == ASQ_F16 || out_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_linear_w8a8_grouped_off: out_dtype must be ASQ_F16 or ASQ_BF16 (got %d)", out_dtype);
+    ASQ_REQUIRE((((uintptr_t)row_off | (uintptr_t)col_off) & 7) == 0, ASQ_ERR_ALIGN, "asq_linear_w8a8_grouped_off: row_off / col_off must be 8-B aligned");
+    return grouped_impl(xq_off, w_off, out, out_dtype, group_offsets, ngroups, M, N, K, s_group, s_row, bias, row_off, col_off, workspace, workspace_bytes, stream);
+}
+
+static int grouped_impl(const int8_t *xq, const int8_t *w, void *out, int out_dtype, const int32_t *group_offsets, int ngroups, int64_t M, int64_t N, int64_t K,
+                        const float *s_group, const float *s_row, const float *bias, const int32_t *row_off, const int32_t *col_off, void *workspace,
+                        size_t workspace_bytes, void *stream)
 {
     int rc = check_gemm_args("asq_linear_w8a8_grouped", xq, w, out, M, N, K);
     if (rc) return rc;
@@ -214,6 +235,7 @@ extern "C" int asq_linear_w8a8_grouped_ws(const int8_t *xq, const int8_t *w, voi
     a.s_group = s_group;
     a.goffs = group_offsets;
     a.ngroups = ngroups;
+    a.off = OffsetArgs{row_off, col_off};
     hipStream_t s = (hipStream_t)stream;
     switch (out_dtype) {
     case ASQ_F32: return launch_dequant<ASQ_F32>(a, s);

@@ -1323,7 +1323,17 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
             return (int)e;
         }
-        hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, 0, (int)tn, 1, goffs, ngroups, gws, epi);
+        bool g_offs = false;
+        if constexpr (Epi::Mma::kIsInt && Epi::kOutBytes == 2) g_offs = off.row != nullptr && !mma32_forced();
+        ASQ_REQUIRE(off.row == nullptr || (g_offs && K <= OFFSET_MAX_K && N % 4 == 0), ASQ_ERR_DIM, "%s: offset operands need int8 groups, 2-byte outputs, K <= 65536, N %% 4 == 0", what);
+        if (g_offs) {
+            e = ensure_dynamic_lds((const void *)kfn, P16_LDS_BYTES);
+            if (e != hipSuccess) {
+                asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+                return (int)e;
+            }
+        }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(512), g_offs ? P16_LDS_BYTES : P8_LDS_BYTES, s, x, w, M, N, K, 0, (int)tn, 1, goffs, ngroups, gws, epi, g_offs ? off : OffsetArgs{});
         return asq_after_launch(s, what);
     }
     constexpr bool kInt = Epi::Mma::kIsInt;
@@ -1407,7 +1417,7 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
                 asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
                 return (int)e;
             }
-            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn * ksplit)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, ksplit, (const int *)nullptr, 0, (char *)nullptr, slab);
+            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn * ksplit)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, ksplit, (const int *)nullptr, 0, (char *)nullptr, slab, OffsetArgs{});
             int64_t blocks = (M * (N / 4) + 255) / 256;
             if (blocks > 8192) blocks = 8192;
             hipLaunchKernelGGL((splitk_reduce<Epi>), dim3((unsigned)blocks), dim3(256), 0, s, (const int32_t *)ws, ksplit, M, N, epi);
@@ -1422,7 +1432,7 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
             return (int)e;
         }
-        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, (const int *)nullptr, 0, (char *)nullptr, epi);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, (const int *)nullptr, 0, (char *)nullptr, epi, OffsetArgs{});
     } else if (kern == KERN_P8H) {
         const int64_t tm = (M + 127) / 128, tn = (N + 255) / 256;
         ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);

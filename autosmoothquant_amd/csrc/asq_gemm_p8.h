@@ -146,7 +146,7 @@ __device__ __forceinline__ void p8_dma16(const int8_t *sbase, unsigned voff, uns
 template <class Epi, int ABL = 0, bool GRP = false, bool L16 = false>   // GRP: the grouped launch (goffs != null); the plain instantiation carries none of its code
 __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N,
                                                      int64_t K, int tiles_m, int tiles_n, int ksplit, const int *__restrict__ goffs, int ngroups,
-                                                     char *gws, Epi epi_in)
+                                                     char *gws, Epi epi_in, OffsetArgs off)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -273,6 +273,19 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
     const int tile_m = first_m + in_group % gm, tile_n = in_group / gm;
     const int64_t m0 = m_base + (int64_t)(tile_m + moff) * 256, n0 = (int64_t)tile_n * 256;
 
+    // OFFSET operands (OffsetArgs; grouped int8 launches on the 16 x 16 x 64 instruction only -- asq_linear_w8a8_grouped_off): as in gemm_i8_p16 the K loop runs
+    // on x + cx[m] / w + cw[n] unchanged and the exact product is recovered in front of the epilogue; the tile's {cx, xsum'} / {cw, wsum} pairs are fetched by one
+    // 8-byte load per thread now and parked behind the ring.  Rows of other groups (>= M = this group's end) are clamped: their outputs are masked anyway.
+    constexpr bool kOffs = GRP && L16 && MMA_kIsInt_ && Epi::kOutBytes == 2 && !Epi::kHasCol;   // (grouped launches carry per-group scalars, never a column-scale vector: those instantiations are not launched)
+    const bool offs = kOffs && off.row != nullptr;   // (block-uniform)
+    v2i opair = {0, 0};
+    if constexpr (kOffs) if (offs) {
+        const int i = tid & 255;
+        const int64_t idx = tid < 256 ? (m0 + i < M ? m0 + i : M - 1) : (int64_t)grp * N + (n0 + i < N ? n0 + i : N - 1);
+        const int32_t *src = (tid < 256 ? off.row : off.col) + 2 * idx;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(opair) : "v"(src) : "memory");
+    }
+
     // ---- DMA sources: uniform tile base (SGPR pair, + k advanced per K-tile) + 32-bit lane offset.
     // This wave fills row-groups 2*wave, 2*wave+1 (8 rows each) of every unit.
     const int nt_all = (int)(K / 128);
@@ -364,6 +377,15 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
 #pragma unroll
     for (int kind = 0; kind < 4; ++kind) issue(kind, 0, 0);
     P8_WAIT_VM(4);
+    typedef __attribute__((address_space(3))) v2i *lds_v2i;
+    typedef __attribute__((address_space(3))) v4i *lds_v4i_;
+    typedef __attribute__((address_space(3))) int *lds_i32;
+    const unsigned obase = lds0 + P8_LDS_BYTES;   // offset launches: [256 row words: (-cx) << 24 | (-xsum') & 0xFFFFFF][256 column pairs {cw, wsum}]
+    if constexpr (kOffs) if (offs) {
+        asm volatile("" : "+v"(opair));   // (keeps every use of the loaded pair behind the wait above: in-order return, the pair is older than the DMAs)
+        if (tid < 256) *(lds_i32)(uintptr_t)(obase + tid * 4) = (int)(((unsigned)(-opair[0]) << 24) | ((unsigned)(-opair[1]) & 0xFFFFFFu));
+        else *(lds_v2i)(uintptr_t)(obase + 1024 + (tid - 256) * 8) = opair;
+    }
     P8_BAR();
     if (wm == 1) P8_BAR();  // stagger: the wm=1 group runs one barrier behind
     P8_BLK(1);
@@ -654,19 +676,56 @@ if constexpr (L16) {
         if constexpr (Epi::kOutBytes >= 2) staged16 = ((((uintptr_t)epi.out) & 15) == 0) && (((N | epi.N) * Epi::kOutBytes) % 16 == 0);
         const int64_t mw0 = m0 + (half ? wm * 64 : wm * 128), nw0 = n0 + wn * 64;   // (half tile: see below)
         const int64_t Mw = half && mw0 + 64 < M ? mw0 + 64 : M;
-        if (staged16) {
-            if constexpr (Epi::kOutBytes >= 2) {
-                P8_BAR();
-                bool rows_path = false;
-                if constexpr (Epi::kOutBytes == 2) rows_path = !half && mw0 + 128 <= M && nw0 + 64 <= N && epi.N < (int64_t(1) << 27);
-                if (rows_path) {
-                    if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<4, 2, true>(epi, get16, mw0, nw0, lane, lds0 + wave * 16384, rows_write_through(M_all, epi));
-                } else
-                    epilogue_wave_staged<4, 0, true>(epi, get16, mw0, nw0, lane, Mw, N, lds0 + wave * 16384);
+        auto run = [&](auto getter) {
+            if (staged16) {
+                if constexpr (Epi::kOutBytes >= 2) {
+                    P8_BAR();
+                    bool rows_path = false;
+                    if constexpr (Epi::kOutBytes == 2) rows_path = !half && mw0 + 128 <= M && nw0 + 64 <= N && epi.N < (int64_t(1) << 27);
+                    if (rows_path) {
+                        if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<4, 2, true>(epi, getter, mw0, nw0, lane, lds0 + wave * 16384, rows_write_through(M_all, epi));
+                    } else
+                        epilogue_wave_staged<4, 0, true>(epi, getter, mw0, nw0, lane, Mw, N, lds0 + wave * 16384);
+                }
+            } else {
+                epilogue_wave16(epi, getter, mw0, nw0, lane, Mw, N);
             }
-        } else {
-            epilogue_wave16(epi, get16, mw0, nw0, lane, Mw, N);
+        };
+        if constexpr (kOffs) if (offs) {
+            // (gemm_i8_p16's correction, with the column pairs PACKED too -- cw << 24 | wsum & 0xFFFFFF, 16 registers instead of 32: this kernel's scheduler and K-split
+            // fix-up leave fewer registers than p16 has; one more shift per accumulator tile.  v_mul_i32_i24 takes the low 24 bits of either factor.)
+            const int t16i = lane & 15, q16i = lane >> 4;
+            int cp[4][4], rw[8];
+#pragma unroll
+            for (int in16 = 0; in16 < 4; ++in16) {
+                const unsigned ca = obase + 1024 + (wn * 64 + in16 * 16 + 4 * q16i) * 8;
+                const v4i p0 = *(lds_v4i_)(uintptr_t)ca, p1 = *(lds_v4i_)(uintptr_t)(ca + 16);
+                cp[in16][0] = (int)(((unsigned)p0[0] << 24) | ((unsigned)p0[1] & 0xFFFFFFu));
+                cp[in16][1] = (int)(((unsigned)p0[2] << 24) | ((unsigned)p0[3] & 0xFFFFFFu));
+                cp[in16][2] = (int)(((unsigned)p1[0] << 24) | ((unsigned)p1[1] & 0xFFFFFFu));
+                cp[in16][3] = (int)(((unsigned)p1[2] << 24) | ((unsigned)p1[3] & 0xFFFFFFu));
+            }
+            const int row0 = (int)(mw0 - m0) + t16i;
+            constexpr bool kRowsInRegs = !(Epi::kHasRow && Epi::kHasBias);   // (the per-token + bias epilogue has no 8 registers to spare: it re-reads the word per tile)
+            if constexpr (kRowsInRegs) {
+#pragma unroll
+                for (int im16 = 0; im16 < 8; ++im16) rw[im16] = *(lds_i32)(uintptr_t)(obase + ((row0 + im16 * 16) & 255) * 4);
+            }
+            auto getc16 = [&](int in16, int im16) -> v4i {
+                const v4i &a = acc16[im16 >> 2][in16 >> 1][im16 & 3][in16 & 1];
+                int r;
+                if constexpr (kRowsInRegs) r = rw[im16];
+                else r = *(lds_i32)(uintptr_t)(obase + ((row0 + im16 * 16) & 255) * 4);
+                const int ncx = r >> 24;
+                v4i o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = __mul24(cp[in16][e] >> 24, r) + (__mul24(ncx, cp[in16][e]) + a[e]);
+                return o;
+            };
+            run(getc16);
+            return;
         }
+        run(get16);
         return;
     }
     // accumulator tile (in = n-half, im = 2*m-half + j) -> rows m0 + wm*128 + 32*im, cols n0 + wn*64 + 32*in

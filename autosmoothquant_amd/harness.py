@@ -535,6 +535,23 @@ class MixtralLayer(LlamaLayer):
             self.__dict__[f"_{name}_scale_host"] = host
         return self
 
+    def _stack_image(self, name):
+        """(image int8 [E,N,K], col_off int32 [E,N,2]) of one expert stack, rebuilt when the stack is (keyed on its storage and version counter)"""
+        from . import ops
+        st = getattr(self, f"_{name}_stack")
+        try:
+            ver = st._version
+        except RuntimeError:
+            ver = -1
+        key = (st.data_ptr(), ver, st.device)
+        hit = self.__dict__.get(f"_{name}_image")
+        if hit is None or hit[0] != key:
+            E, N, K = st.shape
+            img, col = ops.weight_offset_image(st.view(E * N, K))
+            hit = (key, (img.view(E, N, K), col.view(E, N, 2)))
+            self.__dict__[f"_{name}_image"] = hit
+        return hit[1]
+
     def _stacks_current(self):
         """The per-expert modules stay the source of truth (state_dict, load_state_dict, .to(), replica.broadcast_quantized all act on THEIR buffers): the
         stacks are current iff every expert's `weight` is still the stack's own row block and its dequant scale the recorded one.  Anything that re-homes
@@ -564,11 +581,21 @@ class MixtralLayer(LlamaLayer):
             from . import ops
             offs = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int32)
             mode, qs = ex[0].w1._input_mode()
-            xq, srow = ops.quantize_act(xs.contiguous(), mode, qs)
-            h1 = ops.linear_w8a8_grouped(xq, self._w1_stack, offs, self._w1_scale, x.dtype, srow)
-            h3 = ops.linear_w8a8_grouped(xq, self._w3_stack, offs, self._w3_scale, x.dtype, srow)
-            aq, arow = ops.quantize_act(F.silu(h1) * h3, "per-token")
-            y = ops.linear_w8a8_grouped(aq, self._w2_stack, offs, self._w2_scale, x.dtype, arow)
+            R = xs.shape[0]
+            if getattr(self, "offsets", True) and ops.grouped_offsets_supported(R, self._w1_stack.shape[1], H, x.dtype) and ops.grouped_offsets_supported(R, H, self._w2_stack.shape[-1], x.dtype):
+                # offset operand images (include/asq_hip.h): same products, less matrix-core energy; the stacks' images are built once and follow the stacks
+                i1, i3, i2 = (self._stack_image(n) for n in ("w1", "w3", "w2"))
+                xq, srow, ro = ops.quantize_act_off(xs.contiguous(), mode, qs)
+                h1 = ops.linear_w8a8_grouped_off(xq, i1[0], ro, i1[1], offs, self._w1_scale, x.dtype, srow)
+                h3 = ops.linear_w8a8_grouped_off(xq, i3[0], ro, i3[1], offs, self._w3_scale, x.dtype, srow)
+                aq, arow, ao = ops.quantize_act_off(F.silu(h1) * h3, "per-token")
+                y = ops.linear_w8a8_grouped_off(aq, i2[0], ao, i2[1], offs, self._w2_scale, x.dtype, arow)
+            else:
+                xq, srow = ops.quantize_act(xs.contiguous(), mode, qs)
+                h1 = ops.linear_w8a8_grouped(xq, self._w1_stack, offs, self._w1_scale, x.dtype, srow)
+                h3 = ops.linear_w8a8_grouped(xq, self._w3_stack, offs, self._w3_scale, x.dtype, srow)
+                aq, arow = ops.quantize_act(F.silu(h1) * h3, "per-token")
+                y = ops.linear_w8a8_grouped(aq, self._w2_stack, offs, self._w2_scale, x.dtype, arow)
         else:   # the reference's loop (also the float layer's path)
             y, o = torch.empty_like(xs), 0
             for e, c in zip(ex, counts.tolist()):

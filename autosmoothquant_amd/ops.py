@@ -431,6 +431,39 @@ def linear_w8a8_grouped(xq, w, group_offsets, s_group, out_dtype, s_row=None, bi
     return out
 
 
+def grouped_offsets_supported(M, N, K, out_dtype):
+    """grouped launches always run on the 256 x 256 kernel; images pay from a few thousand routed rows on (the matrix cores' energy is the limit there)"""
+    return (out_dtype in (torch.float16, torch.bfloat16) and M >= 2048 and K % 128 == 0 and 128 <= K <= 65536 and N % 4 == 0
+            and bool(L.lib().asq_offsets_supported(4096, 4096, 4096, _DT[out_dtype])))   # (the process-wide ASQ_OFFSETS switch)
+
+
+def linear_w8a8_grouped_off(xq_off, w_off, row_off, col_off, group_offsets, s_group, out_dtype, s_row=None, bias=None):
+    """linear_w8a8_grouped on offset operand images: xq_off / row_off from a *_off quantiser, w_off [G,N,K] / col_off [G,N,2] from weight_offset_image on the
+    stack viewed as [G*N, K].  Bit-identical to linear_w8a8_grouped on the plain operands."""
+    _dev(xq_off, "xq"), _dev(w_off, "weight"), _dev(group_offsets, "group_offsets"), _dev(s_group, "s_group"), _dev(row_off, "row_off"), _dev(col_off, "col_off")
+    if xq_off.dtype != torch.int8 or w_off.dtype != torch.int8 or xq_off.dim() != 2 or w_off.dim() != 3 or xq_off.shape[1] != w_off.shape[2]:
+        raise ValueError("xq [M,K] int8 and weight [G,N,K] int8 with equal K expected")
+    M, K = xq_off.shape
+    G, N = w_off.shape[0], w_off.shape[1]
+    if group_offsets.dtype != torch.int32 or group_offsets.numel() != G + 1 or s_group.dtype != torch.float32 or s_group.numel() != G:
+        raise ValueError("group_offsets must be int32 [G+1] and s_group float32 [G]")
+    if row_off.dtype != torch.int32 or row_off.numel() != 2 * M or col_off.dtype != torch.int32 or col_off.numel() != 2 * G * N:
+        raise ValueError("row_off must be int32 [M,2] and col_off int32 [G,N,2]")
+    for name, t, n in (("s_row", s_row, M), ("bias", bias, G * N)):
+        if t is not None:
+            _dev(t, name)
+            if t.dtype != torch.float32 or t.numel() != n:
+                raise ValueError(f"{name} must be float32 with {n} elements")
+    out = torch.empty((M, N), dtype=out_dtype, device=xq_off.device)
+    dev = _same_device(xq_off, w_off, group_offsets, s_group, s_row, bias, row_off, col_off)
+    with _on(dev):
+        lib, st = L.lib(), _stream(xq_off)
+        ws, n = _grouped_ws(lib, M, N, K, G, dev, st)
+        L.check(lib.asq_linear_w8a8_grouped_off(xq_off.data_ptr(), w_off.data_ptr(), out.data_ptr(), _DT[out_dtype], group_offsets.data_ptr(), G, M, N, K,
+                                                s_group.data_ptr(), _ptr(s_row), _ptr(bias), row_off.data_ptr(), col_off.data_ptr(), _ptr(ws), n, st), "asq_linear_w8a8_grouped_off")
+    return out
+
+
 def linear_w8a8_forward(x2d, w, act_mode, quant_scale, s_scalar, s_col=None, bias=None, image=None):
     """Whole module forward on a 2-D activation: quantise -> GEMM + epilogue, one stream,
     no int32 round trip.  Returns out [M,N] in x's dtype.  image = (w_off, col_off) of this weight (weight_offset_image) or None: with it the C-ABI

@@ -135,29 +135,39 @@ def make_moe_workload(device, seed, dtype, skew=False):
     st = dict(E=E, offs=offs, counts=counts.tolist(), w1=w1, w3=w3, w2=w2, s1=s1 * in_scale, s3=s3 * in_scale, s2=s2,
               x=(x / in_scale).to(dtype))
 
+    # offset operand images of the three stacks (include/asq_hip.h; what harness.MixtralLayer.moe() does): same products bit for bit, less matrix-core energy
+    images = ops.grouped_offsets_supported(R, F_, H, dtype) and ops.grouped_offsets_supported(R, H, F_, dtype)
+    st["operands"] = "offset images" if images else "plain int8"
+    if images:
+        for n in ("w1", "w3", "w2"):
+            img, col = ops.weight_offset_image(st[n].view(-1, st[n].shape[-1]))
+            st[n + "_img"], st[n + "_col"] = img.view(st[n].shape), col.view(E, -1, 2)
+
+    def glin(xq, ro, n, srow=None):
+        if ro is not None:
+            return ops.linear_w8a8_grouped_off(xq, st[n + "_img"], ro, st[n + "_col"], st["offs"], st["s" + n[1]], dtype, srow)
+        return ops.linear_w8a8_grouped(xq, st[n], st["offs"], st["s" + n[1]], dtype, srow)
+
+    def quant(t, mode):
+        if images:
+            return ops.quantize_act_off(t, mode)
+        return (*ops.quantize_act(t, mode), None)
+
     def grouped():
-        xq, _ = ops.quantize_act(st["x"], "per-tensor-round")
-        h1 = ops.linear_w8a8_grouped(xq, st["w1"], st["offs"], st["s1"], dtype)
-        h3 = ops.linear_w8a8_grouped(xq, st["w3"], st["offs"], st["s3"], dtype)
+        xq, _, ro = quant(st["x"], "per-tensor-round")
+        h1, h3 = glin(xq, ro, "w1"), glin(xq, ro, "w3")
         a = torch.nn.functional.silu(h1) * h3
-        aq, srow = ops.quantize_act(a, "per-token")
-        return ops.linear_w8a8_grouped(aq, st["w2"], st["offs"], st["s2"], dtype, srow)
+        aq, srow, ao = quant(a, "per-token")
+        return glin(aq, ao, "w2", srow)
 
-    def grouped_fused():   # N1: SiLU(w1 x) * (w3 x) -> int8 in one pass instead of silu, mul and the per-token quantiser
-        xq, _ = ops.quantize_act(st["x"], "per-tensor-round")
-        h1 = ops.linear_w8a8_grouped(xq, st["w1"], st["offs"], st["s1"], dtype)
-        h3 = ops.linear_w8a8_grouped(xq, st["w3"], st["offs"], st["s3"], dtype)
-        aq, srow = ops.silu_mul_quantize(h1, h3, per_token=True)
-        return ops.linear_w8a8_grouped(aq, st["w2"], st["offs"], st["s2"], dtype, srow)
-    st["grouped_fused"] = grouped_fused
+    def fused(fast):
+        xq, _, ro = quant(st["x"], "per-tensor-round")
+        h1, h3 = glin(xq, ro, "w1"), glin(xq, ro, "w3")
+        r = ops.silu_mul_quantize(h1, h3, per_token=True, fast=fast, offsets=images)
+        return glin(r[0], r[2] if images else None, "w2", r[1])
 
-    def grouped_fused_fast():   # ... with the opt-in hardware exp2/rcp SiLU (ASQ_SILU_FAST: +-1 int8 of the exact kernel, asserted in tests/test_hip_n1.py)
-        xq, _ = ops.quantize_act(st["x"], "per-tensor-round")
-        h1 = ops.linear_w8a8_grouped(xq, st["w1"], st["offs"], st["s1"], dtype)
-        h3 = ops.linear_w8a8_grouped(xq, st["w3"], st["offs"], st["s3"], dtype)
-        aq, srow = ops.silu_mul_quantize(h1, h3, per_token=True, fast=True)
-        return ops.linear_w8a8_grouped(aq, st["w2"], st["offs"], st["s2"], dtype, srow)
-    st["grouped_fused_fast"] = grouped_fused_fast
+    st["grouped_fused"] = lambda: fused(False)        # N1: SiLU(w1 x) * (w3 x) -> int8 in one pass instead of silu, mul and the per-token quantiser
+    st["grouped_fused_fast"] = lambda: fused(True)    # ... with the opt-in hardware exp2/rcp SiLU (ASQ_SILU_FAST: +-1 int8 of the exact kernel, asserted in tests/test_hip_n1.py)
 
     s1h, s3h, s2h = st["s1"].tolist(), st["s3"].tolist(), st["s2"].tolist()
 
@@ -630,7 +640,7 @@ def main():
         for _ in range(10):
             seq_step()
         torch.cuda.synchronize()
-        moe_extra = {"sequential_per_expert_ms": round((time.perf_counter() - t0) / 10 * 1e3, 4), "rows_per_expert": st["counts"]}
+        moe_extra = {"sequential_per_expert_ms": round((time.perf_counter() - t0) / 10 * 1e3, 4), "rows_per_expert": st["counts"], "operands": st.get("operands", "plain")}
         if "grouped_fused" in st:   # the same step with the N1 SiLU*up -> int8 kernel (differs from torch's silu by +-1 int8 at rounding boundaries)
             for _ in range(5):
                 st["grouped_fused"]()
@@ -770,8 +780,12 @@ def main():
                 xq_, sx_ = _ops.quantize_act_fp8(st["x"], "per-token")
                 w1_launch = lambda: _ops.linear_fp8_grouped(xq_, sx_, st["w1"], st["s1"], st["offs"], tdt)
             else:
-                xq_, _ = _ops.quantize_act(st["x"], "per-tensor-round")
-                w1_launch = lambda: _ops.linear_w8a8_grouped(xq_, st["w1"], st["offs"], st["s1"], tdt)
+                if "w1_img" in st:
+                    xq_, _, ro_ = _ops.quantize_act_off(st["x"], "per-tensor-round")
+                    w1_launch = lambda: _ops.linear_w8a8_grouped_off(xq_, st["w1_img"], ro_, st["w1_col"], st["offs"], st["s1"], tdt)
+                else:
+                    xq_, _ = _ops.quantize_act(st["x"], "per-tensor-round")
+                    w1_launch = lambda: _ops.linear_w8a8_grouped(xq_, st["w1"], st["offs"], st["s1"], tdt)
             for _ in range(3):
                 w1_launch()
             torch.cuda.synchronize()

@@ -226,6 +226,9 @@ int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t *w, void *o
  *                             workspace has asq_linear_w8a8_workspace_bytes(); otherwise it IS asq_linear_w8a8_forward (w_off / col_off may be NULL).
  *   asq_norm_quantize_off / asq_add_norm_quantize_off / asq_silu_mul_quantize_off   the N1 fusions (same arithmetic, same arguments + row_off) emitting
  *                             the offset image of their int8 result: xq' - cx[m] is exactly what asq_norm_quantize / ... write.
+ *   asq_linear_w8a8_grouped_off   asq_linear_w8a8_grouped_ws on images: xq' from any *_off quantiser (rows sorted by group, row_off [M][2]), w' / col_off
+ *                             from asq_weight_offset_image on the [ngroups * N, K] stack (col_off [ngroups][N][2]); out_dtype ASQ_F16 / ASQ_BF16,
+ *                             K <= 65536, N % 4 == 0.  Bit-identical to the plain grouped launch, with or without the workspace's K split.
  * Development overrides (read once): ASQ_OFF_CX (default 3), ASQ_OFF_CW (default 64). */
 int asq_weight_offset_image(const int8_t *w, int64_t N, int64_t K, int8_t *w_off, int32_t *col_off, void *stream);
 int asq_quantize_act_off(const void *x, int x_dtype, int mode, float quant_scale,
@@ -235,6 +238,11 @@ int asq_linear_w8a8_off(const int8_t *xq_off, const int8_t *w_off, void *out, in
                         float s_scalar, const float *s_row, const float *s_col, const float *bias, int epi_order,
                         const int32_t *row_off, const int32_t *col_off, void *stream);
 int asq_offsets_supported(int64_t M, int64_t N, int64_t K, int out_dtype);
+int asq_linear_w8a8_grouped_off(const int8_t *xq_off, const int8_t *w_off, void *out, int out_dtype,
+                                const int32_t *group_offsets, int ngroups, int64_t M, int64_t N, int64_t K,
+                                const float *s_group, const float *s_row, const float *bias,
+                                const int32_t *row_off, const int32_t *col_off,
+                                void *workspace, size_t workspace_bytes, void *stream);
 int asq_norm_quantize_off(const void *x, int x_dtype, const void *weight, const void *bias, float eps, int per_token,
                           int8_t *xq_off, float *s_row, int32_t *row_off, int64_t M, int64_t K, void *stream);
 int asq_add_norm_quantize_off(const void *x, const void *residual, void *h_out, int x_dtype, const void *weight, const void *bias,

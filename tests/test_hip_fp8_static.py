@@ -62,7 +62,7 @@ def test_quantize_activations_fp8_flow_matches_the_reference():
     probe = torch.from_numpy(G["p2_probe"]).to(DEV)
     for n, m in replaced.items():
         assert np.array_equal(m.weight.detach().view(torch.uint8).cpu().numpy(), G[f"p2_wq::{n}"]), n
-        assert np.float32(m.weight_scale.item()) == G[f"p2_ws::{n}"]
+        assert abs(float(m.weight_scale) - float(G[f"p2_ws::{n}"])) <= 1.2e-7 * float(G[f"p2_ws::{n}"]), n   # (absmax / 448 computed by torch ON THE DEVICE: its fp32 division may differ from the host's in the last place)
         ref_s = float(G[f"p2_in_scale::{n}"])
         assert abs(float(m.input_scale) - ref_s) <= 2e-4 * ref_s, (n, float(m.input_scale), ref_s)
         key = f"p2_static_y::{n}"

@@ -231,3 +231,30 @@ def test_fused_llama_layer_with_and_without_images_is_identical():
     y_plain = q(xin)
     assert torch.equal(y_img, y_plain)
     assert len(seen) > 0   # (4096 rows on 1024-wide weights: 64 x 4 = 64 tiles of 256 x 256 for the 1024-wide projections, 176 for gate / up of 256 x 256 -- whether the dispatcher takes the 256 x 256 kernel decides; asserted so the test cannot pass vacuously)
+
+
+@pytest.mark.parametrize("counts,per_token,N,K", [([300, 0, 129, 1, 700, 256], False, 512, 256), ([300, 0, 129, 1, 700, 256], True, 260, 1024),
+                                                  ([1100, 900, 1300, 800, 1000, 1092, 1000, 1000], True, 4096, 2048)])
+def test_grouped_launch_on_images_equals_plain_grouped_launch(counts, per_token, N, K):
+    """asq_linear_w8a8_grouped_off == asq_linear_w8a8_grouped bit for bit: ragged groups (empty, one row, half tiles), per-group biases, and -- third case, 8192
+    rows on 8 groups with the workspace -- the K-split tail pieces, whose partial sums get the correction exactly once."""
+    from autosmoothquant_amd import ops
+    rng = np.random.default_rng(31)
+    G, M = len(counts), sum(counts)
+    x = np.clip(np.rint(rng.standard_normal((M, K)) * 2.5), -128, 127).astype(np.int8)
+    x[:: 7, 3] = 127
+    x[3:: 11, 5] = -128
+    w = np.clip(np.rint(rng.standard_normal((G, N, K)) * 22), -128, 127).astype(np.int8)
+    xt, wt = torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device=DEV)
+    sg = torch.from_numpy(rng.random(G).astype(np.float32) * 1e-3 + 1e-4).to(DEV)
+    s_row = torch.from_numpy(rng.random(M).astype(np.float32) * 0.01 + 1e-3).to(DEV) if per_token else None
+    xo, ro = OFF.act_image(x)
+    img, col = ops.weight_offset_image(wt.view(G * N, K))
+    rw, rc = OFF.weight_image(w.reshape(G * N, K))
+    assert np.array_equal(img.cpu().numpy(), rw) and np.array_equal(col.cpu().numpy(), rc)
+    for bias in (None, torch.from_numpy(rng.standard_normal((G, N)).astype(np.float32)).to(DEV)):
+        for dt in (torch.float16, torch.bfloat16):
+            ref = ops.linear_w8a8_grouped(xt, wt, offs, sg, dt, s_row, bias)
+            got = ops.linear_w8a8_grouped_off(torch.from_numpy(xo).to(DEV), img.view(G, N, K), torch.from_numpy(ro).to(DEV), col.view(G, N, 2), offs, sg, dt, s_row, bias)
+            assert torch.equal(ref.view(torch.int16), got.view(torch.int16)), (counts, per_token, N, K, dt, bias is not None)

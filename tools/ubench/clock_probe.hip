@@ -260,8 +260,8 @@ template <class Epi, int XABL = 0> static void run_gemm(const char *name, const 
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int BATCH = 50;
     auto launch = [&](bool prod) {
-        if (prod) hipLaunchKernelGGL(kprod, dim3(tm * tn), dim3(512), P8_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, (const int *)nullptr, 0, (char *)nullptr, epi);
-        else hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, (const int *)nullptr, 0, (char *)nullptr, epi);
+        if (prod) hipLaunchKernelGGL(kprod, dim3(tm * tn), dim3(512), P8_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, (const int *)nullptr, 0, (char *)nullptr, epi, OffsetArgs{});
+        else hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, (const int *)nullptr, 0, (char *)nullptr, epi, OffsetArgs{});
     };
     for (int i = 0; i < 5; ++i) launch(false);
     CK(hipDeviceSynchronize());
@@ -420,8 +420,8 @@ int main(int argc, char **argv)
         auto kprod = gemm_i8_p8<decltype(e16), 0>;
         CK(hipFuncSetAttribute((const void *)kprod, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES));
         for (int i = 0; i < 30; ++i) {
-            hipLaunchKernelGGL(kprod, dim3(256), dim3(512), P8_LDS_BYTES, 0, dxb, dwb, M, N, K, 16, 16, 1, (const int *)nullptr, 0, (char *)nullptr, e16);
-            hipLaunchKernelGGL(kprod, dim3(256), dim3(512), P8_LDS_BYTES, 0, dxb, dwb, M, N, KL, 16, 16, 1, (const int *)nullptr, 0, (char *)nullptr, e16);
+            hipLaunchKernelGGL(kprod, dim3(256), dim3(512), P8_LDS_BYTES, 0, dxb, dwb, M, N, K, 16, 16, 1, (const int *)nullptr, 0, (char *)nullptr, e16, OffsetArgs{});
+            hipLaunchKernelGGL(kprod, dim3(256), dim3(512), P8_LDS_BYTES, 0, dxb, dwb, M, N, KL, 16, 16, 1, (const int *)nullptr, 0, (char *)nullptr, e16, OffsetArgs{});
             hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(512), 0, 0, (int *)nullptr);
         }
         CK(hipDeviceSynchronize());
@@ -450,11 +450,11 @@ int main(int argc, char **argv)
             const int BATCH = 20;
             while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() < seconds) {
                 CK(hipEventRecord(e0));
-                for (int i = 0; i < BATCH; ++i) hipLaunchKernelGGL(kprod, dim3(nb), dim3(512), P8_LDS_BYTES, 0, x2, w2, M2, N2, K, tm, tn, 1, (const int *)nullptr, 0, (char *)nullptr, e2);
+                for (int i = 0; i < BATCH; ++i) hipLaunchKernelGGL(kprod, dim3(nb), dim3(512), P8_LDS_BYTES, 0, x2, w2, M2, N2, K, tm, tn, 1, (const int *)nullptr, 0, (char *)nullptr, e2, OffsetArgs{});
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 CK(hipEventElapsedTime(&msp, e0, e1));
                 CK(hipEventRecord(e0));
-                for (int i = 0; i < BATCH; ++i) hipLaunchKernelGGL(kfn, dim3(nb), dim3(512), P8_LDS_BYTES, 0, x2, w2, M2, N2, K, tm, tn, 1, (const int *)nullptr, 0, (char *)nullptr, e2);
+                for (int i = 0; i < BATCH; ++i) hipLaunchKernelGGL(kfn, dim3(nb), dim3(512), P8_LDS_BYTES, 0, x2, w2, M2, N2, K, tm, tn, 1, (const int *)nullptr, 0, (char *)nullptr, e2, OffsetArgs{});
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 CK(hipEventElapsedTime(&ms, e0, e1));
             }

@@ -20,12 +20,12 @@ template <int ABL> float run(const int8_t* x, const int8_t* w, int32_t* out, int
     CK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES));
     int tm = (M + 255) / 256, tn = (N + 255) / 256;
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, (const int *)nullptr, 0, (char *)nullptr, epi);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, (const int *)nullptr, 0, (char *)nullptr, epi, OffsetArgs{});
     CK(hipDeviceSynchronize());
     float best = 1e30f, sum = 0;
     for (int i = 0; i < iters; ++i) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, (const int *)nullptr, 0, (char *)nullptr, epi);
+        hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, (const int *)nullptr, 0, (char *)nullptr, epi, OffsetArgs{});
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b)); best = ms < best ? ms : best; sum += ms;
     }
@@ -39,7 +39,7 @@ template <class Epi> void blk_timeline(const int8_t* x, const int8_t* w, Epi epi
     auto kfn = gemm_i8_p8<Epi, 128>;
     CK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES));
     int tm = (M + 255) / 256, tn = (N + 255) / 256;
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, (const int *)nullptr, 0, (char *)nullptr, epi);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, (const int *)nullptr, 0, (char *)nullptr, epi, OffsetArgs{});
     CK(hipDeviceSynchronize());
     static unsigned long long h[4096][8];
     CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(p8_blk), sizeof(h)));
