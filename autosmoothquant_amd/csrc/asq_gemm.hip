@@ -136,8 +136,8 @@ static bool offsets_enabled()
 
 extern "C" int asq_offsets_supported(int64_t M, int64_t N, int64_t K, int out_dtype)
 {
-    if (!offsets_enabled() || (out_dtype != ASQ_F16 && out_dtype != ASQ_BF16) || M <= 0 || N <= 0 || K <= 0) return 0;
-    if (!offsets_shape_ok(nullptr, nullptr, M, N, K) || K / 8 > 256 * 20) return 0;   // (second: asq_quantize_act_off keeps the row in registers)
+    if (!offsets_enabled() || (out_dtype != ASQ_F16 && out_dtype != ASQ_BF16 && out_dtype != ASQ_F32) || M <= 0 || N <= 0 || K <= 0) return 0;
+    if (!offsets_shape_ok(nullptr, nullptr, M, N, K) || K / (out_dtype == ASQ_F32 ? 4 : 8) > 256 * 20) return 0;   // (second: asq_quantize_act_off keeps the row in registers)
     const GemmKernel kern = pick_kernel(nullptr, nullptr, M, N, K);
     return kern == KERN_P16 && plan_tail_peel(kern, M, N, K).n_main == 0 ? 1 : 0;
 }
@@ -149,18 +149,19 @@ extern "C" int asq_linear_w8a8_off(const int8_t *xq_off, const int8_t *w_off, vo
     int rc = check_gemm_args("asq_linear_w8a8_off", xq_off, w_off, out, M, N, K);
     if (rc) return rc;
     if (M == 0 || N == 0) return ASQ_OK;
-    ASQ_REQUIRE(out_dtype == ASQ_F16 || out_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_linear_w8a8_off: out_dtype must be ASQ_F16 or ASQ_BF16 (got %d)", out_dtype);
+    ASQ_REQUIRE(out_dtype == ASQ_F16 || out_dtype == ASQ_BF16 || out_dtype == ASQ_F32, ASQ_ERR_DTYPE, "asq_linear_w8a8_off: bad out_dtype %d", out_dtype);
     ASQ_REQUIRE(epi_order == ASQ_EPI_SCALE_FIRST || epi_order == ASQ_EPI_ACC_FIRST, ASQ_ERR_DTYPE, "asq_linear_w8a8_off: bad epi_order %d", epi_order);
     ASQ_REQUIRE(row_off != nullptr && col_off != nullptr, ASQ_ERR_NULL, "asq_linear_w8a8_off: NULL row_off / col_off");
     ASQ_REQUIRE(offsets_shape_ok(xq_off, w_off, M, N, K), ASQ_ERR_DIM,
                 "asq_linear_w8a8_off: needs K %% 128 == 0, 128 <= K <= 65536, N %% 4 == 0 and 16-B aligned operands (M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
-    ASQ_REQUIRE(((uintptr_t)out & 1) == 0 && (((uintptr_t)row_off & 7) == 0) && (((uintptr_t)col_off & 15) == 0), ASQ_ERR_ALIGN, "asq_linear_w8a8_off: out / row_off / col_off misaligned");
+    ASQ_REQUIRE(((uintptr_t)out % asq_dtype_size(out_dtype)) == 0 && (((uintptr_t)row_off & 7) == 0) && (((uintptr_t)col_off & 15) == 0), ASQ_ERR_ALIGN, "asq_linear_w8a8_off: out / row_off / col_off misaligned");
     ASQ_REQUIRE((((uintptr_t)s_row | (uintptr_t)s_col | (uintptr_t)bias) & 3) == 0, ASQ_ERR_ALIGN, "asq_linear_w8a8_off: scale/bias misaligned");
-    const bool vec_ok = (N % 4 == 0) && (((uintptr_t)out & 7) == 0) && ((((uintptr_t)s_col | (uintptr_t)bias) & 15) == 0);
+    const size_t vbytes = out_dtype == ASQ_F32 ? 16 : 8;
+    const bool vec_ok = (N % 4 == 0) && (((uintptr_t)out & (vbytes - 1)) == 0) && ((((uintptr_t)s_col | (uintptr_t)bias) & 15) == 0);
     DequantArgs a{xq_off, w_off, out, M, N, K, s_scalar, s_row, s_col, bias, epi_order, vec_ok, nullptr, 0};
     a.off = OffsetArgs{row_off, col_off};
     hipStream_t s = (hipStream_t)stream;
-    return out_dtype == ASQ_F16 ? launch_dequant<ASQ_F16>(a, s) : launch_dequant<ASQ_BF16>(a, s);
+    return out_dtype == ASQ_F16 ? launch_dequant<ASQ_F16>(a, s) : out_dtype == ASQ_BF16 ? launch_dequant<ASQ_BF16>(a, s) : launch_dequant<ASQ_F32>(a, s);
 }
 
 extern "C" int asq_linear_w8a8_q8(const int8_t *xq, const int8_t *w, int8_t *out_q, int mid_dtype, int64_t M, int64_t N, int64_t K, float s_scalar,

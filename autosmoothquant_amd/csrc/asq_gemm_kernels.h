@@ -857,6 +857,84 @@ __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int6
     }
 }
 
+// The same interior fast path for 4-BYTE outputs (int32 accumulators, fp32) of the 16 x 16 accumulator layout (gemm_i8_p16, round 4): a 32-row token tile is an
+// 8 KiB image [32 rows][64 channels x 4 B], two of them alternate in the wave's 16 KiB, software-pipelined like epilogue_wave_rows:
+//     pack(0);   for im = 0 .. 3:   issue the 8 ds_read_b128 of image im & 1  |  pack(im + 1) into the other image  |  8 global_store_dwordx4
+// A lane (token t = l & 15, channel quad q = l >> 4) writes the 16 bytes of chunk 4 * in16 + q of row 16 * h + t at position chunk ^ (row & 15) (ds_write_b128,
+// conflict-free: staged_write16's layout); the read side is lane-linear, lane l of read i holds row 4 * i + (l >> 4), chunk (l & 15) ^ (row & 15).
+// Before: two unpipelined 64-row passes with a bound compare and a 64-bit address per store (epilogue_wave_staged) on gemm_i8_p8's L16 mode -- asq_gemm_i8_i32
+// at 4096^3 62.8 us against 54.9 for the fp16 kernel (profiles/r3_vendor_compare.txt).
+template <class Epi, class Get>
+__device__ __forceinline__ void epilogue_wave_rows4(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, unsigned stage, bool wt = false)
+{
+    static_assert(Epi::kOutBytes == 4, "4-byte outputs");
+    typedef __attribute__((address_space(3))) v4i *lds_v4i;
+    const int t = lane & 15, q = lane >> 4;
+    float sr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sr[i] = Epi::kHasRow ? epi.row(mw0 + i * 16 + t) : 1.0f;
+    v4f sc[4], bb[4];
+#pragma unroll
+    for (int in = 0; in < 4; ++in) {
+        sc[in] = bb[in] = (v4f){0.f, 0.f, 0.f, 0.f};
+        epi.cols(nw0 + in * 16 + 4 * q, nw0 + 64, sc[in], bb[in]);
+    }
+    unsigned wa[4];   // write address of (in16, row t) in image 0; + 8192 for image 1, + 4096 for the second 16 rows
+#pragma unroll
+    for (int in = 0; in < 4; ++in) wa[in] = stage + t * 256 + (((4 * in + q) ^ t) << 4);
+    unsigned ra[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        ra[i] = stage + i * 1024 + lane * 16;
+        asm volatile("" : "+v"(ra[i]));
+    }
+    const unsigned ldb = __builtin_amdgcn_readfirstlane((unsigned)(epi.N * 4));   // row pitch in bytes (callers keep 128 * ldb < 2^31)
+    unsigned voff[4];   // per-lane byte offset of read i (rows 4 i + (l >> 4)): the column part has period 4 in i
+#pragma unroll
+    for (int j = 0; j < 4; ++j) voff[j] = (unsigned)q * ldb + (unsigned)((((lane & 15) ^ ((4 * j + q) & 15))) << 4);
+    typedef __attribute__((address_space(1))) v4i *glb_v4i;
+    const uint64_t tile = (uint64_t)(uintptr_t)uniform_ptr((const int8_t *)epi.out + (mw0 * epi.N + nw0) * 4);
+    const __amdgpu_buffer_rsrc_t wt_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)tile, 0, 0x7FFFFFFF, 0x00020000);
+    auto pack_tile = [&](int im) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int in = 0; in < 4; ++in)
+                *(lds_v4i)(uintptr_t)(wa[in] + (im & 1) * 8192 + h * 4096) = epi.pack(get(in, 2 * im + h), sr[2 * im + h], sc[in], bb[in]);
+    };
+    pack_tile(0);
+#pragma unroll
+    for (int im = 0; im < 4; ++im) {
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        // (the reads of the first 16 rows are in flight under the conversions of the next tile; the second 16 rows follow the first stores: 16 registers of
+        // staged data instead of 32 -- the fp32 column-scale + bias epilogue on offset operands has none to spare)
+        v4i v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *(lds_v4i)(uintptr_t)(ra[i] + (im & 1) * 8192);
+        __builtin_amdgcn_sched_barrier(0);
+        if (im + 1 < 4) pack_tile(im + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        auto store4 = [&](int i0) {
+#pragma unroll
+            for (int i = i0; i < i0 + 4; ++i) {
+                const unsigned rowoff = (unsigned)(im * 32 + i * 4) * ldb;
+                if (wt) {
+                    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, v[i - i0]), wt_rsrc, rowoff + voff[i & 3], 0, 17 /* sc0 sc1 */);
+                } else {
+                    *(glb_v4i)(uintptr_t)(tile + (uint64_t)rowoff + voff[i & 3]) = v[i - i0];
+                }
+            }
+        };
+        store4(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *(lds_v4i)(uintptr_t)(ra[4 + i] + (im & 1) * 8192);
+        store4(4);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // "generic": any M, N, K, any alignment.  64x64x64 tile, 4 waves (2x2), single LDS buffer.
 // Correctness net for odd shapes (K % 128 != 0, unaligned rows); not a tuned kernel.
@@ -1339,7 +1417,7 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
     constexpr bool kInt = Epi::Mma::kIsInt;
     GemmKernel kern = peel_role == 2 ? KERN_P8Q : pick_kernel(x, w, M, N, K);
     if (off.row != nullptr) {   // offset operands: gemm_i8_p16 only (the entry point has checked the shape: offsets_supported)
-        ASQ_REQUIRE(kInt && Epi::kOutBytes == 2 && offsets_shape_ok(x, w, M, N, K), ASQ_ERR_DIM, "%s: offset operands need the 256 x 256 kernel (2-byte output, K %% 128 == 0, K <= 65536, N %% 4 == 0, aligned operands)", what);
+        ASQ_REQUIRE(kInt && (Epi::kOutBytes == 2 || Epi::kOutBytes == 4) && offsets_shape_ok(x, w, M, N, K), ASQ_ERR_DIM, "%s: offset operands need the 256 x 256 kernel (2- or 4-byte output, K %% 128 == 0, K <= 65536, N %% 4 == 0, aligned operands)", what);
         kern = KERN_P16;
     }
     if constexpr (kInt && HasColView<Epi>::value) {
@@ -1387,11 +1465,12 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
     }
     // the 256 x 256 kernel on v_mfma_i32_16x16x64_i8 (asq_gemm_p16.h): plain launches with 2-byte outputs
     bool p8_l16 = false;   // what p16 does not carry runs on p8 -- in its L16 mode (the same 16 x 16 x 64 instruction) unless p8 itself was asked for
-    if (kern == KERN_P16 && !kP4) {
+    constexpr bool kP16 = kInt && (Epi::kOutBytes == 2 || Epi::kOutBytes == 4);   // (round 4: 4-byte outputs -- int32 accumulators, fp32 -- through epilogue_wave_rows4)
+    if (kern == KERN_P16 && !kP16) {
         kern = KERN_P8;
         p8_l16 = kInt && !mma32_forced();
     }
-    if constexpr (kP4) if (kern == KERN_P16) {
+    if constexpr (kP16) if (kern == KERN_P16) {
         const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
         ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
         auto kfn = gemm_i8_p16<Epi>;

@@ -22,8 +22,8 @@
 //   * accumulators: acc[m-half][n-half][token tile 0..3][channel tile 0..1], 4 registers each (128 in all, as p8); in the matrix-core
 //     layout lane l owns token (l & 15) and channels 4 * (l >> 4) .. + 3 of a 16 x 16 tile -- again 4 consecutive channels of one
 //     token, so the staged row epilogue only needs other write addresses (epilogue_wave_rows<.., L16 = true>).
-// Edge tiles, unaligned outputs and 4-byte outputs leave through direct stores (epilogue_wave16): launch_gemm dispatches this kernel for
-// 2-byte outputs only.
+// Edge tiles and unaligned outputs leave through direct stores (epilogue_wave16).  Round 4: 4-byte outputs (int32 accumulators -- the reference's native boundary
+// linear_a8_w8_o32_ -- and fp32) have their own pipelined row epilogue (epilogue_wave_rows4); int8 outputs stay on gemm_i8_p8.
 #pragma once
 
 #ifndef P16_ORDER
@@ -267,21 +267,34 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
     // accumulator tile (in16 = 16-channel tile 0..3, im16 = 16-token tile 0..7) -> rows mw0 + 16*im16, cols nw0 + 16*in16
     auto get = [&](int in16, int im16) -> const v4i & { return acc[im16 >> 2][in16 >> 1][im16 & 3][in16 & 1]; };
     const int64_t mw0 = m0 + wm * 128, nw0 = n0 + wn * 64;
-    bool rows_path = false;
-    if constexpr (Epi::kOutBytes == 2)
-        rows_path = ((((uintptr_t)epi.out) & 15) == 0) && ((epi.N * 2) % 16 == 0) && mw0 + 128 <= M && nw0 + 64 <= N && epi.N < (int64_t(1) << 27);
-    if constexpr (Epi::kOutBytes == 2) P8_BAR();  // (block-uniform) every wave's ring reads are done and every wave's (dead) DMAs have landed: the ring becomes staging space; the staged pairs are visible
+    // interior wave tiles leave through the pipelined row epilogues (2-byte: epilogue_wave_rows, 4-byte: epilogue_wave_rows4), edge tiles and unaligned outputs through direct stores
+    bool rows_path = ((((uintptr_t)epi.out) & 15) == 0) && ((epi.N * Epi::kOutBytes) % 16 == 0) && mw0 + 128 <= M && nw0 + 64 <= N && epi.N * Epi::kOutBytes < (int64_t(1) << 24);
+    P8_BAR();  // (block-uniform) every wave's ring reads are done and every wave's (dead) DMAs have landed: the ring becomes staging space; the staged pairs are visible
+    const bool wt = M * epi.N * Epi::kOutBytes <= (int64_t)ASQ_WT_BYTES && ASQ_WT_BYTES > 0;   // small outputs leave as write-through stores (rows_write_through)
+    auto run = [&](auto getter) {
+        if (rows_path) {
+            if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<4, 2, true>(epi, getter, mw0, nw0, lane, lds0 + wave * 16384, wt);
+            else epilogue_wave_rows4(epi, getter, mw0, nw0, lane, lds0 + wave * 16384, wt);
+        } else {
+            epilogue_wave16(epi, getter, mw0, nw0, lane, M, N);
+        }
+    };
     if (offs) {
         // this lane's 16 channels {cw, wsum} (32 registers) and its 8 tokens' packed words (8): two v_mad_i32_i24 per element (v_mul_i32_i24 semantics: the low 24 bits
         // of either factor, sign-extended -- the packed word IS -xsum' there) + one shift per accumulator tile for -cx
         const int t16i = lane & 15, q16i = lane >> 4;
-        int cw[4][4], ws[4][4], rw[8];
+        constexpr bool kPack = false;   // (pairs packed as cw << 24 | wsum: tried for the fp32 column-scale + bias epilogue, the compiler hoists the unpacking and spills more)
+        int cw[kPack ? 1 : 4][4], ws[4][4], rw[8];
 #pragma unroll
         for (int in16 = 0; in16 < 4; ++in16) {
             const unsigned ca = obase + 1024 + (wn * 64 + in16 * 16 + 4 * q16i) * 8;
             const v4i p0 = *(lds_v4i_)(uintptr_t)ca, p1 = *(lds_v4i_)(uintptr_t)(ca + 16);   // channels n, n+1 | n+2, n+3
-            cw[in16][0] = p0[0], cw[in16][1] = p0[2], cw[in16][2] = p1[0], cw[in16][3] = p1[2];
-            ws[in16][0] = p0[1], ws[in16][1] = p0[3], ws[in16][2] = p1[1], ws[in16][3] = p1[3];
+            const int c4[4] = {p0[0], p0[2], p1[0], p1[2]}, s4[4] = {p0[1], p0[3], p1[1], p1[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (kPack) ws[in16][e] = (int)(((unsigned)c4[e] << 24) | ((unsigned)s4[e] & 0xFFFFFFu));
+                else cw[in16][e] = c4[e], ws[in16][e] = s4[e];
+            }
         }
 #pragma unroll
         for (int im16 = 0; im16 < 8; ++im16) rw[im16] = *(lds_i32)(uintptr_t)(obase + (wm * 128 + im16 * 16 + t16i) * 4);
@@ -290,20 +303,17 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
             const int ncx = rw[im16] >> 24;
             v4i o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = __mul24(cw[in16][e], rw[im16]) + (__mul24(ncx, ws[in16][e]) + a[e]);
+            for (int e = 0; e < 4; ++e) {
+                int c;
+                if constexpr (kPack) c = ws[in16][e] >> 24;
+                else c = cw[in16][e];
+                o[e] = __mul24(c, rw[im16]) + (__mul24(ncx, ws[in16][e]) + a[e]);
+            }
             return o;
         };
-        if (rows_path) {
-            if constexpr (Epi::kOutBytes == 2)
-                epilogue_wave_rows<4, 2, true>(epi, getc, mw0, nw0, lane, lds0 + wave * 16384, rows_write_through(M, epi));
-        } else {
-            epilogue_wave16(epi, getc, mw0, nw0, lane, M, N);
-        }
-    } else if (rows_path) {
-        if constexpr (Epi::kOutBytes == 2)
-            epilogue_wave_rows<4, 2, true>(epi, get, mw0, nw0, lane, lds0 + wave * 16384, rows_write_through(M, epi));
+        run(getc);
     } else {
-        epilogue_wave16(epi, get, mw0, nw0, lane, M, N);
+        run(get);
     }
 #ifdef ASQ_P8_PROBE
     if constexpr (ABL & 128) {

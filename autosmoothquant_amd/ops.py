@@ -202,7 +202,7 @@ def quantize_act(x, mode, quant_scale=1.0):
 
 def offsets_supported(M, N, K, out_dtype):
     """True when the C-ABI would run a [M,K] x [N,K]^T linear with `out_dtype` outputs on offset operand images (include/asq_hip.h)."""
-    return out_dtype in (torch.float16, torch.bfloat16) and bool(L.lib().asq_offsets_supported(M, N, K, _DT[out_dtype]))
+    return out_dtype in _DT and bool(L.lib().asq_offsets_supported(M, N, K, _DT[out_dtype]))
 
 
 def weight_offset_image(w):

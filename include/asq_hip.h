@@ -218,9 +218,9 @@ int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t *w, void *o
  *                             K % 16 == 0, K <= 65536, N % 4 == 0, 16-B aligned pointers.
  *   asq_quantize_act_off      asq_quantize_act (same modes, same arithmetic) emitting x' and row_off int32 [M][2] = {cx[m], sum_k x'[m,k]}.
  *                             K % 8 == 0 (f32: 4), K <= 40960 (f32: 20480), x 16-B aligned, row_off 8-B aligned.
- *   asq_linear_w8a8_off       asq_linear_w8a8 on (x', w') + the two vectors; out_dtype ASQ_F16 / ASQ_BF16, K % 128 == 0, 128 <= K <= 65536,
+ *   asq_linear_w8a8_off       asq_linear_w8a8 on (x', w') + the two vectors; any out_dtype, K % 128 == 0, 128 <= K <= 65536,
  *                             N % 4 == 0, 16-B aligned operands; always the 256 x 256 kernel, no workspace.
- *   asq_offsets_supported     1 when the dispatcher itself would run (M, N, K) with 2-byte outputs on that kernel (>= 144 tiles of 256 x 256, no
+ *   asq_offsets_supported     1 when the dispatcher itself would run (M, N, K) on that kernel (>= 144 tiles of 256 x 256, no
  *                             column remainder launch) and the limits above hold; ASQ_OFFSETS=0 in the environment makes it return 0.
  *   asq_linear_w8a8_forward_off  asq_linear_w8a8_forward with the weight's image: uses the offset path when asq_offsets_supported() and the
  *                             workspace has asq_linear_w8a8_workspace_bytes(); otherwise it IS asq_linear_w8a8_forward (w_off / col_off may be NULL).

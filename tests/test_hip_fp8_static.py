@@ -1,7 +1,7 @@
 """GPU (-m gpu): the fp8 static calibration on the device against G5b -- FP8StaticLinearQuantizer (running-maximum input scale, the GEMM on the RUNNING
 scale; reference layers/nn/linear.py:455-500) and quantize_activations_fp8 (quantize/calibration.py:292-339) on the toy LLaMA, then FP8LinearStatic.from_float.
-Tolerance: the scales are absmax / 448 of the same inputs -> exact for module inputs that are exact (part 1), 2e-4 relative where they are fp32 sums of a
-model forward (part 2); outputs 1e-3 relative (fp32 summation order; the fp8 matrix cores accumulate in fp32)."""
+Tolerance: the scales are absmax / 448 of the same inputs -> exact for module inputs that are exact (part 1), 2e-4 relative for the first linears of the model
+forward and 3e-2 behind fp8 GEMMs (part 2, see there); outputs 1e-3 relative (fp32 summation order; the fp8 matrix cores accumulate in fp32)."""
 import os
 
 import numpy as np
@@ -64,7 +64,10 @@ def test_quantize_activations_fp8_flow_matches_the_reference():
         assert np.array_equal(m.weight.detach().view(torch.uint8).cpu().numpy(), G[f"p2_wq::{n}"]), n
         assert abs(float(m.weight_scale) - float(G[f"p2_ws::{n}"])) <= 1.2e-7 * float(G[f"p2_ws::{n}"]), n   # (absmax / 448 computed by torch ON THE DEVICE: its fp32 division may differ from the host's in the last place)
         ref_s = float(G[f"p2_in_scale::{n}"])
-        assert abs(float(m.input_scale) - ref_s) <= 2e-4 * ref_s, (n, float(m.input_scale), ref_s)
+        # layer 0's q/k/v read the (float) embedding norm: same inputs as the recording up to fp32 summation order.  Everything behind them has been through fp8
+        # GEMMs: a last-place difference in a sum flips e4m3 codes (2^-3 relative each) and the absmax statistics downstream move by up to a few per cent
+        first = n.startswith("model.layers.0.self_attn.") and n.rsplit(".", 1)[1] in ("q_proj", "k_proj", "v_proj")
+        assert abs(float(m.input_scale) - ref_s) <= (2e-4 if first else 3e-2) * ref_s, (n, float(m.input_scale), ref_s)
         key = f"p2_static_y::{n}"
         if key in G.files:
             st = FP8LinearStatic.from_float(m).to(DEV)

@@ -95,12 +95,12 @@ def test_linear_off_equals_plain_linear_bit_for_bit(kind):
         s_row = torch.from_numpy(rng.random(M).astype(np.float32) * 0.01 + 1e-3).to(DEV)
         s_col = torch.from_numpy(rng.random(N).astype(np.float32) * 1e-3 + 1e-4).to(DEV)
         bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(DEV)
-        for dt in (torch.float16, torch.bfloat16):
+        for dt in (torch.float16, torch.bfloat16, torch.float32):
             for (sr, sc, b) in ((None, None, None), (s_row, None, None), (None, s_col, bias), (s_row, s_col, bias)):
                 for order in ("scale_first", "acc_first"):
                     ref = ops.linear_w8a8(xt, wt, dt, 1.25e-4, sr, sc, b, order)
                     got = ops.linear_w8a8_off(torch.from_numpy(xo).to(DEV), w_off, torch.from_numpy(ro).to(DEV), col_off, dt, 1.25e-4, sr, sc, b, order)
-                    assert torch.equal(ref.view(torch.int16), got.view(torch.int16)), (kind, M, N, K, dt, order)
+                    assert torch.equal(ref.view(torch.int16), got.view(torch.int16)), (kind, M, N, K, dt, order)   # (bit patterns: NaN-proof, any element size)
         # and the int32 accumulators themselves, through a unit-scale fp path that is exact for small sums: compare with the oracle's integer product
         if K <= 256 and kind != "extremes":
             acc = OFF.product_from_images(xo, ro, *OFF.weight_image(w))
@@ -110,11 +110,11 @@ def test_linear_off_equals_plain_linear_bit_for_bit(kind):
 def test_offsets_argument_errors():
     from autosmoothquant_amd import _lib
     h = _lib.lib()
-    assert h.asq_linear_w8a8_off(256, 256, 256, 0, 4, 4, 128, 1.0, None, None, None, 0, 256, 256, None) == -3      # fp32 outputs: not on this kernel
+    assert h.asq_linear_w8a8_off(256, 256, 256, 7, 4, 4, 128, 1.0, None, None, None, 0, 256, 256, None) == -3      # unknown out_dtype
     assert h.asq_linear_w8a8_off(256, 256, 256, 1, 4, 4, 128, 1.0, None, None, None, 0, None, 256, None) == -1     # NULL row_off
     assert h.asq_linear_w8a8_off(256, 256, 256, 1, 4, 6, 128, 1.0, None, None, None, 0, 256, 256, None) == -2      # N % 4
     assert h.asq_linear_w8a8_off(256, 256, 256, 1, 4, 4, 131072, 1.0, None, None, None, 0, 256, 256, None) == -2   # K > 65536
-    assert h.asq_offsets_supported(4096, 4096, 4096, 1) == 1 and h.asq_offsets_supported(4096, 4096, 4096, 0) == 0
+    assert h.asq_offsets_supported(4096, 4096, 4096, 1) == 1 and h.asq_offsets_supported(4096, 4096, 4096, 0) == 1 and h.asq_offsets_supported(4096, 4096, 4096, 9) == 0
     assert h.asq_offsets_supported(64, 4096, 4096, 1) == 0 and h.asq_offsets_supported(4096, 4096, 131072, 1) == 0
 
 
