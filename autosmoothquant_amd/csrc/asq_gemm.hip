@@ -139,7 +139,11 @@ extern "C" int asq_offsets_supported(int64_t M, int64_t N, int64_t K, int out_dt
     if (!offsets_enabled() || (out_dtype != ASQ_F16 && out_dtype != ASQ_BF16 && out_dtype != ASQ_F32) || M <= 0 || N <= 0 || K <= 0) return 0;
     if (!offsets_shape_ok(nullptr, nullptr, M, N, K) || K / (out_dtype == ASQ_F32 ? 4 : 8) > 256 * 20) return 0;   // (second: asq_quantize_act_off keeps the row in registers)
     const GemmKernel kern = pick_kernel(nullptr, nullptr, M, N, K);
-    return kern == KERN_P16 && plan_tail_peel(kern, M, N, K).n_main == 0 ? 1 : 0;
+    if (kern != KERN_P16) return 0;
+    // a launch with a peeled column remainder runs on plain operands (the remainder kernels take no images) -- unless it has three or more full rounds: then the
+    // images are worth more than the peel (8192 x 11008 x 4096: -5.7 % against -3.2 %; 2048 x 11008 x 4096: -2.7 % against -9.5 %; profiles/r4_tail_rule_ab.txt)
+    const int64_t tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    return plan_tail_peel(kern, M, N, K).n_main == 0 || tiles >= 3 * 256 ? 1 : 0;
 }
 
 extern "C" int asq_linear_w8a8_off(const int8_t *xq_off, const int8_t *w_off, void *out, int out_dtype, int64_t M, int64_t N, int64_t K, float s_scalar,

@@ -1325,6 +1325,7 @@ template <class Epi> int launch_skinny(const int8_t *x, const int8_t *w, int64_t
 struct TailPeel {
     int64_t n_main = 0;  // columns [0, n_main) stay with the main launch; 0 = no peel
     size_t ws_bytes = 0; // workspace that lets the remainder split K (optional)
+    bool rem_p8h = false; // the remainder runs on 128 x 256 tiles (gemm_i8_p8h) instead of 128 x 128 (gemm_i8_p8q)
 };
 static inline TailPeel plan_tail_peel(GemmKernel kern, int64_t M, int64_t N, int64_t K)
 {
@@ -1336,12 +1337,19 @@ static inline TailPeel plan_tail_peel(GemmKernel kern, int64_t M, int64_t N, int
     const int64_t rows = kern == KERN_P8H ? 128 : 256;
     const int64_t tm = (M + rows - 1) / rows, tn = (N + 255) / 256, tiles = tm * tn;
     const int64_t full = tiles / 256, r = tiles % 256;
-    if (full < 1 || r == 0 || r > 96) return p;
+    // Round 4 (profiles/r4_tail_sweep.txt, 2048 rows x (32 + c) tile columns, K = 4096, remainder = 8 c tiles of 256 x 256): as 128 x 128 tiles (p8q, four times
+    // the blocks) the remainder gains 21 ... 14 % up to 64 tiles and nothing beyond; as 128 x 256 tiles (p8h, ONE round of twice the blocks) 11 ... 7 % from 88 to
+    // 128 tiles; from 160 tiles on both lose to the plain second round.
+    const int64_t r_max = rows == 256 ? 128 : 96;
+    if (full < 1 || r == 0 || r > r_max) return p;
     const int64_t c = (r + tm - 1) / tm;
-    if (c >= tn || ((M + 255) / 256) * c > 48) return p;  // measured: remainders of 6-36 256 x 256 tiles' worth gain 3-19 %, 88 (2048 x 11008) nothing
+    const int64_t rem256 = ((M + 255) / 256) * c;   // the remainder in 256 x 256 tiles' worth
+    if (c >= tn || rem256 > (rows == 256 ? 128 : 48)) return p;
+    p.rem_p8h = rem256 > 64;
     p.n_main = (tn - c) * 256;
     const int64_t n_rem = N - p.n_main;
-    const int ks = pick_ksplit_p8q(((M + 127) / 128) * ((n_rem + 127) / 128), K, M, n_rem, (size_t)-1);
+    const int ks = p.rem_p8h ? pick_ksplit_p8h(((M + 127) / 128) * ((n_rem + 255) / 256), K, M, n_rem, (size_t)-1)
+                             : pick_ksplit_p8q(((M + 127) / 128) * ((n_rem + 127) / 128), K, M, n_rem, (size_t)-1);
     p.ws_bytes = ks > 1 ? (size_t)ks * (size_t)M * (size_t)n_rem * 4 : 0;
     return p;
 }
@@ -1373,7 +1381,7 @@ template <class Epi> struct HasColView<Epi, std::enable_if_t<Epi::kColView>> : s
 // `ws` below is the scratch part (split-K slabs), `ws_hdr` the whole thing (null when the caller's buffer is too small to hold a header).
 template <class Epi>
 int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, Epi epi, hipStream_t s, const char *what, void *ws_hdr, void *ws,
-                     size_t ws_bytes, const int *goffs = nullptr, int ngroups = 0, int peel_role = 0 /* 0 top level, 1 main part, 2 remainder (128 x 128 tiles) */,
+                     size_t ws_bytes, const int *goffs = nullptr, int ngroups = 0, int peel_role = 0 /* 0 top level, 1 main part, 2 / 3 remainder (128 x 128 / 128 x 256 tiles) */,
                      OffsetArgs off = OffsetArgs{})
 {
     if (M == 0 || N == 0) return ASQ_OK;
@@ -1415,7 +1423,7 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
         return asq_after_launch(s, what);
     }
     constexpr bool kInt = Epi::Mma::kIsInt;
-    GemmKernel kern = peel_role == 2 ? KERN_P8Q : pick_kernel(x, w, M, N, K);
+    GemmKernel kern = peel_role == 2 ? KERN_P8Q : peel_role == 3 ? KERN_P8H : pick_kernel(x, w, M, N, K);   // (2 / 3: the column remainder of a tail peel)
     if (off.row != nullptr) {   // offset operands: gemm_i8_p16 only (the entry point has checked the shape: offsets_supported)
         ASQ_REQUIRE(kInt && (Epi::kOutBytes == 2 || Epi::kOutBytes == 4) && offsets_shape_ok(x, w, M, N, K), ASQ_ERR_DIM, "%s: offset operands need the 256 x 256 kernel (2- or 4-byte output, K %% 128 == 0, K <= 65536, N %% 4 == 0, aligned operands)", what);
         kern = KERN_P16;
@@ -1426,7 +1434,7 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
             if (tp.n_main > 0) {
                 const int rc = launch_gemm_impl(x, w, M, tp.n_main, K, epi, s, what, nullptr, nullptr, 0, nullptr, 0, 1);
                 if (rc) return rc;
-                return launch_gemm_impl(x, w + tp.n_main * K, M, N - tp.n_main, K, epi.col_view(tp.n_main), s, what, nullptr, ws, ws_bytes, nullptr, 0, 2);
+                return launch_gemm_impl(x, w + tp.n_main * K, M, N - tp.n_main, K, epi.col_view(tp.n_main), s, what, nullptr, ws, ws_bytes, nullptr, 0, tp.rem_p8h ? 3 : 2);
             }
         }
     }

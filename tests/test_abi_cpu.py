@@ -67,7 +67,8 @@ def test_argument_errors_without_gpu():
     assert h.asq_gemm_kernel_name(3072, 11008, 8192) == b"p16+tail"
     assert h.asq_gemm_kernel_name(1536, 12288, 4096) == b"p16+tail"       # 288 tiles: 6 tile columns (36 tiles' worth) as 128 x 128 tiles
     assert h.asq_gemm_kernel_name(768, 11008, 4096) == b"p8h+tail"       # 258 tiles of 128 rows
-    assert h.asq_gemm_kernel_name(2048, 11008, 4096) == b"p16"           # last wave 88 / 256 full: left alone
+    assert h.asq_gemm_kernel_name(2048, 11008, 4096) == b"p16+tail"      # last wave 88 / 256 full: r4 -- 11 tile columns as ONE round of 128 x 256 tiles (p8h), 85 -> 76 us
+    assert h.asq_gemm_kernel_name(2048, 13312, 4096) == b"p16"           # 160 tiles over: both remainder forms lose to the second round
     assert h.asq_gemm_kernel_name(65536, 11008, 4096) == b"p16"          # cfg3: 43 full waves
 
 

@@ -710,7 +710,8 @@ def test_forward_workspace_cache_streams_growth_and_graph_replay(dev):
     assert np.array_equal(t_out(yg), want_g)
 
 
-TAIL_SHAPES = [(1536, 11008, 4096), (4352, 4096, 4096), (1536, 11000, 4096), (3072, 11008, 8192), (768, 11008, 4096), (1152, 14336, 4096)]
+TAIL_SHAPES = [(1536, 11008, 4096), (4352, 4096, 4096), (1536, 11000, 4096), (3072, 11008, 8192), (768, 11008, 4096), (1152, 14336, 4096),
+               (2048, 11008, 4096), (2000, 12284, 4096)]   # (the last two: remainders of 88 / 128 tiles, run as one round of 128 x 256 tiles -- gemm_i8_p8h)
 
 
 def _tail_case(shape, dev):
