@@ -1438,144 +1438,108 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
             }
         }
     }
-    constexpr bool kP4 = kInt && Epi::kOutBytes == 2;  // the 4-wave kernel: int8 operands, 2-byte outputs (its row epilogue; the int32 / int8-out
-                                                       // epilogues next to 256 accumulator registers would spill)
-    if (kern == KERN_P4 && !kP4) kern = KERN_P8;
-    if constexpr (kP4) if (kern == KERN_P4) {
-        const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
-        ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
-        auto kfn = gemm_i8_p4<Epi>;
-        hipError_t e = ensure_dynamic_lds((const void *)kfn, P4_LDS_BYTES);
+    // ---- the tiled kernels: one launcher (dynamic-LDS attribute once per kernel, launch) and one split-K tail (exact int32 slabs, then reduce + the caller's epilogue)
+    auto launch_tiled = [&](auto kfn, int lds_attr, int lds, int64_t grid, int block, auto... args) -> int {
+        ASQ_REQUIRE(grid < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
+        const hipError_t e = ensure_dynamic_lds((const void *)kfn, lds_attr);
         if (e != hipSuccess) {
             asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
             return (int)e;
         }
-        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(256), P4_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, epi);
-        return asq_after_launch(s, what);
-    }
-    // four waves x 128 x 128 on the 16 x 16 x 64 instruction (asq_gemm_p4x16.h): scalar / per-token scale epilogues with 2-byte outputs; otherwise p16
-    if (kern == KERN_P4X16) {
-        constexpr bool kP4X = kP4 && !Epi::kHasCol && !Epi::kHasBias;
-        if constexpr (kP4X) {
-            const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
-            ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
-            auto kfn = gemm_i8_p4x16<Epi>;
-            hipError_t e = ensure_dynamic_lds((const void *)kfn, P4_LDS_BYTES);
-            if (e != hipSuccess) {
-                asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
-                return (int)e;
-            }
-            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(256), P4_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, epi);
-            return asq_after_launch(s, what);
-        } else {
-            kern = KERN_P16;
+        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)block), lds, s, x, w, M, N, K, args...);
+        return ASQ_OK;
+    };
+    auto reduce_slabs = [&](int ksplit) {
+        if constexpr (kInt) {
+            int64_t blocks = (M * (N / 4) + 255) / 256;
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL((splitk_reduce<Epi>), dim3((unsigned)blocks), dim3(256), 0, s, (const int32_t *)ws, ksplit, M, N, epi);
         }
-    }
-    // the 256 x 256 kernel on v_mfma_i32_16x16x64_i8 (asq_gemm_p16.h): plain launches with 2-byte outputs
-    bool p8_l16 = false;   // what p16 does not carry runs on p8 -- in its L16 mode (the same 16 x 16 x 64 instruction) unless p8 itself was asked for
-    constexpr bool kP16 = kInt && (Epi::kOutBytes == 2 || Epi::kOutBytes == 4);   // (round 4: 4-byte outputs -- int32 accumulators, fp32 -- through epilogue_wave_rows4)
+    };
+    const bool ws_ok = kInt && ws != nullptr && (((uintptr_t)ws) & 15) == 0;
+    const int64_t tm256 = (M + 255) / 256, tm128 = (M + 127) / 128, tn256 = (N + 255) / 256, tn128 = (N + 127) / 128;
+    [[maybe_unused]] const EpiI32 slab{(int32_t *)ws, N, true};
+    const int *const no_groups = nullptr;
+    char *const no_gws = nullptr;
+    const uint8_t *const no_mx = nullptr;
+    int rc = ASQ_OK;
+
+    constexpr bool kP4 = kInt && Epi::kOutBytes == 2;  // the 4-wave kernels: int8 operands, 2-byte outputs (their row epilogue; the int32 / int8-out
+                                                       // epilogues next to 256 accumulator registers would spill)
+    if (kern == KERN_P4 && !kP4) kern = KERN_P8;
+    // four waves x 128 x 128 on the 16 x 16 x 64 instruction (asq_gemm_p4x16.h): scalar / per-token scale epilogues with 2-byte outputs; otherwise p16
+    constexpr bool kP4X = kP4 && !Epi::kHasCol && !Epi::kHasBias;
+    if (kern == KERN_P4X16 && !kP4X) kern = KERN_P16;
+    // the 256 x 256 kernel on v_mfma_i32_16x16x64_i8 (asq_gemm_p16.h): plain launches with 2- and (round 4, epilogue_wave_rows4) 4-byte outputs; what it does not
+    // carry -- int8 outputs, K splits -- runs on p8, in its L16 mode (the same instruction) unless the 32 x 32 x 32 form was asked for
+    constexpr bool kP16 = kInt && (Epi::kOutBytes == 2 || Epi::kOutBytes == 4);
+    bool p8_l16 = false;
     if (kern == KERN_P16 && !kP16) {
         kern = KERN_P8;
         p8_l16 = kInt && !mma32_forced();
     }
-    if constexpr (kP16) if (kern == KERN_P16) {
-        const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
-        ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
-        auto kfn = gemm_i8_p16<Epi>;
-        hipError_t e = ensure_dynamic_lds((const void *)kfn, P16_LDS_BYTES);
-        if (e != hipSuccess) {
-            asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
-            return (int)e;
-        }
-        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), off.row ? P16_LDS_BYTES : P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, epi, off);
-        return asq_after_launch(s, what);
-    }
-    ASQ_REQUIRE(off.row == nullptr, ASQ_ERR_DIM, "%s: offset operands: no kernel", what);
-    if (kern == KERN_P8) {
-        const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
-        ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
-        const int ksplit = (kInt && ws != nullptr && (((uintptr_t)ws) & 15) == 0) ? pick_ksplit(tm * tn, K, M, N, ws_bytes) : 1;
-        if constexpr (kInt) if (ksplit > 1) {
-            // pass 1: int32 partial slabs; pass 2: reduce + the caller's epilogue
-            EpiI32 slab{(int32_t *)ws, N, true};
-            auto kfn = p8_l16 ? gemm_i8_p8<EpiI32, 0, false, true> : gemm_i8_p8<EpiI32>;
-            hipError_t e = ensure_dynamic_lds((const void *)kfn, P8_LDS_BYTES);
-            if (e != hipSuccess) {
-                asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
-                return (int)e;
+    ASQ_REQUIRE(off.row == nullptr || kern == KERN_P16, ASQ_ERR_DIM, "%s: offset operands: no kernel", what);
+
+    if (kern == KERN_P4) {
+        if constexpr (kP4) rc = launch_tiled(gemm_i8_p4<Epi>, P4_LDS_BYTES, P4_LDS_BYTES, tm256 * tn256, 256, (int)tm256, (int)tn256, epi);
+    } else if (kern == KERN_P4X16) {
+        if constexpr (kP4X) rc = launch_tiled(gemm_i8_p4x16<Epi>, P4_LDS_BYTES, P4_LDS_BYTES, tm256 * tn256, 256, (int)tm256, (int)tn256, epi);
+    } else if (kern == KERN_P16) {
+        if constexpr (kP16) rc = launch_tiled(gemm_i8_p16<Epi>, P16_LDS_BYTES, off.row ? P16_LDS_BYTES : P8_LDS_BYTES, tm256 * tn256, 512, (int)tm256, (int)tn256, epi, off);
+    } else if (kern == KERN_P8) {
+        const int ksplit = ws_ok ? pick_ksplit(tm256 * tn256, K, M, N, ws_bytes) : 1;
+        if (ksplit > 1) {
+            if constexpr (kInt) {
+                rc = p8_l16 ? launch_tiled(gemm_i8_p8<EpiI32, 0, false, true>, P8_LDS_BYTES, P8_LDS_BYTES, tm256 * tn256 * ksplit, 512, (int)tm256, (int)tn256, ksplit, no_groups, 0, no_gws, slab, OffsetArgs{})
+                            : launch_tiled(gemm_i8_p8<EpiI32>, P8_LDS_BYTES, P8_LDS_BYTES, tm256 * tn256 * ksplit, 512, (int)tm256, (int)tn256, ksplit, no_groups, 0, no_gws, slab, OffsetArgs{});
+                if (rc == ASQ_OK) reduce_slabs(ksplit);
             }
-            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn * ksplit)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, ksplit, (const int *)nullptr, 0, (char *)nullptr, slab, OffsetArgs{});
-            int64_t blocks = (M * (N / 4) + 255) / 256;
-            if (blocks > 8192) blocks = 8192;
-            hipLaunchKernelGGL((splitk_reduce<Epi>), dim3((unsigned)blocks), dim3(256), 0, s, (const int32_t *)ws, ksplit, M, N, epi);
-            return asq_after_launch(s, what);
+        } else {
+            bool done = false;
+            if constexpr (kInt && !kP16) {   // (int8 outputs at p16's sizes)
+                if (p8_l16) {
+                    rc = launch_tiled(gemm_i8_p8<Epi, 0, false, true>, P8_LDS_BYTES, P8_LDS_BYTES, tm256 * tn256, 512, (int)tm256, (int)tn256, 1, no_groups, 0, no_gws, epi, OffsetArgs{});
+                    done = true;
+                }
+            }
+            if (!done) rc = launch_tiled(gemm_i8_p8<Epi>, P8_LDS_BYTES, P8_LDS_BYTES, tm256 * tn256, 512, (int)tm256, (int)tn256, 1, no_groups, 0, no_gws, epi, OffsetArgs{});
         }
-        auto kfn = gemm_i8_p8<Epi>;
-        if constexpr (kInt && !kP4) {   // (2-byte outputs have gemm_i8_p16 for this)
-            if (p8_l16) kfn = gemm_i8_p8<Epi, 0, false, true>;
-        }
-        hipError_t e = ensure_dynamic_lds((const void *)kfn, P8_LDS_BYTES);
-        if (e != hipSuccess) {
-            asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
-            return (int)e;
-        }
-        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, (const int *)nullptr, 0, (char *)nullptr, epi, OffsetArgs{});
     } else if (kern == KERN_P8H) {
-        const int64_t tm = (M + 127) / 128, tn = (N + 255) / 256;
-        ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
-        const int ksplit = (kInt && ws != nullptr && (((uintptr_t)ws) & 15) == 0) ? pick_ksplit_p8h(tm * tn, K, M, N, ws_bytes) : 1;
-        if constexpr (kInt) if (ksplit > 1) {
-            EpiI32 slab{(int32_t *)ws, N, true};
-            auto kfn = mma32_forced() ? gemm_i8_p8h<EpiI32> : gemm_i8_p8h<EpiI32, false, true>;
-            hipError_t e = ensure_dynamic_lds((const void *)kfn, P8H_LDS_BYTES);
-            if (e != hipSuccess) {
-                asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
-                return (int)e;
+        const int ksplit = ws_ok ? pick_ksplit_p8h(tm128 * tn256, K, M, N, ws_bytes) : 1;
+        if (ksplit > 1) {
+            if constexpr (kInt) {
+                rc = mma32_forced() ? launch_tiled(gemm_i8_p8h<EpiI32>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256 * ksplit, 512, (int)tm128, (int)tn256, ksplit, slab)
+                                    : launch_tiled(gemm_i8_p8h<EpiI32, false, true>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256 * ksplit, 512, (int)tm128, (int)tn256, ksplit, slab);
+                if (rc == ASQ_OK) reduce_slabs(ksplit);
             }
-            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn * ksplit)), dim3(512), P8H_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, ksplit, slab);
-            int64_t blocks = (M * (N / 4) + 255) / 256;
-            if (blocks > 8192) blocks = 8192;
-            hipLaunchKernelGGL((splitk_reduce<Epi>), dim3((unsigned)blocks), dim3(256), 0, s, (const int32_t *)ws, ksplit, M, N, epi);
-            return asq_after_launch(s, what);
+        } else {
+            bool done = false;
+            if constexpr (kInt) {
+                if (!mma32_forced()) {
+                    rc = launch_tiled(gemm_i8_p8h<Epi, false, true>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256, 512, (int)tm128, (int)tn256, 1, epi);
+                    done = true;
+                }
+            }
+            if (!done) rc = launch_tiled(gemm_i8_p8h<Epi>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256, 512, (int)tm128, (int)tn256, 1, epi);
         }
-        auto kfn = gemm_i8_p8h<Epi>;
-        if constexpr (kInt) {
-            if (!mma32_forced()) kfn = gemm_i8_p8h<Epi, false, true>;
-        }
-        hipError_t e = ensure_dynamic_lds((const void *)kfn, P8H_LDS_BYTES);
-        if (e != hipSuccess) {
-            asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
-            return (int)e;
-        }
-        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8H_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, epi);
     } else if (kern == KERN_P8Q) {
-        const int64_t tm = (M + 127) / 128, tn = (N + 127) / 128;
-        ASQ_REQUIRE(tm * tn < (1ll << 24), ASQ_ERR_DIM, "%s: too many tiles", what);
-        const int ksplit = (kInt && ws != nullptr && (((uintptr_t)ws) & 15) == 0) ? pick_ksplit_p8q(tm * tn, K, M, N, ws_bytes) : 1;
-        if constexpr (kInt) if (ksplit > 1) {
-            EpiI32 slab{(int32_t *)ws, N, true};
-            auto kfn = mma32_forced() ? gemm_i8_p8q<EpiI32> : gemm_i8_p8q<EpiI32, false, true>;
-            hipError_t e = ensure_dynamic_lds((const void *)kfn, P8Q_LDS_BYTES);
-            if (e != hipSuccess) {
-                asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
-                return (int)e;
+        const int ksplit = ws_ok ? pick_ksplit_p8q(tm128 * tn128, K, M, N, ws_bytes) : 1;
+        if (ksplit > 1) {
+            if constexpr (kInt) {
+                rc = mma32_forced() ? launch_tiled(gemm_i8_p8q<EpiI32>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128 * ksplit, 512, (int)tm128, (int)tn128, ksplit, slab, no_mx, no_mx)
+                                    : launch_tiled(gemm_i8_p8q<EpiI32, false, true>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128 * ksplit, 512, (int)tm128, (int)tn128, ksplit, slab, no_mx, no_mx);
+                if (rc == ASQ_OK) reduce_slabs(ksplit);
             }
-            hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn * ksplit)), dim3(512), P8Q_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, ksplit, slab, (const uint8_t *)nullptr, (const uint8_t *)nullptr);
-            int64_t blocks = (M * (N / 4) + 255) / 256;
-            if (blocks > 8192) blocks = 8192;
-            hipLaunchKernelGGL((splitk_reduce<Epi>), dim3((unsigned)blocks), dim3(256), 0, s, (const int32_t *)ws, ksplit, M, N, epi);
-            return asq_after_launch(s, what);
+        } else {
+            bool done = false;
+            if constexpr (kInt) {
+                if (!mma32_forced()) {
+                    rc = launch_tiled(gemm_i8_p8q<Epi, false, true>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128, 512, (int)tm128, (int)tn128, 1, epi, no_mx, no_mx);
+                    done = true;
+                }
+            }
+            if (!done) rc = launch_tiled(gemm_i8_p8q<Epi>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128, 512, (int)tm128, (int)tn128, 1, epi, no_mx, no_mx);
         }
-        auto kfn = gemm_i8_p8q<Epi>;
-        if constexpr (kInt) {
-            if (!mma32_forced()) kfn = gemm_i8_p8q<Epi, false, true>;
-        }
-        hipError_t e = ensure_dynamic_lds((const void *)kfn, P8Q_LDS_BYTES);
-        if (e != hipSuccess) {
-            asq_set_error("%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
-            return (int)e;
-        }
-        hipLaunchKernelGGL(kfn, dim3((unsigned)(tm * tn)), dim3(512), P8Q_LDS_BYTES, s, x, w, M, N, K, (int)tm, (int)tn, 1, epi, (const uint8_t *)nullptr, (const uint8_t *)nullptr);
     } else if (kern == KERN_SKINNY) {
         const int rc = launch_skinny(x, w, M, N, K, epi, s, ws_hdr, ws_hdr ? ws_bytes + WS_HEADER_BYTES : 0);
         if (rc) return rc;
@@ -1585,6 +1549,7 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
         ASQ_REQUIRE(grid.y < 65536, ASQ_ERR_DIM, "%s: M too large for the generic kernel (K %% 128 != 0 or unaligned operands)", what);
         hipLaunchKernelGGL((gemm_i8_generic<Epi>), grid, dim3(256), 0, s, x, w, M, N, K, fast, epi);
     }
+    if (rc != ASQ_OK) return rc;
     return asq_after_launch(s, what);
 }
 
