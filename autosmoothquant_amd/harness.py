@@ -546,6 +546,8 @@ class MixtralLayer(LlamaLayer):
         key = (st.data_ptr(), ver, st.device)
         hit = self.__dict__.get(f"_{name}_image")
         if hit is None or hit[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                return None   # (see _W8A8Base.offset_image)
             E, N, K = st.shape
             img, col = ops.weight_offset_image(st.view(E * N, K))
             hit = (key, (img.view(E, N, K), col.view(E, N, 2)))
@@ -585,6 +587,9 @@ class MixtralLayer(LlamaLayer):
             if getattr(self, "offsets", True) and ops.grouped_offsets_supported(R, self._w1_stack.shape[1], H, x.dtype) and ops.grouped_offsets_supported(R, H, self._w2_stack.shape[-1], x.dtype):
                 # offset operand images (include/asq_hip.h): same products, less matrix-core energy; the stacks' images are built once and follow the stacks
                 i1, i3, i2 = (self._stack_image(n) for n in ("w1", "w3", "w2"))
+            else:
+                i1 = None
+            if i1 is not None and i3 is not None and i2 is not None:
                 xq, srow, ro = ops.quantize_act_off(xs.contiguous(), mode, qs)
                 h1 = ops.linear_w8a8_grouped_off(xq, i1[0], ro, i1[1], offs, self._w1_scale, x.dtype, srow)
                 h3 = ops.linear_w8a8_grouped_off(xq, i3[0], ro, i3[1], offs, self._w3_scale, x.dtype, srow)

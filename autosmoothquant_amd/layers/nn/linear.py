@@ -162,9 +162,16 @@ class _W8A8Base(torch.nn.Module):
         key = (w.data_ptr(), ver, w.device)
         hit = self.__dict__.get("_offset_cache")
         if hit is None or hit[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                return None   # (an image built inside a capture would only exist after the first replay: this capture runs on the plain operands)
             hit = (key, ops.weight_offset_image(w))
             self.__dict__["_offset_cache"] = hit
         return hit[1]
+
+    def invalidate_offset_image(self):
+        """Drop the cached image.  Needed only after a write into `weight` that torch cannot see (a raw pointer write, an external library): in-place torch
+        operations, load_state_dict, .to() and replica.broadcast_quantized change the storage or its version counter and rebuild the image by themselves."""
+        self.__dict__.pop("_offset_cache", None)
 
     def forward_q(self, x, consumer, act=None):
         """This linear, an optional activation (act = "relu": OPT's fc1 -> ReLU -> fc2, reference models/opt.py:127-128) and the
