@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdarg.h>
+#include <utility>
+#include <type_traits>
 
 #include "../../include/asq_hip.h"
 
@@ -103,6 +105,13 @@ template <> struct ElemT<ASQ_BF16> {
     __device__ static __forceinline__ float round(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
     __device__ static __forceinline__ uint16_t store(float v) { return f32_to_bf16_bits(v); }
 };
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // .round().clamp(-128,127).to(int8): half-to-even; NaN -> 0 (reference CPU path), +-inf saturate
 // Three instructions: v_rndne_f32, v_cvt_i32_f32 (the hardware conversion saturates out-of-range values and +-inf and turns NaN

@@ -486,11 +486,6 @@ template <int DT, bool HAS_BIAS, class MMA_ = MmaFp8> struct EpiFp8 {
     }
 };
 
-template <class F, int... I> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>)
-{
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // Wave-level epilogue over NTN x NTM accumulator tiles; tile (in, im) covers
 // n in [nw0 + 32*in, +32), m in [mw0 + mstep(im), +32).  `get(in, im)` returns the v16i.

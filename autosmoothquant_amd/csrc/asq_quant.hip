@@ -6,6 +6,8 @@
 // cast, div, round, clamp, cast as separate ATen launches).
 #include "asq_common.h"
 #include <type_traits>
+#include <algorithm>
+#include <cstdlib>
 
 namespace asq {
 
@@ -278,6 +280,15 @@ struct RowStats {
         sum += a + b;
         n += 4;
     }
+    // branch-free form for a lane whose vector may be a DUPLICATE of a valid one (max / min do not care; sum and count must skip it)
+    __device__ __forceinline__ void add(uint32_t packed, bool valid)
+    {
+        const uint32_t u = packed ^ 0x80808080u, a = u & 0x00FF00FFu, b = (u >> 8) & 0x00FF00FFu;
+        mx = pk_max_u16(mx, pk_max_u16(a, b));
+        mn = pk_min_u16(mn, pk_min_u16(a, b));
+        sum += valid ? a + b : 0u;
+        n += valid ? 4 : 0;
+    }
 };
 // block-wide (256 threads) max / min / sum of the quantised row; red: 12 ints of shared memory
 __device__ __forceinline__ void block_row_stats(const RowStats &st, int *red, int &rmax, int &rmin, int &rsum)
@@ -380,86 +391,105 @@ __global__ void __launch_bounds__(256) quant_rows_off(const void *__restrict__ x
 // 15.1 / 17.4 us for 4096 x 4096 fp16 (3.3 / 2.9 TB/s) against 12.5 us for the flat per-tensor kernel.  Here a wave owns a row: NV 16-byte loads per lane in flight
 // (non-temporal: the activation is read once), every reduction a wave butterfly, no LDS, no barrier; 4 rows per 256-thread block.  K <= 64 * VEC * NV.
 // OFF = false is the plain per-token quantiser (same arithmetic as quant_per_token_cached), OFF = true emits the offset image + row_off.
-__device__ __forceinline__ v4i load16_nt(const void *p)
+// The loads are inline asm and the waits are counted BY HAND (hipcc does not count asm memory operations): with C loads under `if (idx < nvec)` hipcc waited
+// for each load at its branch's join -- ONE load in flight per wave instead of NV (4096 x 4096 fp16 per-token: 13.5 -> 10.7 us, its image 15.4 -> 12.7 us).
+__device__ __forceinline__ void load16_nt_async(v4i &dst, const void *p)
 {
-    return __builtin_nontemporal_load((const v4i *)p);
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(dst) : "v"(p) : "memory");
 }
+__device__ __forceinline__ void pin_vgprs(v4i &x) { asm volatile("" : "+v"(x)); }   // (uses of x stay below this point)
+template <int N> __device__ __forceinline__ void wait_vm()   // at most N vector memory operations still in flight (they retire in issue order)
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// (Tried and dropped: two rows per wave with the second row's loads in flight behind the first row's arithmetic -- 4 .. 10 % SLOWER than one row per wave at
+// every shape, profiles/r4_quantiser_rows.txt: the chip-wide bytes in flight matter more than overlapping a wave's own arithmetic.)
 template <int DT, int NV, class Q, bool PER_TOKEN, bool OFF>
 __global__ void __launch_bounds__(256) quant_rows_wave(const void *__restrict__ xv, int8_t *__restrict__ xq, float *__restrict__ s_row,
                                                        int32_t *__restrict__ row_off, int M, int K, Q q_in, int C)
 {
     constexpr int VEC = ElemT<DT>::VEC;
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (row >= M) return;   // (wave-uniform; nothing below synchronises across waves)
-    const char *xrow = (const char *)xv + row * (int64_t)K * (16 / VEC);
     const int nvec = K / VEC;
-    v4i v[NV];
-    [[maybe_unused]] AbsMax<DT> am;
+    // straight-line: a lane past the end of the row re-reads the row's last vector (a duplicate changes no maximum or minimum; sums and stores skip it)
+    auto load = [&](v4i (&v)[NV], int64_t r) {
+        const char *xrow = (const char *)xv + r * (int64_t)K * (16 / VEC);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int idx = i * 64 + lane;
-        if (idx < nvec) {
-            v[i] = load16_nt(xrow + (int64_t)idx * 16);
-            if constexpr (PER_TOKEN) am.add(v[i]);
+        for (int i = 0; i < NV; ++i) {
+            const int idx = i * 64 + lane;
+            load16_nt_async(v[i], xrow + (int64_t)(idx < nvec ? idx : nvec - 1) * 16);
         }
-    }
-    uint32_t o[NV][2];
-    [[maybe_unused]] RowStats st;
-    auto emit = [&](auto q) {
+    };
+    auto finish = [&](v4i (&v)[NV], int64_t r) {
+        [[maybe_unused]] AbsMax<DT> am;
+        uint32_t o[NV][2];
+        [[maybe_unused]] RowStats st;
+        auto arrive = [&](auto ic) {   // v[i] is in its registers from here on
+            constexpr int i = decltype(ic)::value;
+            wait_vm<NV - 1 - i>();   // (operations retire in issue order)
+            pin_vgprs(v[i]);
+        };
+        auto emit = [&](auto q, auto waits) {
+            static_for<NV>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (decltype(waits)::value) arrive(ic);
+                quant_vec<DT>(v[i], q, o[i]);
+                if constexpr (OFF) {
+                    const bool valid = i * 64 + lane < nvec;
+                    st.add(o[i][0], valid);
+                    if constexpr (DT != ASQ_F32) st.add(o[i][1], valid);
+                }
+            });
+        };
+        if constexpr (PER_TOKEN) {
+            static_for<NV>([&](auto ic) { arrive(ic); am.add(v[decltype(ic)::value]); });
+            uint32_t mb = am.f32bits();
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mb = umax32(mb, (uint32_t)__shfl_xor((int)mb, off, 64));
+            const float m = __uint_as_float(mb);
+            const float qs = ElemT<DT>::round(m / 127.0f);
+            if (lane == 0) s_row[r] = qs;
+            const RowDivisor d(qs, m);
+            if (d.fast) emit(QRowFast{d.s, d.y}, std::false_type{});
+            else emit(QDivF32<DT>{qs}, std::false_type{});
+        } else {
+            emit(q_in, std::true_type{});
+        }
+        uint32_t c4 = 0;
+        if constexpr (OFF) {
+            int mx = (int)umax32(st.mx & 0xFFFFu, st.mx >> 16) - 128, mn = (int)(((st.mn & 0xFFFFu) < (st.mn >> 16)) ? (st.mn & 0xFFFFu) : (st.mn >> 16)) - 128;
+            int sm = (int)((st.sum & 0xFFFFu) + (st.sum >> 16)) - 128 * st.n;
+            if (st.n == 0) { mx = -128; mn = 127; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const int omx = __shfl_xor(mx, off, 64), omn = __shfl_xor(mn, off, 64);
+                mx = mx > omx ? mx : omx;
+                mn = mn < omn ? mn : omn;
+                sm += __shfl_xor(sm, off, 64);
+            }
+            const int cx = pick_row_offset(mx, mn, C);
+            if (lane == 0) *(v2i *)(row_off + 2 * r) = (v2i){cx, sm + cx * K};
+            c4 = (uint32_t)(cx & 0xFF) * 0x01010101u;
+        }
+        int8_t *orow = xq + r * (int64_t)K;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = i * 64 + lane;
             if (idx < nvec) {
-                quant_vec<DT>(v[i], q, o[i]);
-                if constexpr (OFF) {
-                    st.add(o[i][0]);
-                    if constexpr (DT != ASQ_F32) st.add(o[i][1]);
+                if constexpr (DT == ASQ_F32) {
+                    *(uint32_t *)(orow + (int64_t)idx * 4) = OFF ? pk_add_i8(o[i][0], c4) : o[i][0];
+                } else {
+                    *(uint2 *)(orow + (int64_t)idx * 8) = OFF ? make_uint2(pk_add_i8(o[i][0], c4), pk_add_i8(o[i][1], c4)) : make_uint2(o[i][0], o[i][1]);
                 }
             }
         }
     };
-    if constexpr (PER_TOKEN) {
-        uint32_t mb = am.f32bits();
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mb = umax32(mb, (uint32_t)__shfl_xor((int)mb, off, 64));
-        const float m = __uint_as_float(mb);
-        const float qs = ElemT<DT>::round(m / 127.0f);
-        if (lane == 0) s_row[row] = qs;
-        const RowDivisor d(qs, m);
-        if (d.fast) emit(QRowFast{d.s, d.y});
-        else emit(QDivF32<DT>{qs});
-    } else {
-        emit(q_in);
-    }
-    uint32_t c4 = 0;
-    if constexpr (OFF) {
-        int mx = (int)umax32(st.mx & 0xFFFFu, st.mx >> 16) - 128, mn = (int)(((st.mn & 0xFFFFu) < (st.mn >> 16)) ? (st.mn & 0xFFFFu) : (st.mn >> 16)) - 128;
-        int sm = (int)((st.sum & 0xFFFFu) + (st.sum >> 16)) - 128 * st.n;
-        if (st.n == 0) { mx = -128; mn = 127; }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const int omx = __shfl_xor(mx, off, 64), omn = __shfl_xor(mn, off, 64);
-            mx = mx > omx ? mx : omx;
-            mn = mn < omn ? mn : omn;
-            sm += __shfl_xor(sm, off, 64);
-        }
-        const int cx = pick_row_offset(mx, mn, C);
-        if (lane == 0) *(v2i *)(row_off + 2 * row) = (v2i){cx, sm + cx * K};
-        c4 = (uint32_t)(cx & 0xFF) * 0x01010101u;
-    }
-    int8_t *orow = xq + row * (int64_t)K;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int idx = i * 64 + lane;
-        if (idx < nvec) {
-            if constexpr (DT == ASQ_F32) {
-                *(uint32_t *)(orow + (int64_t)idx * 4) = OFF ? pk_add_i8(o[i][0], c4) : o[i][0];
-            } else {
-                *(uint2 *)(orow + (int64_t)idx * 8) = OFF ? make_uint2(pk_add_i8(o[i][0], c4), pk_add_i8(o[i][1], c4)) : make_uint2(o[i][0], o[i][1]);
-            }
-        }
-    }
+    v4i a[NV];
+    load(a, row);
+    finish(a, row);
 }
 
 // true when a launch was made (rows of up to 64 * VEC * 24 elements)
@@ -469,14 +499,18 @@ bool launch_rows_wave(const void *x, int8_t *xq, float *s_row, int32_t *row_off,
     constexpr int VEC = ElemT<DT>::VEC;
     const int64_t nvec = K / VEC;
     if (nvec > 64 * 24 || M >= (1ll << 31)) return false;
+    const int nv = (int)((nvec + 63) / 64);
     dim3 grid((unsigned)((M + 3) / 4)), block(256);
 #define ASQ_RW(NV) hipLaunchKernelGGL((quant_rows_wave<DT, NV, Q, PT, OFF>), grid, block, 0, s, x, xq, s_row, row_off, (int)M, (int)K, q, C)
-    if (nvec <= 64 * 1) ASQ_RW(1);
-    else if (nvec <= 64 * 2) ASQ_RW(2);
-    else if (nvec <= 64 * 4) ASQ_RW(4);
-    else if (nvec <= 64 * 8) ASQ_RW(8);
-    else if (nvec <= 64 * 12) ASQ_RW(12);
-    else if (nvec <= 64 * 16) ASQ_RW(16);
+    if (nv <= 1) ASQ_RW(1);
+    else if (nv <= 2) ASQ_RW(2);
+    else if (nv <= 4) ASQ_RW(4);
+    else if (nv <= 6) ASQ_RW(6);
+    else if (nv <= 8) ASQ_RW(8);
+    else if (nv <= 10) ASQ_RW(10);
+    else if (nv <= 12) ASQ_RW(12);
+    else if (nv <= 16) ASQ_RW(16);
+    else if (nv <= 22) ASQ_RW(22);
     else ASQ_RW(24);
 #undef ASQ_RW
     return true;

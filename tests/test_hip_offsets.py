@@ -63,6 +63,41 @@ def test_quantize_act_off_is_quantize_act_plus_row_offsets(dt, mode):
             assert torch.equal(s_row, s_row2)
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("mode", ["per-tensor-round", "per-tensor-div", "per-token"])
+def test_two_rows_per_wave_quantisers_against_the_oracle(dt, mode):
+    """>= 4096 rows of 4 / 6 / 8 / 10 / 12 sixty-four-lane vectors take the two-rows-per-wave kernel (second row's loads in flight behind the first row's arithmetic,
+    waits counted by hand): plain and image outputs against the oracle, with a row count that leaves the last waves without a second row and row lengths whose
+    last vector is partial (lanes past the row re-read its last vector)."""
+    from autosmoothquant_amd import ops
+    rng = np.random.default_rng(11)
+    vec = 4 if dt == "f32" else 8
+    for (M, K) in ((4096, 8 * 64 * vec), (4101, 8 * 64 * vec - vec), (4097, 4 * 64 * vec), (4099, 6 * 64 * vec - 17 * vec), (4096, 10 * 64 * vec), (4103, 12 * 64 * vec - 63 * vec)):
+        x = rng.standard_normal((M, K)).astype(np.float32) * (1.4 if mode != "per-tensor-div" else 0.05)
+        x[:, rng.random(K) < 0.01] *= 20.0
+        x[1, 3] = 500.0; x[2, 5] = -500.0; x[4] = 0.0
+        x[M - 1, K - 1] = 77.0; x[M // 2, 0] = -91.0
+        x = O.round_to(x, dt)
+        xt = torch.from_numpy(x).to(DEV).to(TDT[dt])
+        qs = 0.0371 if mode == "per-tensor-div" else 1.0
+        if mode == "per-token":
+            rq, rs = O.act_quant_per_token(x, dt)
+        elif mode == "per-tensor-round":
+            rq, rs = O.act_quant_round(x, dt), None
+        else:
+            rq, rs = O.act_quant_div(x, dt, qs), None
+        xq, s_row = ops.quantize_act(xt, mode, qs)
+        assert np.array_equal(xq.cpu().numpy(), rq), (M, K)
+        if rs is not None:
+            assert np.array_equal(s_row.cpu().numpy(), rs.reshape(-1)), (M, K)
+        xo, s_row2, row_off = ops.quantize_act_off(xt, mode, qs)
+        rx, rr = OFF.act_image(rq)
+        assert np.array_equal(xo.cpu().numpy(), rx), (M, K)
+        assert np.array_equal(row_off.cpu().numpy(), rr), (M, K)
+        if rs is not None:
+            assert torch.equal(s_row, s_row2)
+
+
 def _operands(rng, M, N, K, kind):
     if kind == "bench":
         x = np.clip(np.rint(rng.standard_normal((M, K)) * 1.41), -128, 127)
