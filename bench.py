@@ -12,8 +12,8 @@ tokens -> M = 4096, i.e. four 4096x4096x4096 GEMMs: BASELINE.json configs[1]'s b
 batch the north-star target is quoted on.  Multi-GPU = replica-parallel (weak scaling): every
 rank runs the same step on its own rows after one RCCL broadcast of the quantised buffers.
 
-Timing: an untimed settle phase (--settle-ms, default 40 ms of steps: the power controller needs ~20 ms of sustained load to reach its
-operating clock), then W warm-up steps, then EXACTLY K timed steps between barrier + synchronize, max over ranks.
+Timing: an untimed settle phase (--settle-ms, default 100 ms of steps: the power controller needs 30-60 ms of sustained load to reach its
+operating clock, profiles/r4_settle_ab.txt), then W warm-up steps, then EXACTLY K timed steps between barrier + synchronize, max over ranks.
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around the
 dominant kernel (the fused GEMM); `cpu_baseline` times the oracle on the host cores on a
 bounded row sample of the same workload (rank 0, N=1 only).
@@ -325,13 +325,15 @@ def run_step(mods, spec, xs):
     return [outs[label] for label, kind, K, N, aq, bias in spec]
 
 
-def measure_dominant_kernel(mod, x, iters=10, batch=20, warm=200, plain_compare=True):
+def measure_dominant_kernel(mod, x, iters=10, batch=50, warm=200, plain_compare=True, warm_ms=0.0):
     """HIP-event timing of the dominant kernel alone -- the fused INT8 GEMM + dequant epilogue --
     on the SAME quantised activations and weights the timed step uses, launched on torch's current
     stream (the stream the C-ABI launches on).  `batch` back-to-back launches per event pair keep the
-    ~6 us event/launch floor out of the per-launch figure; `warm` launches first let the power
-    controller settle (the first ~3 ms after a change of kernel run 15-25 % below the steady clock,
-    profiles/r2_clock_power_evidence.md section 4)."""
+    ~6 us event/launch floor out of the per-launch figure (50 per pair: 0.1 us of it per launch; what is measured is the launch-to-launch period,
+    i.e. the kernel plus the ~2 us the stream idles between two launches -- the same quantity rocprofv3 reports for back-to-back launches); `warm` launches AND `warm_ms` milliseconds of launches first (the step's own
+    --settle-ms) let the power controller settle: after an idle stretch or a change of kernel the clock starts 15-25 % below its
+    sustained value and climbs back over tens of milliseconds (profiles/r2_clock_power_evidence.md section 4; the per-launch durations
+    in profiles/r4_bench_kernel_trace_windows.txt show the climb)."""
     from autosmoothquant_amd import ops
     qa = mod.quantize_input(x)      # what the step's own forward computes: the offset image of the activation when the module runs this shape on images
     xq, s_row = qa.xq, qa.s_row
@@ -350,6 +352,11 @@ def measure_dominant_kernel(mod, x, iters=10, batch=20, warm=200, plain_compare=
         for _ in range(warm):
             fn()
         torch.cuda.synchronize()
+        t_warm = time.perf_counter()
+        while (time.perf_counter() - t_warm) * 1e3 < warm_ms:
+            for _ in range(batch):
+                fn()
+            torch.cuda.synchronize()
         ts = []
         for _ in range(iters):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -563,10 +570,12 @@ def main():
     ap.add_argument("--fuse-qkv", action="store_true", help="layer workloads: q/k/v as one W8A8BFP32OFP32QKVLinear (the reference's own fused class, used by its Baichuan model)")
     ap.add_argument("--fp8", action="store_true", help="mixtral_experts only: FP8LinearDynamic math (e4m3 weights, per-token e4m3 activations) on the fp8 matrix cores")
     ap.add_argument("--graph", action="store_true", help="capture one step in a hipGraph and replay it in the timed loop (launch-bound decode shapes)")
-    ap.add_argument("--settle-ms", type=float, default=40.0,
-                    help="untimed steps run for this long BEFORE the --warmup steps: after an idle period the power controller starts ~15-25 %% below "
-                         "the clock it settles at under sustained GEMM load and takes ~20 ms to get there (profiles/r2_clock_power_evidence.md section 4); "
-                         "0 disables; reported as dvfs_settle_ms")
+    ap.add_argument("--settle-ms", type=float, default=100.0,
+                    help="untimed steps run for this long BEFORE the --warmup steps: after an idle period (or a change of kernel) the power controller starts "
+                         "~15-25 %% below the clock it settles at under sustained GEMM load and climbs back over 30-60 ms (profiles/r2_clock_power_evidence.md "
+                         "section 4; per-launch durations of a traced run: profiles/r4_bench_kernel_trace_windows.txt; 40 / 100 / 200 ms A/B: "
+                         "profiles/r4_settle_ab.txt); the same settle precedes the fused-QKV comparison and the dominant-kernel timing; 0 disables; "
+                         "reported as dvfs_settle_ms")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for --gpus > 1.  nccl (= RCCL over xGMI) is the measured configuration; gloo exists so that the WHOLE multi-rank flow "
                          "(arena broadcast, fingerprints, barriers, max-over-ranks timing) can be rehearsed on a box with fewer GPUs than ranks: ranks then share "
@@ -748,6 +757,11 @@ def main():
 
         def fstep():
             return [qkv(xs[xk])] + [mods[label](xs[(K, aq, kind)]) for label, kind, K, N, aq, bias in rest]
+        t_settle = time.perf_counter()   # (a change of kernel: the same settle as the main step gets)
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+            for _ in range(8):
+                fstep()
+            torch.cuda.synchronize()
         for _ in range(max(args.warmup, 20)):
             fstep()
         sync_all()
@@ -801,10 +815,10 @@ def main():
             plain_ms, on_images = None, "w1_img" in st
         elif layer_mode:
             xin = (torch.randn(min(M, 8192), K, device=device) * 40).to(tdt)
-            avg_ms, min_ms, kname, plain_ms, on_images = measure_dominant_kernel(getattr(mods[0], lbl + "_proj"), xin, plain_compare=not args.no_plain_compare)
+            avg_ms, min_ms, kname, plain_ms, on_images = measure_dominant_kernel(getattr(mods[0], lbl + "_proj"), xin, plain_compare=not args.no_plain_compare, warm_ms=args.settle_ms)
             M_k = xin.shape[0]
         else:
-            avg_ms, min_ms, kname, plain_ms, on_images = measure_dominant_kernel(mods[lbl], xs[(K, aq, kind)], plain_compare=not args.no_plain_compare)
+            avg_ms, min_ms, kname, plain_ms, on_images = measure_dominant_kernel(mods[lbl], xs[(K, aq, kind)], plain_compare=not args.no_plain_compare, warm_ms=args.settle_ms)
             M_k = M
         ops_k = 2.0 * M_k * N * K
         esz = {"f16": 2, "bf16": 2, "f32": 4}[args.dtype]

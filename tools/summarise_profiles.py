@@ -28,6 +28,28 @@ for name in ("bench", "bench_under_rocprof"):
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
 shutil.copy(stats, os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
 
+# The --stats average of a kernel is over EVERY launch of the traced command, including the launches that run while the power controller is still
+# climbing to its sustained clock (after the process' idle set-up and after every change of kernel).  The per-launch trace of the same pass shows
+# it: windows of 50 consecutive launches of the dominant kernel, in launch order.  rocprofv3 stamps a back-to-back launch's start at the previous
+# launch's end, so these durations also contain the ~2 us launch-to-launch gap that HIP events around a batch see as well.
+trace = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)
+if trace:
+    rows = sorted(csv.DictReader(open(trace[0])), key=lambda r: int(r["Start_Timestamp"]))
+    names = collections.Counter(r["Kernel_Name"] for r in rows if "asq::gemm_i8" in r["Kernel_Name"])
+    dom = names.most_common(1)[0][0]
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if r["Kernel_Name"] == dom]
+    live = last_json_line(os.path.join(src, "bench_under_rocprof.json"))["roofline"]
+    with open(os.path.join(dst, f"{tag}_bench_kernel_trace_windows.txt"), "w") as f:
+        f.write("# per-launch durations of the dominant kernel from the SAME rocprofv3 --kernel-trace --stats pass as %s_bench_kernel_stats.csv, in launch order,\n" % tag)
+        f.write("# windows of 50 launches: mean / min / max us.  Order of the command: settle phase + warm-up + timed steps (3 launches per step, quantisers between),\n")
+        f.write("# fused-QKV comparison (other kernel), then the dominant-kernel timing (warm launches, then 10 x 20 event-timed launches = the LAST 200).\n")
+        f.write("# kernel: %s\n" % dom.split("(")[0])
+        for j in range(0, len(d), 50):
+            w = d[j:j + 50]
+            f.write("%5d..%-5d  mean %6.2f  min %6.2f  max %6.2f\n" % (j, j + len(w) - 1, sum(w) / len(w), min(w), max(w)))
+        f.write("all %d launches: mean %.2f us (the --stats AverageNs)\n" % (len(d), sum(d) / len(d)))
+        f.write("last 200 launches (the event-timed ones): mean %.2f us; bench.py's live HIP-event figure in this pass: avg %.2f us, min %.2f us\n" % (sum(d[-200:]) / 200, live["avg_us"], live["min_us"]))
+
 
 def pmc_means(counter):
     f = glob.glob(os.path.join(src, f"pmc_{counter}", "**", "*counter_collection.csv"), recursive=True)[0]
