@@ -44,6 +44,15 @@ __device__ __forceinline__ const int8_t *uniform_ptr(const int8_t *p)
     return (const int8_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
 
+// d = sext24(a) * sext24(b) + c as ONE v_mad_i32_i24 (the offset-image correction in front of the epilogues: from `__mul24(a, b) + c` chains hipcc prefers
+// v_mul_i32_i24 with an SDWA operand select + v_add3_u32, one VALU operation more per element)
+__device__ __forceinline__ int mad24(int a, int b, int c)
+{
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // ---------------------------------------------------------------------------------
 // matrix-core policies: one "MMA step" consumes 16 k-bytes per lane of each operand (a v4i)
 // ---------------------------------------------------------------------------------

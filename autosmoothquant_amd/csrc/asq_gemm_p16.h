@@ -307,7 +307,9 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
                 int c;
                 if constexpr (kPack) c = ws[in16][e] >> 24;
                 else c = cw[in16][e];
-                o[e] = __mul24(c, rw[im16]) + (__mul24(ncx, ws[in16][e]) + a[e]);
+                // two v_mad_i32_i24, spelled out: from the C expression hipcc builds v_mul_i32_i24 x 2 (the >> 24 folded into an SDWA byte select) + v_add3_u32,
+                // three VALU operations per element where two do (128 elements per lane, two waves per SIMD: ~1 k cycles of a 85 k-cycle block)
+                o[e] = mad24(c, rw[im16], mad24(ncx, ws[in16][e], a[e]));
             }
             return o;
         };
