@@ -117,10 +117,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
         for (int i = 0; i < 2; ++i) p8_dma16(b, voff[kind][i], dma_dst + stage * P8_STAGE + kind * P8_UNIT + i * 1024);
     };
 
-    // Accumulators.  Plain launches start at 0.  OFFSET operands (OffsetArgs, asq_gemm_kernels.h): x and w hold X + cx[m] and W + cw[n]; the two rank-1
-    // correction terms go into the accumulators' START values, so the K loop and the epilogue are the plain ones and the result is the exact X . W^T
-    // (int32 arithmetic wraps, in the matrix cores too).  The vectors are requested BEFORE the first K-tile's DMAs (in-order return: the compiler's
-    // vmcnt for them never waits for a DMA) and the 128 start values are formed while that tile is in flight.
+    // Accumulators start at 0, on plain operands and on offset images alike (the images' correction waits in LDS for the epilogue, above).
     // ---- prologue: K-tile 0 entirely (units 0..3), wait for the two units P1 reads
 #pragma unroll
     for (int kind = 0; kind < 4; ++kind) issue(kind, 0, 0);

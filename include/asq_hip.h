@@ -209,8 +209,8 @@ int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t *w, void *o
  *     x'[m,k] = xq[m,k] + cx[m]      cx[m] = +3 if max_k xq[m,k] <= 124, else -3 if min_k xq[m,k] >= -125, else 0
  *     w'[n,k] = w[n,k]  + cw[n]      cw[n] = min(64, 127 - max_k w[n,k])
  *     sum_k xq[m,k] w[n,k] = sum_k x'[m,k] w'[n,k]  -  cx[m] * sum_k w[n,k]  -  cw[n] * sum_k x'[m,k]
- * The kernel multiplies the primed matrices and starts its int32 accumulators at the two correction terms (two's-complement wrap-around, also
- * inside v_mfma_i32_*): K loop and epilogue are the plain ones, the result equals asq_linear_w8a8 on (xq, w) in every bit.  There is no reference
+ * The kernel multiplies the primed matrices with the plain K loop and subtracts the two correction terms from its int32 accumulators in front of the
+ * epilogue (two's-complement wrap-around, also inside v_mfma_i32_*): the result equals asq_linear_w8a8 on (xq, w) in every bit.  There is no reference
  * counterpart (cuBLASLt sees the raw operands, cublasINT8MMWrapper.cc:224-354); what it replaces is the operand handling in front of
  * asq_linear_w8a8.  4096^3, fp16 out, bench operands: 48.2 -> 44.0 us (56.7 -> 62.1 % of the INT8 peak).
  *
