@@ -1094,7 +1094,13 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
         // 128-row tiles when the 256-row tiling cannot fill 256 CUs (or wastes half a tile row).  Measured
         // (tools/ksplit_sweep.sh): p8h is ~14 % slower per op on a full chip but wins up to 1.45x below ~144 tiles
         const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
-        if (t256 < 144) {
+        // two one-round corners (round 4, profiles/r4_dispatch_holes.txt, forced kernels on cold weights): 129..143 tiles of 256 x 256 whose 128 x 256 tiling no
+        // longer fits ONE round run faster as one (partly filled) round of p16 than as p8h + a peeled remainder (768 x 11008 x 4096: 40.4 -> 37.3 us); and
+        // >= 144 tiles whose last 256-row tile row is at most half full while the 128 x 256 tiling fits one round stay with p8h (640 x 12288 x 4096: 37.5 -> 28.6)
+        const bool one_round_p16 = t256 >= 128 && th > 256;
+        const bool odd_half_row = t256 >= 144 && th <= 256 && (((M + 127) / 128) & 1) != 0 && K < 16384;
+        if ((t256 < 144 && !one_round_p16) || odd_half_row) {
+            if (odd_half_row) return KERN_P8H;
             // 128 x 128 tiles (p8q) where the 128 x 256 tiling has at most 128 tiles, i.e. leaves half of the CUs without one: twice the
             // tiles at twice the L2->LDS bytes per MFMA.  Measured (tools/kbench.py, forced vs default, 48 shapes): -3 ... -22 % for 32..128
             // p8h tiles (512 x 4096 x 4096: 22.8 -> 17.7 us), +15 ... +35 % above 128.

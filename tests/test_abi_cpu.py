@@ -66,7 +66,9 @@ def test_argument_errors_without_gpu():
     assert h.asq_gemm_kernel_name(1536, 11008, 4096) == b"p16+tail" and h.asq_gemm_workspace_bytes(1536, 11008, 4096) == hdr + 4 * 1536 * 256 * 4   # 24 tiles of 128 x 128, 4 K splits
     assert h.asq_gemm_kernel_name(3072, 11008, 8192) == b"p16+tail"
     assert h.asq_gemm_kernel_name(1536, 12288, 4096) == b"p16+tail"       # 288 tiles: 6 tile columns (36 tiles' worth) as 128 x 128 tiles
-    assert h.asq_gemm_kernel_name(768, 11008, 4096) == b"p8h+tail"       # 258 tiles of 128 rows
+    assert h.asq_gemm_kernel_name(768, 11008, 4096) == b"p16"            # 258 tiles of 128 rows no longer fit one round; r4: ONE round of 129 tiles of 256 x 256 beats p8h + tail (40.4 -> 37.3 us)
+    assert h.asq_gemm_kernel_name(640, 12288, 4096) == b"p8h"            # r4: 144 tiles of 256 rows with a half-empty last tile row, 240 tiles of 128 rows in one round (37.5 -> 28.6 us)
+    assert h.asq_gemm_kernel_name(768, 12288, 4096) == b"p16" and h.asq_gemm_kernel_name(2048, 4096, 4096) == b"p8h"   # (their neighbours keep their kernels)
     assert h.asq_gemm_kernel_name(2048, 11008, 4096) == b"p16+tail"      # last wave 88 / 256 full: r4 -- 11 tile columns as ONE round of 128 x 256 tiles (p8h), 85 -> 76 us
     assert h.asq_gemm_kernel_name(2048, 13312, 4096) == b"p16"           # 160 tiles over: both remainder forms lose to the second round
     assert h.asq_gemm_kernel_name(65536, 11008, 4096) == b"p16"          # cfg3: 43 full waves

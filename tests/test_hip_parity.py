@@ -331,7 +331,8 @@ def test_empty_and_degenerate_inputs(dev):
 
 # ---- full-size properties (BASELINE.json sizes; the oracle would take minutes) -----------
 @pytest.mark.parametrize("shape", [(4096, 4096, 4096), (2048, 11008, 4096), (2048, 4096, 11008), (256, 5120, 20480),
-                                   (1024, 4096, 4096), (128, 4096, 11008), (3072, 11008, 4096)],   # 128 x 128 kernel, its split-K, tail peel
+                                   (1024, 4096, 4096), (128, 4096, 11008), (3072, 11008, 4096),    # 128 x 128 kernel, its split-K, tail peel
+                                   (768, 11008, 4096), (640, 12288, 4096)],                         # r4's two one-round corners of the dispatcher (p16 on 129 tiles, p8h on 240)
                          ids=lambda s: "x".join(map(str, s)))
 def test_full_size_checksums(shape, dev):
     """sum_n acc[m,n] == x[m,:] . (sum_n w[n,:]) and sum_m acc[m,n] == (sum_m x[m,:]) . w[n,:] in exact
@@ -710,7 +711,7 @@ def test_forward_workspace_cache_streams_growth_and_graph_replay(dev):
     assert np.array_equal(t_out(yg), want_g)
 
 
-TAIL_SHAPES = [(1536, 11008, 4096), (4352, 4096, 4096), (1536, 11000, 4096), (3072, 11008, 8192), (768, 11008, 4096), (1152, 14336, 4096),
+TAIL_SHAPES = [(1536, 11008, 4096), (4352, 4096, 4096), (1536, 11000, 4096), (3072, 11008, 8192), (1152, 14336, 4096),   # (r4: 768 x 11008 x 4096, the one p8h + tail shape, now runs as one round of p16)
                (2048, 11008, 4096), (2000, 12284, 4096)]   # (the last two: remainders of 88 / 128 tiles, run as one round of 128 x 256 tiles -- gemm_i8_p8h)
 
 
