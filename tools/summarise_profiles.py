@@ -41,14 +41,14 @@ if trace:
     live = last_json_line(os.path.join(src, "bench_under_rocprof.json"))["roofline"]
     with open(os.path.join(dst, f"{tag}_bench_kernel_trace_windows.txt"), "w") as f:
         f.write("# per-launch durations of the dominant kernel from the SAME rocprofv3 --kernel-trace --stats pass as %s_bench_kernel_stats.csv, in launch order,\n" % tag)
-        f.write("# windows of 50 launches: mean / min / max us.  Order of the command: settle phase + warm-up + timed steps (3 launches per step, quantisers between),\n")
-        f.write("# fused-QKV comparison (other kernel), then the dominant-kernel timing (warm launches, then 10 x 20 event-timed launches = the LAST 200).\n")
+        f.write("# windows of 100 launches: mean / min / max us.  Order of the command: settle phase + warm-up + timed steps (3 launches per step, quantisers between),\n")
+        f.write("# fused-QKV comparison (other kernel), then the dominant-kernel timing (200 warm launches + the settle time, then 20 x 50 event-timed launches = the LAST 1000).\n")
         f.write("# kernel: %s\n" % dom.split("(")[0])
-        for j in range(0, len(d), 50):
-            w = d[j:j + 50]
+        for j in range(0, len(d), 100):
+            w = d[j:j + 100]
             f.write("%5d..%-5d  mean %6.2f  min %6.2f  max %6.2f\n" % (j, j + len(w) - 1, sum(w) / len(w), min(w), max(w)))
         f.write("all %d launches: mean %.2f us (the --stats AverageNs)\n" % (len(d), sum(d) / len(d)))
-        f.write("last 200 launches (the event-timed ones): mean %.2f us; bench.py's live HIP-event figure in this pass: avg %.2f us, min %.2f us\n" % (sum(d[-200:]) / 200, live["avg_us"], live["min_us"]))
+        f.write("last 1000 launches (the event-timed ones): mean %.2f us; bench.py's live HIP-event figure in this pass: avg %.2f us, min %.2f us\n" % (sum(d[-1000:]) / 1000, live["avg_us"], live["min_us"]))
 
 
 def pmc_means(counter):
@@ -116,7 +116,7 @@ for t in ("cfg3", "cfg3_fused"):
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     with open(os.path.join(dst, f"{tag}_{t}_kernel_stats.txt"), "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --workload llama7b_decoder_b32_s2048 {'--fuse-norm --fuse-qkv ' if 'fused' in t else ''}--steps 2 --warmup 1 --no-cpu-baseline\n")
-        f.write("# 3 forwards + set-up + the dominant-kernel timing batch (gate GEMM at M = 8192, 400 launches); share of total GPU kernel time\n")
+        f.write("# 3 forwards + set-up + the dominant-kernel timing batches (gate GEMM at M = 8192: warm launches + the settle time + 20 x 50 timed launches, on images and on plain operands); share of total GPU kernel time\n")
         for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:24]:
             f.write("%5.1f%%  calls %6s  avg %9.1f us  %s\n" % (float(r["TotalDurationNs"]) / tot * 100, r["Calls"], float(r["AverageNs"]) / 1e3, re.sub(r"\(.*", "", r["Name"])[:110]))
         f.write("total %.1f ms\n" % (tot / 1e6))
