@@ -23,6 +23,8 @@ from ... import ops
 from ..._CUDA import I8CUGEMM
 from .fused import QuantizedActivation
 
+_ACT_CODE = dict(ops._ACT)   # quantiser mode name -> C-ABI code
+
 _ACT_QUANT = ("per-token", "per-tensor")
 
 
@@ -219,9 +221,26 @@ def _module_forward(mod, x, mode, qs, s_scalar, s_col):
     """quantise -> GEMM + epilogue for a floating input: every forward quantises its own input, as the reference does
     (layers/nn/linear.py:88-96).  Callers that KNOW several modules read one tensor (q/k/v, gate/up) quantise it once,
     explicitly: `qa = mod.quantize_input(x)` and pass `qa` to each (harness.shared_input)."""
+    if not x.is_cuda:   # (before anything is moved for it)
+        raise RuntimeError(f"x is on {x.device}: autosmoothquant_amd ops need a HIP (cuda:N) tensor; there is no CPU fallback")
     lead = x.shape[:-1]
     x2 = mod._flatten(x)
-    out = ops.linear_w8a8_forward(x2, mod.weight, mode, qs, s_scalar, s_col, mod._bias_on(x.device), mod.offset_image(x2.shape[0], x.dtype))
+    w = mod._buffers["weight"]
+    bias = mod._bias_on(x.device)
+    # the module's own tensors are validated once per tensor OBJECT (a new object -- .to(), load_state_dict(assign=True), a re-homed buffer -- is checked again;
+    # dtype / device / contiguity of an existing object only change through `.data = ...`, which the device check of the trusted op still catches)
+    seen = mod.__dict__.get("_checked")
+    if seen is None or seen[0] is not w or seen[1] is not bias or seen[2] is not s_col:
+        ops._dev(w, "weight")
+        if w.dtype != torch.int8 or w.dim() != 2 or tuple(w.shape) != (mod.out_features, mod.in_features):
+            raise ValueError(f"weight must be int8 [{mod.out_features}, {mod.in_features}], got {tuple(w.shape)} {w.dtype}")
+        for name, t in (("s_col", s_col), ("bias", bias)):
+            if t is not None:
+                ops._dev(t, name)
+                if t.dtype != torch.float32 or t.numel() != mod.out_features or t.device != w.device:
+                    raise ValueError(f"{name} must be float32 with {mod.out_features} elements on {w.device}")
+        mod.__dict__["_checked"] = (w, bias, s_col)
+    out = ops.linear_w8a8_forward_trusted(x2, w, _ACT_CODE[mode], float(qs), float(s_scalar), s_col, bias, mod.offset_image(x2.shape[0], x.dtype), mod.out_features, mod.in_features)
     return out.view(*lead, mod.out_features)
 
 

@@ -499,6 +499,37 @@ def linear_w8a8_forward(x2d, w, act_mode, quant_scale, s_scalar, s_col=None, bia
     return out
 
 
+def linear_w8a8_forward_trusted(x2d, w, act_code, quant_scale, s_scalar, s_col, bias, image, N, K):
+    """linear_w8a8_forward without the per-call validation of the module's own state, for callers that check it where it can change (the nn modules:
+    weight / bias / scale vector are validated once per tensor object, layers/nn/linear.py::_module_forward).  Still checked here, per call: the activation
+    (HIP tensor of a supported dtype; contiguity and K are the caller's `_flatten`).  At decode sizes the module call is host-bound (12.9 us at 32 x 4096 x 4096,
+    5.6 us of it the two launches): this path takes ~2 us of Python out of it (tools/pyoverhead.py).  act_code: _lib.ASQ_ACT_*; quant_scale, s_scalar: Python floats."""
+    dt = _DT.get(x2d.dtype)
+    if dt is None or not x2d.is_cuda:
+        raise (ValueError(f"unsupported activation dtype {x2d.dtype}") if x2d.is_cuda else
+               RuntimeError(f"x is on {x2d.device}: autosmoothquant_amd ops need a HIP (cuda:N) tensor; there is no CPU fallback"))
+    dev = x2d.device
+    if w.device != dev:
+        raise RuntimeError(f"tensors on different devices: {dev} vs {w.device}")
+    M = x2d.shape[0]
+    out = torch.empty((M, N), dtype=x2d.dtype, device=dev)
+    if M == 0 or N == 0:
+        return out
+    lib = L.lib()
+    stream = _stream(x2d)
+    ws, nbytes = _forward_ws(lib, M, N, K, dev, stream)
+    with _on(dev):
+        if image is not None:
+            rc = lib.asq_linear_w8a8_forward_off(x2d.data_ptr(), dt, w.data_ptr(), image[0].data_ptr(), image[1].data_ptr(), out.data_ptr(), M, N, K, act_code, quant_scale, s_scalar,
+                                                 None if s_col is None else s_col.data_ptr(), None if bias is None else bias.data_ptr(), ws.data_ptr(), nbytes, stream)
+        else:
+            rc = lib.asq_linear_w8a8_forward(x2d.data_ptr(), dt, w.data_ptr(), out.data_ptr(), M, N, K, act_code, quant_scale, s_scalar,
+                                             None if s_col is None else s_col.data_ptr(), None if bias is None else bias.data_ptr(), ws.data_ptr(), nbytes, stream)
+    if rc:
+        L.check(rc, "asq_linear_w8a8_forward")
+    return out
+
+
 _FP8 = {"per-token": L.ASQ_FP8_PER_TOKEN, "per-tensor": L.ASQ_FP8_PER_TENSOR, "static": L.ASQ_FP8_STATIC}
 
 
