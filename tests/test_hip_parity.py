@@ -322,6 +322,21 @@ def test_empty_and_degenerate_inputs(dev):
         m(torch.zeros(2, 63, dtype=torch.float16, device=dev))
     with pytest.raises(RuntimeError):
         m(torch.zeros(2, 64, dtype=torch.float16))  # CPU tensor: no fallback
+    assert m.bias.is_cuda                            # ... and nothing was moved for it
+    # the module validates its own tensors once per tensor OBJECT: a replaced buffer is checked again, a restored one runs again
+    good, x64 = m.weight, torch.randn(3, 64, device=dev).half()
+    ref = m(x64)
+    m.weight = good.to(torch.int16)
+    with pytest.raises(ValueError):
+        m(x64)
+    m.weight = good.cpu()
+    with pytest.raises(RuntimeError):
+        m(x64)
+    m.weight = good[:, :32].contiguous()
+    with pytest.raises(ValueError):
+        m(x64)
+    m.weight = good.clone()
+    assert torch.equal(m(x64), ref)
     # non-contiguous but reshape-able input
     xb = torch.randn(4, 128, device=dev).half()
     y1 = m(xb[:, ::2])
