@@ -1,6 +1,7 @@
 // C-ABI plumbing + the whole-module forward (quantise -> GEMM+epilogue on one stream).
 #include "asq_common.h"
 #include <string.h>
+#include <dlfcn.h>
 
 static thread_local char g_err[512] = "";
 
@@ -21,6 +22,32 @@ int asq_debug_sync()
     }
     return v;
 }
+
+// ---- roctx ranges (ASQ_ROCTX=1)
+typedef int (*roctx_push_fn)(const char *);
+typedef int (*roctx_pop_fn)(void);
+static roctx_push_fn g_roctx_push = nullptr;
+static roctx_pop_fn g_roctx_pop = nullptr;
+int asq_roctx_enabled()
+{
+    static const int v = [] {
+        const char *e = getenv("ASQ_ROCTX");
+        if (!(e && e[0] && e[0] != '0')) return 0;
+        // rocprofv3's marker library first, the legacy roctracer one second
+        for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            g_roctx_push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+            g_roctx_pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+            if (g_roctx_push && g_roctx_pop) return 1;
+        }
+        fprintf(stderr, "libasq_hip: ASQ_ROCTX=1 but no roctx library could be loaded; ranges are off\n");
+        return 0;
+    }();
+    return v;
+}
+void asq_range_push(const char *name) { if (g_roctx_push) g_roctx_push(name); }
+void asq_range_pop() { if (g_roctx_pop) g_roctx_pop(); }
 
 extern "C" int asq_version(void) { return ASQ_VERSION; }
 extern "C" const char *asq_last_error(void) { return g_err; }
@@ -45,6 +72,7 @@ extern "C" int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t 
                                        int act_mode, float quant_scale, float s_scalar, const float *s_col, const float *bias,
                                        void *workspace, size_t workspace_bytes, void *stream)
 {
+    const AsqRange range_("asq_linear_w8a8_forward");
     ASQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, ASQ_ERR_DIM, "asq_linear_w8a8_forward: bad dims");
     if (M == 0 || N == 0) return ASQ_OK;
     const size_t need = round_up((size_t)M * (size_t)K, 256) + round_up((size_t)M * 4, 256);  // the GEMM part is optional
@@ -68,11 +96,13 @@ extern "C" int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t 
 }
 
 // The same forward on OFFSET operand images (include/asq_hip.h): when the caller passes the weight's image and the shape is one the dispatcher gives to the
-// 256 x 256 kernel, the quantiser emits x + cx[m] and the GEMM starts its accumulators at the correction terms; every other call is the plain forward.
+// 256 x 256 kernel, the quantiser emits x + cx[m] (+ the row's {cx, sum}) and the GEMM subtracts the two rank-1 correction terms in front of its epilogue
+// (asq_gemm_p16.h); every other call is the plain forward.
 extern "C" int asq_linear_w8a8_forward_off(const void *x, int x_dtype, const int8_t *w, const int8_t *w_off, const int32_t *col_off, void *out, int64_t M, int64_t N,
                                            int64_t K, int act_mode, float quant_scale, float s_scalar, const float *s_col, const float *bias, void *workspace,
                                            size_t workspace_bytes, void *stream)
 {
+    const AsqRange range_("asq_linear_w8a8_forward_off");
     ASQ_REQUIRE(M >= 0 && N >= 0 && K >= 0, ASQ_ERR_DIM, "asq_linear_w8a8_forward_off: bad dims");
     if (M == 0 || N == 0) return ASQ_OK;
     const size_t plain = round_up((size_t)M * (size_t)K, 256) + round_up((size_t)M * 4, 256), need = plain + round_up((size_t)M * 8, 256);

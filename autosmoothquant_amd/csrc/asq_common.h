@@ -41,6 +41,19 @@ static inline int asq_after_launch(hipStream_t s, const char *what)
     return ASQ_OK;
 }
 
+// ASQ_ROCTX=1: roctx ranges around the C-ABI entry points (quantise / GEMM / forward), so that `rocprofv3 --marker-trace` attributes kernels to the call that
+// launched them.  The marker library is dlopen'ed on first use; without the variable (the default) a range is one predictable branch.
+void asq_range_push(const char *name);
+void asq_range_pop();
+int asq_roctx_enabled();
+struct AsqRange {
+    bool on;
+    explicit AsqRange(const char *name) : on(asq_roctx_enabled() != 0) { if (on) asq_range_push(name); }
+    ~AsqRange() { if (on) asq_range_pop(); }
+    AsqRange(const AsqRange &) = delete;
+    AsqRange &operator=(const AsqRange &) = delete;
+};
+
 static inline size_t asq_dtype_size(int dt) { return dt == ASQ_F32 ? 4 : 2; }
 
 // ---------------------------------------------------------------------------------

@@ -87,6 +87,7 @@ extern "C" size_t asq_workspace_header_bytes(void) { return (size_t)WS_HEADER_BY
 extern "C" int asq_gemm_i8_i32(const int8_t *x, const int8_t *w, int32_t *out, int64_t M, int64_t N, int64_t K, void *workspace,
                                size_t workspace_bytes, void *stream)
 {
+    const AsqRange range_("asq_gemm_i8_i32");
     int rc = check_gemm_args("asq_gemm_i8_i32", x, w, out, M, N, K);
     if (rc) return rc;
     ASQ_REQUIRE(((uintptr_t)out & 3) == 0, ASQ_ERR_ALIGN, "asq_gemm_i8_i32: out misaligned");
@@ -97,6 +98,7 @@ extern "C" int asq_gemm_i8_i32(const int8_t *x, const int8_t *w, int32_t *out, i
 extern "C" int asq_gemm_i8_i8(const int8_t *x, const int8_t *w, int8_t *out, int64_t M, int64_t N, int64_t K, float alpha, float beta,
                               void *workspace, size_t workspace_bytes, void *stream)
 {
+    const AsqRange range_("asq_gemm_i8_i8");
     int rc = check_gemm_args("asq_gemm_i8_i8", x, w, out, M, N, K);
     if (rc) return rc;
     EpiI8 epi{out, N, alpha, beta, (N % 4 == 0) && (((uintptr_t)out & 3) == 0)};
@@ -107,6 +109,7 @@ extern "C" int asq_linear_w8a8(const int8_t *xq, const int8_t *w, void *out, int
                                float s_scalar, const float *s_row, const float *s_col, const float *bias, int epi_order, void *workspace,
                                size_t workspace_bytes, void *stream)
 {
+    const AsqRange range_("asq_linear_w8a8");
     int rc = check_gemm_args("asq_linear_w8a8", xq, w, out, M, N, K);
     if (rc) return rc;
     ASQ_REQUIRE(out_dtype == ASQ_F32 || out_dtype == ASQ_F16 || out_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_linear_w8a8: bad out_dtype %d", out_dtype);
@@ -150,6 +153,7 @@ extern "C" int asq_linear_w8a8_off(const int8_t *xq_off, const int8_t *w_off, vo
                                    const float *s_row, const float *s_col, const float *bias, int epi_order, const int32_t *row_off, const int32_t *col_off,
                                    void *stream)
 {
+    const AsqRange range_("asq_linear_w8a8_off");
     int rc = check_gemm_args("asq_linear_w8a8_off", xq_off, w_off, out, M, N, K);
     if (rc) return rc;
     if (M == 0 || N == 0) return ASQ_OK;
@@ -172,6 +176,7 @@ extern "C" int asq_linear_w8a8_q8(const int8_t *xq, const int8_t *w, int8_t *out
                                   const float *s_row, const float *s_col, const float *bias, int epi_order, int act, int qmode, float quant_scale,
                                   void *workspace, size_t workspace_bytes, void *stream)
 {
+    const AsqRange range_("asq_linear_w8a8_q8");
     int rc = check_gemm_args("asq_linear_w8a8_q8", xq, w, out_q, M, N, K);
     if (rc) return rc;
     ASQ_REQUIRE(mid_dtype == ASQ_F32 || mid_dtype == ASQ_F16 || mid_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_linear_w8a8_q8: bad mid_dtype %d", mid_dtype);
@@ -208,6 +213,7 @@ extern "C" int asq_linear_w8a8_grouped_ws(const int8_t *xq, const int8_t *w, voi
                                           int64_t M, int64_t N, int64_t K, const float *s_group, const float *s_row, const float *bias,
                                           void *workspace, size_t workspace_bytes, void *stream)
 {
+    const AsqRange range_("asq_linear_w8a8_grouped_ws");
     return grouped_impl(xq, w, out, out_dtype, group_offsets, ngroups, M, N, K, s_group, s_row, bias, nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 
@@ -215,6 +221,7 @@ extern "C" int asq_linear_w8a8_grouped_off(const int8_t *xq_off, const int8_t *w
                                            int64_t M, int64_t N, int64_t K, const float *s_group, const float *s_row, const float *bias,
                                            const int32_t *row_off, const int32_t *col_off, void *workspace, size_t workspace_bytes, void *stream)
 {
+    const AsqRange range_("asq_linear_w8a8_grouped_off");
     ASQ_REQUIRE(M == 0 || N == 0 || (row_off != nullptr && col_off != nullptr), ASQ_ERR_NULL, "asq_linear_w8a8_grouped_off: NULL row_off / col_off");
     ASQ_REQUIRE(out_dtype == ASQ_F16 || out_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_linear_w8a8_grouped_off: out_dtype must be ASQ_F16 or ASQ_BF16 (got %d)", out_dtype);
     ASQ_REQUIRE((((uintptr_t)row_off | (uintptr_t)col_off) & 7) == 0, ASQ_ERR_ALIGN, "asq_linear_w8a8_grouped_off: row_off / col_off must be 8-B aligned");

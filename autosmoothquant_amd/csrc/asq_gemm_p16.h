@@ -26,10 +26,6 @@
 // linear_a8_w8_o32_ -- and fp32) have their own pipelined row epilogue (epilogue_wave_rows4); int8 outputs stay on gemm_i8_p8.
 #pragma once
 
-#ifndef P16_ORDER
-#define P16_ORDER 1   // issue order inside a quadrant: 0 = the weight fragment stays for 4 instructions, 1 = the activation fragment stays for 2
-#endif
-
 namespace asq {
 
 template <class Epi, int ABL = 0>
@@ -146,38 +142,15 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
 
     v4i xf[4][2], wa[2][2], wb[2][2];  // [tile][k-step]
     auto ld = [&](unsigned a) { return *(p8_lds_v4i)(uintptr_t)a; };
-    // 16 MFMAs of one quadrant: k-step outermost, then the W fragment (kept for 4 instructions), then the token tiles
+    // 16 MFMAs of one quadrant: k-step outermost; the activation fragment stays for two instructions, the weight fragments alternate (measured against the
+    // weight-stationary, snaking and token-tile-major orders in rounds 3 / 4: profiles/r3_p16_order_ab.txt, r4_p16_order_images.txt -- within noise, this one kept)
     auto quadrant = [&](v4i (&A)[4][2], const v4i (&wf)[2][2]) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-#if P16_ORDER == 1
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
                 for (int it = 0; it < 2; ++it) A[jt][it] = MmaI8x16::mma(wf[it][kk], xf[jt][kk], A[jt][it]);
-#elif P16_ORDER == 3   // token tile outermost, both k-steps of a tile back to back (experiment: the same accumulator two instructions apart)
-            if (kk == 0) {
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                    for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-                        for (int it = 0; it < 2; ++it) A[jt][it] = MmaI8x16::mma(wf[it][k2], xf[jt][k2], A[jt][it]);
-            }
-#elif P16_ORDER == 2   // as 1 with the weight fragments snaking (w0, w1 | w1, w0 | ...): exactly one operand changes between consecutive instructions
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int it = (jt & 1) ? 1 - i : i;
-                    A[jt][it] = MmaI8x16::mma(wf[it][kk], xf[jt][kk], A[jt][it]);
-                }
-#else
-#pragma unroll
-            for (int it = 0; it < 2; ++it)
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt) A[jt][it] = MmaI8x16::mma(wf[it][kk], xf[jt][kk], A[jt][it]);
-#endif
         }
     };
 
@@ -314,13 +287,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
     } else {
         run(get);
     }
-#ifdef ASQ_P8_PROBE
-    if constexpr (ABL & 128) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        P8_BLK(3);
-        P8_BLK_RT(7);
-    }
-#endif
+    P8_PROBE_END();
 }
 
 }  // namespace asq

@@ -39,13 +39,6 @@ __device__ __forceinline__ void p4_dma16(const int8_t *sbase, unsigned voff, uns
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-#ifdef ASQ_P8_PROBE
-#define P4_BLK(i) do { if constexpr (PROBE) { if (wave == 0 && lane == 0 && blockIdx.x < 4096) p8_blk[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } } while (0)
-#define P4_BLK_RT(i) do { if constexpr (PROBE) { if (wave == 0 && lane == 0 && blockIdx.x < 4096) p8_blk[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#else
-#define P4_BLK(i) do { } while (0)
-#define P4_BLK_RT(i) do { } while (0)
-#endif
 
 // Staged, coalescing epilogue of one 128(m) x 128(n) wave tile with 2-byte outputs, pipelined over the four 32-row token
 // tiles: tile im is packed and written to a wave-private 8 KiB LDS image [32 rows][16 x 16 B] (two images, used alternately),
@@ -270,13 +263,7 @@ __global__ void __launch_bounds__(256, 1) gemm_i8_p4(const int8_t *__restrict__ 
         epilogue_wave<2, 4>(epi, [&](int in, int im) -> const v16i & { return acc[in][im]; }, [](int im) { return im * 32; }, mw0, nw0, lane, M, N);
         epilogue_wave<2, 4>(epi, [&](int in, int im) -> const v16i & { return acc[2 + in][im]; }, [](int im) { return im * 32; }, mw0, nw0 + 64, lane, M, N);
     }
-#ifdef ASQ_P8_PROBE
-    if constexpr (PROBE) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        P4_BLK(3);
-        P4_BLK_RT(7);
-    }
-#endif
+    P4_PROBE_END();
 }
 
 }  // namespace asq

@@ -159,13 +159,7 @@ __global__ void __launch_bounds__(256, 1) gemm_i8_p4x16(const int8_t *__restrict
     const bool rows_path = ((((uintptr_t)epi.out) & 15) == 0) && ((epi.N * 2) % 16 == 0) && mw0 + 128 <= M && nw0 + 128 <= N && epi.N < (int64_t(1) << 27);
     if (rows_path) epilogue_wave_rows<4, 4, true>(epi, get, mw0, nw0, lane, lds0 + wave * 32768);
     else epilogue_wave16<8, 8>(epi, get, mw0, nw0, lane, M, N);
-#ifdef ASQ_P8_PROBE
-    if constexpr (PROBE) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        P4_BLK(3);
-        P4_BLK_RT(7);
-    }
-#endif
+    P4_PROBE_END();
 }
 
 }  // namespace asq

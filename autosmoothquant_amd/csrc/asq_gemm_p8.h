@@ -67,21 +67,24 @@ constexpr size_t P8_GROUPED_WS_BYTES = (size_t)8 * P8_CUS_PER_XCD * 256 * 256 * 
 //       32 = timing stamps of block 0 waves 0/4, 64 = no s_setprio, 128 = per-block stamps,
 //       256 / 512 / 768 = epilogue stores nt / sc1 / sc0 sc1 instead of P8_STORE_DEFAULT.
 //       2048 = the round-2 staged epilogue on interior tiles too (A/B against epilogue_wave_rows).
-#ifdef ASQ_P8_PROBE
-static __device__ unsigned long long p8_dbg[2][4][8];
-// ABL & 128: per-block {start, prologue done, loop done, end} in s_memtime ticks, xcc_id, tile id, {start, end} in s_memrealtime (100 MHz) ticks
-static __device__ unsigned long long p8_blk[4096][8];
-#define P8_ABL_OK(ABL) true
-#define P8_BLK(i) do { if constexpr (ABL & 128) { if (wave == 0 && lane == 0 && blockIdx.x < 4096) p8_blk[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } } while (0)
-#define P8_BLK_RT(i) do { if constexpr (ABL & 128) { if (wave == 0 && lane == 0 && blockIdx.x < 4096) p8_blk[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#define P8_STAMP(i) do { if constexpr (ABL & 32) st[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#define P8_ACCUM(ph) do { if constexpr (ABL & 32) { _Pragma("unroll") for (int q_ = 0; q_ < 7; ++q_) tacc[ph][q_] += st[q_ + 1] - st[q_]; } } while (0)
+#ifdef ASQ_P8_PROBE   // a probe TU under tools/ubench: the stamping hooks live there, not in the product
+#include "../../tools/ubench/probe_hooks.h"
 #else
 #define P8_ABL_OK(ABL) ((ABL) == 0)
 #define P8_BLK(i) do { } while (0)
 #define P8_BLK_RT(i) do { } while (0)
 #define P8_STAMP(i) do { } while (0)
 #define P8_ACCUM(ph) do { } while (0)
+#define P8_PROBE_TIMERS() do { } while (0)
+#define P8_PROBE_DUMP_TIMERS() do { } while (0)
+#define P8_PROBE_END() do { } while (0)
+#define P8_PROBE_END_WHERE(tile_m, tile_n) do { } while (0)
+#define P8_PROBE_PIN_BASE(p) do { } while (0)
+#define P8H_BLK(i) do { } while (0)
+#define P8H_PROBE_END(tile_m, tile_n) do { } while (0)
+#define P4_BLK(i) do { } while (0)
+#define P4_BLK_RT(i) do { } while (0)
+#define P4_PROBE_END() do { } while (0)
 #endif
 #ifndef P8_STORE_DEFAULT
 #define P8_STORE_DEFAULT 0   // cache policy of the staged epilogue's global stores (store16_policy)
@@ -132,9 +135,7 @@ template <int ABL> __device__ __forceinline__ v4i p8_ldfrag(unsigned lds_addr, i
 __device__ __forceinline__ void p8_dma16(const int8_t *sbase, unsigned voff, unsigned lds_dst)
 {
     unsigned keep;
-#ifdef ASQ_P8_PROBE   // (some ablation instantiations of tools/ubench/clock_probe evaluate base + k on the VALU: pin it again; production builds are untouched)
-    sbase = uniform_ptr(sbase);
-#endif
+    P8_PROBE_PIN_BASE(sbase);
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" P8_DMA_MOD "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
@@ -402,11 +403,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8(const int8_t *__restrict__ 
                 for (int it = 0; it < 2; ++it) A[jt][it] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[it][kk], xf16[jt][kk], A[jt][it], 0, 0, 0);
     };
     auto ld16 = [&](unsigned a) { return *(p8_lds_v4i)(uintptr_t)a; };
-#ifdef ASQ_P8_PROBE
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tacc[4][7] = {};
-    (void)st;
-    (void)tacc;
-#endif
+    P8_PROBE_TIMERS();
 
     // one K-tile at LDS stage S (compile-time), prefetching K-tile (t+1) into stage S^1
     auto ktile = [&](auto stage_tag, int t) {
@@ -595,13 +592,7 @@ if constexpr (L16) {
     }
     if (t < nt) ktile(std::integral_constant<int, 0>{}, t);
 
-#ifdef ASQ_P8_PROBE
-    if constexpr (ABL & 32) {
-        if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))
-            for (int a = 0; a < 4; ++a)
-                for (int b = 0; b < 7; ++b) p8_dbg[wave >> 2][a][b] = tacc[a][b];
-    }
-#endif
+    P8_PROBE_DUMP_TIMERS();
     P8_BLK(2);
     P8_WAIT_VM(0);          // drain the dead prefetches before LDS is released
     if (wm == 0) P8_BAR();  // balance the stagger barrier
@@ -749,20 +740,7 @@ if constexpr (L16) {
     } else {
         epilogue_wave<2, 4>(epi, get, [](int im) { return im * 32; }, mw0, n0 + wn * 64, lane, Mw, N);
     }
-#ifdef ASQ_P8_PROBE
-    if constexpr (ABL & 128) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        P8_BLK(3);
-        P8_BLK_RT(7);
-        if (wave == 0 && lane == 0 && blockIdx.x < 4096) {
-            unsigned xcc, hwid;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            p8_blk[blockIdx.x][4] = (xcc & 7) | ((unsigned long long)hwid << 8);  // bits 0-2 XCC; HW_ID above (cu_id 8-11, sh_id 12, se_id 13-15 of it)
-            p8_blk[blockIdx.x][5] = (unsigned)(tile_m * 65536 + tile_n);
-        }
-    }
-#endif
+    P8_PROBE_END_WHERE(tile_m, tile_n);
 }
 
 }  // namespace asq

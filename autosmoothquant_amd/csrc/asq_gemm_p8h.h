@@ -32,11 +32,6 @@ namespace asq {
 constexpr int P8H_STAGE = 3 * P8_UNIT;      // 48 KiB
 constexpr int P8H_LDS_BYTES = 3 * P8H_STAGE;  // 144 KiB
 
-#ifdef ASQ_P8_PROBE
-#define P8H_BLK(i) do { if constexpr (PROBE) { if (wave == 0 && lane == 0 && blockIdx.x < 4096) p8_blk[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); } } while (0)
-#else
-#define P8H_BLK(i) do { } while (0)
-#endif
 
 // L16 (int8 only): the matrix work on v_mfma_i32_16x16x64_i8 (asq_gemm_p16.h for why): a phase is 2 k-steps x {4 token tiles x 2 channel tiles} = 16
 // instructions of 16 cycles on acc16[n-half][token tile][channel tile]; fragments 16 rows x 64 k-bytes from the same unit images.
@@ -293,18 +288,7 @@ if constexpr (L16) {
     } else {
         epilogue_wave<2, 2>(epi, get, [](int im) { return im * 32; }, m0 + wm * 64, n0 + wn * 64, lane, M, N);
     }
-#ifdef ASQ_P8_PROBE
-    if constexpr (PROBE) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        P8H_BLK(3);
-        if (wave == 0 && lane == 0 && blockIdx.x < 4096) {
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            p8_blk[blockIdx.x][4] = xcc;
-            p8_blk[blockIdx.x][5] = (unsigned)(tile_m * 65536 + tile_n);
-        }
-    }
-#endif
+    P8H_PROBE_END(tile_m, tile_n);
 }
 
 }  // namespace asq

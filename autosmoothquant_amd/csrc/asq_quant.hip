@@ -1027,6 +1027,7 @@ using namespace asq;
 extern "C" int asq_quantize_act(const void *x, int x_dtype, int mode, float quant_scale, int8_t *xq, float *s_row,
                                 int64_t M, int64_t K, void *stream)
 {
+    const AsqRange range_("asq_quantize_act");
     ASQ_REQUIRE(M >= 0 && K >= 0 && M < (1ll << 31), ASQ_ERR_DIM, "asq_quantize_act: bad dims M=%lld K=%lld", (long long)M, (long long)K);
     ASQ_REQUIRE(x_dtype == ASQ_F32 || x_dtype == ASQ_F16 || x_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_quantize_act: bad x_dtype %d", x_dtype);
     ASQ_REQUIRE(mode == ASQ_ACT_ROUND || mode == ASQ_ACT_DIV || mode == ASQ_ACT_PER_TOKEN, ASQ_ERR_DTYPE, "asq_quantize_act: bad mode %d", mode);
@@ -1046,6 +1047,7 @@ extern "C" int asq_quantize_act(const void *x, int x_dtype, int mode, float quan
 extern "C" int asq_quantize_act_off(const void *x, int x_dtype, int mode, float quant_scale, int8_t *xq, float *s_row, int32_t *row_off,
                                     int64_t M, int64_t K, void *stream)
 {
+    const AsqRange range_("asq_quantize_act_off");
     ASQ_REQUIRE(M >= 0 && K > 0 && M < (1ll << 31), ASQ_ERR_DIM, "asq_quantize_act_off: bad dims M=%lld K=%lld", (long long)M, (long long)K);
     ASQ_REQUIRE(x_dtype == ASQ_F32 || x_dtype == ASQ_F16 || x_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_quantize_act_off: bad x_dtype %d", x_dtype);
     ASQ_REQUIRE(mode == ASQ_ACT_ROUND || mode == ASQ_ACT_DIV || mode == ASQ_ACT_PER_TOKEN, ASQ_ERR_DTYPE, "asq_quantize_act_off: bad mode %d", mode);
@@ -1067,6 +1069,7 @@ extern "C" int asq_quantize_act_off(const void *x, int x_dtype, int mode, float 
 
 extern "C" int asq_weight_offset_image(const int8_t *w, int64_t N, int64_t K, int8_t *w_off, int32_t *col_off, void *stream)
 {
+    const AsqRange range_("asq_weight_offset_image");
     ASQ_REQUIRE(N >= 0 && K > 0 && N < (1ll << 31) && K <= 65536, ASQ_ERR_DIM, "asq_weight_offset_image: bad dims N=%lld K=%lld (K <= 65536)", (long long)N, (long long)K);
     if (N == 0) return ASQ_OK;
     ASQ_REQUIRE(w != nullptr && w_off != nullptr && col_off != nullptr, ASQ_ERR_NULL, "asq_weight_offset_image: NULL pointer");
@@ -1104,11 +1107,13 @@ static int norm_quantize_impl(const void *x, int x_dtype, const void *weight, co
 extern "C" int asq_norm_quantize(const void *x, int x_dtype, const void *weight, const void *bias, float eps, int per_token, int8_t *xq,
                                  float *s_row, int64_t M, int64_t K, void *stream)
 {
+    const AsqRange range_("asq_norm_quantize");
     return norm_quantize_impl(x, x_dtype, weight, bias, eps, per_token, xq, s_row, nullptr, M, K, stream);
 }
 extern "C" int asq_norm_quantize_off(const void *x, int x_dtype, const void *weight, const void *bias, float eps, int per_token, int8_t *xq,
                                      float *s_row, int32_t *row_off, int64_t M, int64_t K, void *stream)
 {
+    const AsqRange range_("asq_norm_quantize_off");
     ASQ_REQUIRE(M == 0 || (row_off != nullptr && ((uintptr_t)row_off & 7) == 0), ASQ_ERR_NULL, "asq_norm_quantize_off: row_off NULL or not 8-B aligned");
     ASQ_REQUIRE(K <= 65536, ASQ_ERR_DIM, "asq_norm_quantize_off: K <= 65536");
     return norm_quantize_impl(x, x_dtype, weight, bias, eps, per_token, xq, s_row, row_off, M, K, stream);
@@ -1142,11 +1147,13 @@ static int add_norm_quantize_impl(const void *x, const void *residual, void *h_o
 extern "C" int asq_add_norm_quantize(const void *x, const void *residual, void *h_out, int x_dtype, const void *weight, const void *bias, float eps,
                                      int per_token, int8_t *xq, float *s_row, int64_t M, int64_t K, void *stream)
 {
+    const AsqRange range_("asq_add_norm_quantize");
     return add_norm_quantize_impl(x, residual, h_out, x_dtype, weight, bias, eps, per_token, xq, s_row, nullptr, M, K, stream);
 }
 extern "C" int asq_add_norm_quantize_off(const void *x, const void *residual, void *h_out, int x_dtype, const void *weight, const void *bias, float eps,
                                          int per_token, int8_t *xq, float *s_row, int32_t *row_off, int64_t M, int64_t K, void *stream)
 {
+    const AsqRange range_("asq_add_norm_quantize_off");
     ASQ_REQUIRE(M == 0 || (row_off != nullptr && ((uintptr_t)row_off & 7) == 0), ASQ_ERR_NULL, "asq_add_norm_quantize_off: row_off NULL or not 8-B aligned");
     ASQ_REQUIRE(K <= 65536, ASQ_ERR_DIM, "asq_add_norm_quantize_off: K <= 65536");
     return add_norm_quantize_impl(x, residual, h_out, x_dtype, weight, bias, eps, per_token, xq, s_row, row_off, M, K, stream);
@@ -1183,11 +1190,13 @@ static int silu_mul_quantize_impl(const void *gate, const void *up, int x_dtype,
 extern "C" int asq_silu_mul_quantize(const void *gate, const void *up, int x_dtype, int per_token, float quant_scale, int8_t *xq, float *s_row,
                                      int64_t M, int64_t K, void *stream)
 {
+    const AsqRange range_("asq_silu_mul_quantize");
     return silu_mul_quantize_impl(gate, up, x_dtype, per_token, quant_scale, xq, s_row, nullptr, M, K, stream);
 }
 extern "C" int asq_silu_mul_quantize_off(const void *gate, const void *up, int x_dtype, int per_token, float quant_scale, int8_t *xq, float *s_row,
                                          int32_t *row_off, int64_t M, int64_t K, void *stream)
 {
+    const AsqRange range_("asq_silu_mul_quantize_off");
     ASQ_REQUIRE(M == 0 || (row_off != nullptr && ((uintptr_t)row_off & 7) == 0), ASQ_ERR_NULL, "asq_silu_mul_quantize_off: row_off NULL or not 8-B aligned");
     ASQ_REQUIRE(K <= 65536, ASQ_ERR_DIM, "asq_silu_mul_quantize_off: K <= 65536");
     return silu_mul_quantize_impl(gate, up, x_dtype, per_token, quant_scale, xq, s_row, row_off, M, K, stream);

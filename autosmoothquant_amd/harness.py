@@ -251,6 +251,7 @@ def to_w8a8(layer, scales, quant_config=None, fuse_norm=False, fuse_qkv=False, b
     q = LlamaLayer.__new__(LlamaLayer)
     torch.nn.Module.__init__(q)
     q.hidden, q.heads, q.kv_heads, q.hd, q.rope_theta = layer.hidden, layer.heads, layer.kv_heads, layer.hd, layer.rope_theta
+    q.calib_scales, q.quant_config = dict(scales), dict(cfg)   # (kept for all_per_tensor_view)
 
     def conv(lin, cls, scale, aq):
         src = torch.nn.Linear(lin.in_features, lin.out_features, bias=False)
@@ -287,6 +288,42 @@ def to_w8a8(layer, scales, quant_config=None, fuse_norm=False, fuse_qkv=False, b
             q.qkv_proj = qkv_from_parts(q.q_proj, q.k_proj, q.v_proj)
         q.use_fused = False
     return q
+
+
+@torch.no_grad()
+def per_tensor_twin(mod, input_scale):
+    """The per-tensor W8A8BFP32OFP32LinearWithQuantScale that `from_float(..., act_quant="per-tensor")` would have produced from the float weight behind the
+    per-token module `mod` -- over the SAME int8 buffer (weight quantisation does not depend on act_quant, reference linear.py:304-329): quant_scale =
+    input_scale, dequant_scale = input_scale * weight_scale (mod's own dequant_scale IS the weight scale)."""
+    from .layers.nn.linear import W8A8BFP32OFP32LinearWithQuantScale
+    if mod.act_quant != "per-token":
+        raise ValueError("per_tensor_twin: expected a per-token module")
+    t = W8A8BFP32OFP32LinearWithQuantScale(mod.in_features, mod.out_features, mod.use_bias, "per-tensor")
+    t.weight = mod._buffers["weight"]
+    if mod.use_bias:
+        t.bias = mod._buffers["bias"]
+    wscale = mod._buffers["dequant_scale"].detach().to("cpu", torch.float32)
+    t.dequant_scale = (input_scale * wscale).to(torch.float32)
+    t.quant_scale = torch.tensor(input_scale, dtype=torch.float32)
+    t._pin_scalars()
+    if "_offset_cache" in mod.__dict__:   # one weight, one image
+        t.__dict__["_offset_cache"] = mod.__dict__["_offset_cache"]
+    return t
+
+
+@torch.no_grad()
+def all_per_tensor_view(qlayer):
+    """A second LlamaLayer object over the SAME quantised weights as `qlayer` (to_w8a8 with the default config) whose o_proj / down_proj quantise their inputs
+    per TENSOR with the calibrated scales: the "linears all per-tensor" composition BASELINE configs[2] / SURVEY 8d cfg3 name (quant_config = {qkv, out, fc1,
+    fc2: per-tensor}, reference models/llama.py:289-339).  Shares every module except the two twins; `use_fused` etc. are per view."""
+    import copy
+    v = copy.copy(qlayer)
+    v._modules = dict(qlayer._modules)
+    v.__dict__.pop("_asq_arena", None)
+    v.o_proj = per_tensor_twin(qlayer.o_proj, qlayer.calib_scales["o_in"])
+    v.down_proj = per_tensor_twin(qlayer.down_proj, qlayer.calib_scales["down_in"])
+    v.quant_config = dict(qlayer.quant_config, out="per-tensor", fc2="per-tensor")
+    return v
 
 
 # ---------------------------------------------------------------------------------------------
@@ -542,17 +579,34 @@ class MixtralLayer(LlamaLayer):
         try:
             ver = st._version
         except RuntimeError:
-            ver = -1
+            return None   # a stack without a version counter (built under inference_mode): writes into it cannot be seen -> plain operands
         key = (st.data_ptr(), ver, st.device)
         hit = self.__dict__.get(f"_{name}_image")
         if hit is None or hit[0] != key:
             if torch.cuda.is_current_stream_capturing():
                 return None   # (see _W8A8Base.offset_image)
             E, N, K = st.shape
-            img, col = ops.weight_offset_image(st.view(E * N, K))
+            out = None   # rebuild INTO the existing buffers when they still fit: a hipGraph captured on them then replays the new image
+            if hit is not None and hit[1][0].device == st.device and tuple(hit[1][0].shape) == (E, N, K):
+                out = (hit[1][0].view(E * N, K), hit[1][1].view(E * N, 2))
+            try:
+                img, col = ops.weight_offset_image(st.view(E * N, K), out=out)
+            except torch.cuda.OutOfMemoryError:
+                self.offsets = False
+                self.__dict__.pop(f"_{name}_image", None)
+                return None
             hit = (key, (img.view(E, N, K), col.view(E, N, 2)))
             self.__dict__[f"_{name}_image"] = hit
         return hit[1]
+
+    def refresh_offset_images(self):
+        """Rebuild the three stacks' images from the current stacks into their existing buffers (after a weight update, before replaying a hipGraph captured
+        on them; see _W8A8Base.refresh_offset_image)."""
+        for name in ("w1", "w3", "w2"):
+            hit = self.__dict__.get(f"_{name}_image")
+            if hit is not None:
+                self.__dict__[f"_{name}_image"] = (None, hit[1])   # (key None never matches: the next _stack_image call rebuilds in place)
+                self._stack_image(name)
 
     def _stacks_current(self):
         """The per-expert modules stay the source of truth (state_dict, load_state_dict, .to(), replica.broadcast_quantized all act on THEIR buffers): the

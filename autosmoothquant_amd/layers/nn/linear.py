@@ -133,19 +133,51 @@ class _W8A8Base(torch.nn.Module):
         mode, qs = self._input_mode()
         x2 = self._flatten(x)
         mods = (self,) if consumers is None else tuple(consumers)
-        if x2.is_cuda and all(isinstance(m, _W8A8Base) and m.offset_image(x2.shape[0], x.dtype) is not None for m in mods):
+        # (the image quantiser has no scalar path for a contiguous view that does not start on a 16-byte boundary; the plain one has)
+        if x2.is_cuda and x2.data_ptr() % 16 == 0 and all(isinstance(m, _W8A8Base) and m.offset_image(x2.shape[0], x.dtype) is not None for m in mods):
             xq, s_row, row_off = ops.quantize_act_off(x2, mode, qs)
             return QuantizedActivation(xq, s_row, x.dtype, x.shape[:-1], row_off)
         xq, s_row = ops.quantize_act(x2, mode, qs)
         return QuantizedActivation(xq, s_row, x.dtype, x.shape[:-1])
 
-    # ---- offset operand image of the weight (include/asq_hip.h): built on the first forward whose shape the C-ABI runs on it, kept until the weight changes
+    # ---- offset operand image of the weight (include/asq_hip.h): built on the first forward whose shape the C-ABI runs on it (or up front by
+    # build_offset_image), kept in ONE pair of buffers for the module's lifetime on a device and rebuilt INTO them when the weight changes
     offsets = True   # class / instance switch (ASQ_OFFSETS=0 in the environment switches the C-ABI side off for the whole process)
+
+    @staticmethod
+    def _weight_key(w):
+        try:
+            ver = w._version
+        except RuntimeError:   # an inference tensor has no version counter: writes into it cannot be seen
+            ver = None
+        return (w.data_ptr(), ver, w.device)
+
+    def _image_buffers(self, w, rebuild_key):
+        """(re)build the image for weight `w`; reuses the module's buffers when they still fit (same shape and device), so a hipGraph captured on them sees the new
+        image at its next replay instead of a freed one.  Allocation failure switches images off for this module: the forward runs on plain operands."""
+        hit = self.__dict__.get("_offset_cache")
+        out = None
+        if hit is not None and hit[1][0].device == w.device and tuple(hit[1][0].shape) == tuple(w.shape):
+            out = hit[1]
+        try:
+            image = ops.weight_offset_image(w, out=out)
+        except torch.cuda.OutOfMemoryError:
+            self.offsets = False   # (a second int8 copy of the weight did not fit: stay on plain operands from now on)
+            self.__dict__.pop("_offset_cache", None)
+            return None
+        self.__dict__["_offset_cache"] = (rebuild_key, image)
+        self.__dict__.pop("_offset_dirty", None)
+        return image
 
     def offset_image(self, M, dtype):
         """(w_off int8 [N,K], col_off int32 [N,2]) when a forward of M rows with `dtype` outputs runs on offset operand images, else None.
-        The image is a second int8 copy of the weight (only modules that see prefill-sized inputs ever build one); it is keyed on the weight's
-        storage and version counter, so load_state_dict / in-place updates / .to() rebuild it."""
+        The image is a second int8 copy of the weight -- N x K bytes more per module that sees prefill-sized inputs (build_offset_image builds it at load
+        time instead of inside the first such forward).  It is keyed on the weight's storage and version counter: in-place torch operations, .to() and
+        replica.broadcast_quantized are seen and the image is rebuilt into the same buffers; load_state_dict marks it stale explicitly.
+        A weight without a version counter (an inference tensor) gets an image only through build_offset_image(): writes into it are invisible, the caller
+        then owns the refresh (refresh_offset_image).
+        hipGraphs: a graph captured while an image exists bakes its buffers in.  They are stable, but their CONTENT follows the weight only when some eager call
+        notices the change -- after writing the weight, call refresh_offset_image() before the next replay."""
         w = self._buffers["weight"]
         if not (self.offsets and w.is_cuda):
             return None
@@ -157,23 +189,45 @@ class _W8A8Base(torch.nn.Module):
             sup = ok[(M, dtype)] = ops.offsets_supported(int(M), self.out_features, self.in_features, dtype)
         if not sup:
             return None
-        try:
-            ver = w._version
-        except RuntimeError:   # an inference tensor has no version counter
-            ver = -1
-        key = (w.data_ptr(), ver, w.device)
+        key = self._weight_key(w)
         hit = self.__dict__.get("_offset_cache")
-        if hit is None or hit[0] != key:
-            if torch.cuda.is_current_stream_capturing():
-                return None   # (an image built inside a capture would only exist after the first replay: this capture runs on the plain operands)
-            hit = (key, ops.weight_offset_image(w))
-            self.__dict__["_offset_cache"] = hit
-        return hit[1]
+        if key[1] is None and not self.__dict__.get("_offset_pinned", False):
+            return None   # no version counter and nobody promised to refresh: plain operands
+        if hit is not None and hit[0] == key and not self.__dict__.get("_offset_dirty", False):
+            return hit[1]
+        if torch.cuda.is_current_stream_capturing():
+            return None   # (an image built inside a capture would only exist after the first replay: this capture runs on the plain operands)
+        return self._image_buffers(w, key)
+
+    def build_offset_image(self):
+        """Build the image now (load time) instead of lazily inside the first prefill-sized forward: the N x K extra bytes are allocated where an OOM is
+        cheap to handle, and a later capture finds the image in place.  Returns True when the module now holds one.  For a weight without a version counter
+        (inference tensor) this is also the opt-in: the caller refreshes after writes."""
+        w = self._buffers["weight"]
+        if not (self.offsets and w.is_cuda):
+            return False
+        self.__dict__["_offset_pinned"] = True
+        return self._image_buffers(w, self._weight_key(w)) is not None
+
+    def refresh_offset_image(self):
+        """Rebuild the image from the current weight INTO the existing buffers (one pass over the weight).  Call after a weight update that torch cannot
+        see -- a raw pointer write, an external library, copy_ into an inference tensor -- and after ANY weight update before replaying a hipGraph that was
+        captured on the image.  No-op (returns False) when the module holds no image."""
+        w = self._buffers["weight"]
+        if self.__dict__.get("_offset_cache") is None or not (self.offsets and w.is_cuda):
+            return False
+        return self._image_buffers(w, self._weight_key(w)) is not None
 
     def invalidate_offset_image(self):
-        """Drop the cached image.  Needed only after a write into `weight` that torch cannot see (a raw pointer write, an external library): in-place torch
-        operations, load_state_dict, .to() and replica.broadcast_quantized change the storage or its version counter and rebuild the image by themselves."""
-        self.__dict__.pop("_offset_cache", None)
+        """Mark the cached image stale: the next eager forward that wants it rebuilds it into the same buffers.  (In-place torch operations on a weight with a
+        version counter, .to() and replica.broadcast_quantized are detected without this; load_state_dict calls it.)"""
+        if self.__dict__.get("_offset_cache") is not None:
+            self.__dict__["_offset_dirty"] = True
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        if prefix + "weight" in state_dict:
+            self.invalidate_offset_image()   # (copy_ into an inference tensor bumps no version counter)
 
     def forward_q(self, x, consumer, act=None):
         """This linear, an optional activation (act = "relu": OPT's fc1 -> ReLU -> fc2, reference models/opt.py:127-128) and the

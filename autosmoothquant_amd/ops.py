@@ -205,14 +205,28 @@ def offsets_supported(M, N, K, out_dtype):
     return out_dtype in _DT and bool(L.lib().asq_offsets_supported(M, N, K, _DT[out_dtype]))
 
 
-def weight_offset_image(w):
-    """w int8 [N,K] -> (w_off int8 [N,K], col_off int32 [N,2] = {cw[n], sum_k w[n,k]}): the weight's offset operand image (asq_weight_offset_image), built once per weight."""
+def _check_image(image, N, K, device):
+    """an offset operand image handed to a C-ABI call: int8 [N,K] + int32 [N,2], contiguous, on `device` (the kernels read both through raw pointers)"""
+    w_off, col_off = image
+    if (w_off.dtype != torch.int8 or tuple(w_off.shape) != (N, K) or not w_off.is_contiguous() or w_off.device != device
+            or col_off.dtype != torch.int32 or tuple(col_off.shape) != (N, 2) or not col_off.is_contiguous() or col_off.device != device):
+        raise ValueError(f"offset image must be (int8 [{N}, {K}], int32 [{N}, 2]), contiguous, on {device}; got "
+                         f"{tuple(w_off.shape)} {w_off.dtype} {w_off.device} / {tuple(col_off.shape)} {col_off.dtype} {col_off.device}")
+
+
+def weight_offset_image(w, out=None):
+    """w int8 [N,K] -> (w_off int8 [N,K], col_off int32 [N,2] = {cw[n], sum_k w[n,k]}): the weight's offset operand image (asq_weight_offset_image), built once per weight.
+    out = (w_off, col_off): rebuild INTO these buffers (a hipGraph captured on them then sees the new image at its next replay)."""
     _dev(w, "weight")
     if w.dtype != torch.int8 or w.dim() != 2:
         raise ValueError("weight must be int8 [N,K]")
     N, K = w.shape
-    w_off = torch.empty_like(w)
-    col_off = torch.empty((N, 2), dtype=torch.int32, device=w.device)
+    if out is not None:
+        _check_image(out, N, K, w.device)
+        w_off, col_off = out
+    else:
+        w_off = torch.empty_like(w)
+        col_off = torch.empty((N, 2), dtype=torch.int32, device=w.device)
     with _on(w.device):
         L.check(L.lib().asq_weight_offset_image(w.data_ptr(), N, K, w_off.data_ptr(), col_off.data_ptr(), _stream(w)), "asq_weight_offset_image")
     return w_off, col_off
@@ -481,6 +495,8 @@ def linear_w8a8_forward(x2d, w, act_mode, quant_scale, s_scalar, s_col=None, bia
             if t.dtype != torch.float32 or t.numel() != N:
                 raise ValueError(f"{name} must be float32 with {N} elements")
     dev = _same_device(x2d, w, s_col, bias)
+    if image is not None:
+        _check_image(image, N, K, dev)
     out = torch.empty((M, N), dtype=x2d.dtype, device=dev)
     if M == 0 or N == 0:
         return out
@@ -502,7 +518,8 @@ def linear_w8a8_forward(x2d, w, act_mode, quant_scale, s_scalar, s_col=None, bia
 def linear_w8a8_forward_trusted(x2d, w, act_code, quant_scale, s_scalar, s_col, bias, image, N, K):
     """linear_w8a8_forward without the per-call validation of the module's own state, for callers that check it where it can change (the nn modules:
     weight / bias / scale vector are validated once per tensor object, layers/nn/linear.py::_module_forward).  Still checked here, per call: the activation
-    (HIP tensor of a supported dtype; contiguity and K are the caller's `_flatten`).  At decode sizes the module call is host-bound (12.9 us at 32 x 4096 x 4096,
+    (HIP tensor of a supported dtype; contiguity and K are the caller's `_flatten`; `image` must come from the module's own cache, whose buffers
+    weight_offset_image allocated or validated).  At decode sizes the module call is host-bound (12.9 us at 32 x 4096 x 4096,
     5.6 us of it the two launches): this path takes ~2 us of Python out of it (tools/pyoverhead.py).  act_code: _lib.ASQ_ACT_*; quant_scale, s_scalar: Python floats."""
     dt = _DT.get(x2d.dtype)
     if dt is None or not x2d.is_cuda:

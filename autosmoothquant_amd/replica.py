@@ -180,6 +180,17 @@ def buffers_fingerprint(root):
     return acc
 
 
+def gather_fingerprints(fp, group=None, device=None):
+    """[fingerprint of rank 0, ..., of rank G-1] on every rank (the bench line prints them: one glance shows that every replica holds rank 0's buffers)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return [int(fp)]
+    mine = torch.tensor([int(fp)], dtype=torch.int64, device=device or "cpu")
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    return [int(t.item()) for t in out]
+
+
 def broadcast_report(nbytes, seconds, world, timing=None):
     """The `weight_broadcast` block of the bench line: achieved GB/s of the collective phase next to one xGMI link and the
     scatter + all-gather model (payload/G over one link, then (G-1)/G of the payload over G-1 links)."""

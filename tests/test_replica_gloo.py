@@ -179,3 +179,68 @@ def test_broadcast_mismatch_raises_everywhere_and_subgroup_source_world3():
         assert p.exitcode == 0
     assert all(r[1] for r in res), "every rank must raise the structure mismatch (no hang, no silent return)"
     assert res[1][2] is True and res[2][2] is True and res[0][2] is None
+
+
+def _mixtral(seed):
+    from autosmoothquant_amd import harness
+    torch.manual_seed(seed)
+    fl = harness.MixtralLayer(64, 96, 4, 2, experts=4, top_k=2)
+    with torch.no_grad():
+        for p in fl.parameters():
+            if p.dim() == 2:
+                p.copy_(torch.randn(p.shape) * 0.05)
+    scales = {"attn_in": 0.05, "o_in": 0.05, "mlp_in": 0.05, "down_in": [0.05 + 0.01 * seed, 0.06, 0.07, 0.08]}
+    return harness.to_w8a8_mixtral(fl, scales)
+
+
+def _worker_mixtral(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from autosmoothquant_amd import replica
+        from autosmoothquant_amd.layers.nn.linear import W8A8BFP32OFP32Linear
+        layer = _mixtral(seed=0 if rank == 0 else 5)
+        lin = W8A8BFP32OFP32Linear(64, 48, False, "per-tensor")
+        lin.weight = torch.randint(-128, 128, (48, 64), generator=torch.Generator().manual_seed(rank), dtype=torch.int8)
+        root = torch.nn.ModuleDict({"layer": layer, "lin": lin})
+        assert layer._stacks_current()
+        # a cached offset image on every rank (stand-in tensors: building a real one needs a HIP device; the KEY logic under test is device-agnostic)
+        lin.__dict__["_offset_cache"] = (lin._weight_key(lin.weight), ("image", "col"))
+        key_before = lin.__dict__["_offset_cache"][0]
+        st_ptr = layer._w1_stack.data_ptr()
+        nbytes = replica.broadcast_quantized(root, src=0)
+        fp = replica.buffers_fingerprint(root)
+        fps = replica.gather_fingerprints(fp)
+        # 1. the per-expert buffers were re-homed into the arena: the stacks are stale until moe() restacks, and their image key with them
+        stale = not layer._stacks_current()
+        layer.stack_experts()
+        restacked = layer._stacks_current() and layer._w1_stack.data_ptr() != st_ptr
+        # 2. the module's cached image is keyed on the weight's storage: the arena view is a different storage -> the next offset_image() rebuilds it
+        key_moved = lin._weight_key(lin.weight) != key_before
+        q.put((rank, nbytes, fp, fps, stale, restacked, key_moved, [float(e.w2.dequant_scale) for e in layer.experts], layer._w2_scale.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_broadcast_mixtral_layer_and_image_keys_world2():
+    """a Mixtral layer (expert stacks) and a module with a cached offset image through the arena broadcast: every rank ends with rank 0's
+    experts, the stacks are rebuilt from the re-homed buffers, the image cache key no longer matches (so the receiver rebuilds the image), and the per-rank
+    fingerprints bench.py prints are equal."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mixtral, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _mixtral(0)
+    want_scales = [float(e.w2.dequant_scale) for e in ref.experts]
+    for rank, nbytes, fp, fps, stale, restacked, key_moved, scales, stack_scales in res:
+        assert nbytes > 0 and stale and restacked and key_moved
+        assert fps == [res[0][2]] * world and fp == res[0][2]
+        assert scales == want_scales and stack_scales == pytest.approx(want_scales)
