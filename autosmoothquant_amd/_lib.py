@@ -42,6 +42,8 @@ SIGNATURES = {
     "asq_quantize_act_off": (_int, [_vp, _int, _int, _f32, _vp, _vp, _vp, _i64, _i64, _vp]),
     "asq_linear_w8a8_off": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
     "asq_offsets_supported": (_int, [_i64, _i64, _i64, _int]),
+    "asq_forward_fused_supported": (_int, [_i64, _i64, _i64, _int]),
+    "asq_linear_w8a8_forward_fused": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _int, _f32, _f32, _vp, _vp, _vp]),
     "asq_linear_w8a8_grouped_off": (_int, [_vp, _vp, _vp, _int, _vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "asq_norm_quantize_off": (_int, [_vp, _int, _vp, _vp, _f32, _int, _vp, _vp, _vp, _i64, _i64, _vp]),
     "asq_add_norm_quantize_off": (_int, [_vp, _vp, _vp, _int, _vp, _vp, _f32, _int, _vp, _vp, _vp, _i64, _i64, _vp]),

@@ -79,6 +79,11 @@ extern "C" int asq_linear_w8a8_forward(const void *x, int x_dtype, const int8_t 
     ASQ_REQUIRE(workspace != nullptr && workspace_bytes >= need, ASQ_ERR_WORKSPACE,
                 "asq_linear_w8a8_forward: workspace %zu B < required %zu B", workspace_bytes, need);
     ASQ_REQUIRE(((uintptr_t)workspace & 255) == 0, ASQ_ERR_ALIGN, "asq_linear_w8a8_forward: workspace must be 256-B aligned");
+    {   // <= 16 rows on a weight-streaming shape: ONE launch, the quantiser is the GEMM's prologue (asq_gemm_skinny_fq.h; the workspace is not touched)
+        int launched = 0;
+        const int rc = asq_try_fused_forward(x, x_dtype, w, out, M, N, K, act_mode, quant_scale, s_scalar, s_col, bias, stream, &launched);
+        if (rc || launched) return rc;
+    }
     // Layout by size (never put activations over a header other calls rely on):
     //   >= gemm part + need : [ header + GEMM scratch | xq | s_row ]   (the full layout)
     //   >= header + need    : [ header | xq | s_row ], the GEMM runs without scratch -- the header of a shared, initialised buffer stays intact

@@ -54,6 +54,10 @@ struct AsqRange {
     AsqRange &operator=(const AsqRange &) = delete;
 };
 
+// the one-launch forward for decode-sized inputs (asq_gemm_fq.hip); *launched = 0: not this shape, run quantiser + GEMM
+int asq_try_fused_forward(const void *x, int x_dtype, const int8_t *w, void *out, int64_t M, int64_t N, int64_t K, int act_mode, float quant_scale, float s_scalar,
+                          const float *s_col, const float *bias, void *stream, int *launched);
+
 static inline size_t asq_dtype_size(int dt) { return dt == ASQ_F32 ? 4 : 2; }
 
 // ---------------------------------------------------------------------------------

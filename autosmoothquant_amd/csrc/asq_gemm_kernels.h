@@ -751,7 +751,11 @@ template <class Epi> __device__ __forceinline__ bool rows_write_through(int64_t 
 {
     return ASQ_WT_BYTES > 0 && M * epi.N * 2 <= (int64_t)ASQ_WT_BYTES && epi.N < (int64_t(1) << 23);
 }
-template <int NTM, int NTN, bool L16 = false, class Epi, class Get>
+// IMGS: token-tile images at `stage` (default: one per tile, side by side; 2: two images used alternately -- half the staging space, for the persistent kernel whose
+// other LDS stage already holds the next tile's operands; a wave's LDS operations execute in order, so rewriting an image behind its own reads is safe).
+// DRAIN: `s_waitcnt vmcnt(0)` between the first tile's conversions and the first store (gemm_i8_p16p: retires the next tile's in-flight operand DMAs at a point
+// where only they are outstanding -- behind ~500 cycles of VALU work, before any store joins the counter).
+template <int NTM, int NTN, bool L16 = false, int IMGS = NTM, bool DRAIN = false, class Epi, class Get>
 __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, unsigned stage, bool wt = false)
 {
     static_assert(Epi::kOutBytes == 2, "2-byte outputs");
@@ -821,18 +825,19 @@ __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int6
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int in = 0; in < 2 * NTN; ++in)
-                    *(lds_u2)(uintptr_t)(wa[in] + im * IMG + h * 16 * ROWB) = epi.pack(get(in, 2 * im + h), sr[2 * im + h], sc[in][0], bb[in][0]);
+                    *(lds_u2)(uintptr_t)(wa[in] + (im % IMGS) * IMG + h * 16 * ROWB) = epi.pack(get(in, 2 * im + h), sr[2 * im + h], sc[in][0], bb[in][0]);
         } else {
 #pragma unroll
             for (int in = 0; in < NTN; ++in) {
                 const auto a = get(in, im);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    *(lds_u2)(uintptr_t)(wa[in * 4 + g] + im * IMG) = epi.pack((acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g]);
+                    *(lds_u2)(uintptr_t)(wa[in * 4 + g] + (im % IMGS) * IMG) = epi.pack((acc4_t){a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]}, sr[im], sc[in][g], bb[in][g]);
             }
         }
     };
     pack_tile(0);
+    if constexpr (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int im = 0; im < NTM; ++im) {
         __builtin_amdgcn_wave_barrier();
@@ -840,8 +845,8 @@ __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int6
         v2u lo[NRD], up[NRD];
 #pragma unroll
         for (int i = 0; i < NRD; ++i) {
-            lo[i] = *(lds_u2)(uintptr_t)(ra0[i] + im * IMG);
-            up[i] = *(lds_u2)(uintptr_t)(ra1[i] + im * IMG);
+            lo[i] = *(lds_u2)(uintptr_t)(ra0[i] + (im % IMGS) * IMG);
+            up[i] = *(lds_u2)(uintptr_t)(ra1[i] + (im % IMGS) * IMG);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (im + 1 < NTM) pack_tile(im + 1);
@@ -1020,9 +1025,11 @@ constexpr int64_t OFFSET_MAX_K = 65536;   // the start values are formed with 24
 #include "asq_gemm_p8.h"
 #include "asq_gemm_p4.h"
 #include "asq_gemm_p16.h"
+#include "asq_gemm_p16p.h"
 #include "asq_gemm_p4x16.h"
 #include "asq_gemm_p8h.h"
 #include "asq_gemm_p8q.h"
+#include "asq_gemm_p8q2.h"
 #include "asq_gemm_skinny.h"
 #include "asq_gemm_wstream.h"
 
@@ -1372,6 +1379,16 @@ static inline bool mma32_forced()
     return v;
 }
 
+// ASQ_P8Q2=0: the 128 x 128 int8 launches stay on gemm_i8_p8q (one barrier per K-tile) instead of gemm_i8_p8q2 (two staggered wave groups); A/B switch, read once
+static inline bool p8q2_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("ASQ_P8Q2");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 // ASQ_GROUPED_SPLIT=0: grouped launches never split the K loop of their tail tiles (A/B switch; the default is on when a workspace is passed)
 static inline bool grouped_tail_split_enabled()
 {
@@ -1495,7 +1512,21 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
     } else if (kern == KERN_P4X16) {
         if constexpr (kP4X) rc = launch_tiled(gemm_i8_p4x16<Epi>, P4_LDS_BYTES, P4_LDS_BYTES, tm256 * tn256, 256, (int)tm256, (int)tn256, epi);
     } else if (kern == KERN_P16) {
-        if constexpr (kP16) rc = launch_tiled(gemm_i8_p16<Epi>, P16_LDS_BYTES, off.row ? P16_LDS_BYTES : P8_LDS_BYTES, tm256 * tn256, 512, (int)tm256, (int)tn256, epi, off);
+        bool done = false;
+        if constexpr (kP16 && Epi::kOutBytes == 2) {
+            // multi-round launches without edge tiles: the persistent form (asq_gemm_p16p.h) -- the next tile's first K-tile and epilogue operands arrive under
+            // this tile's last K-tile and epilogue.  ASQ_P16_PERSIST=0 keeps gemm_i8_p16 (A/B); =2 also takes single-round launches (development).
+            static const int persist = [] { const char *e = getenv("ASQ_P16_PERSIST"); return e ? atoi(e) : 1; }();
+            const int64_t T = tm256 * tn256;
+            if (persist && M % 256 == 0 && N % 256 == 0 && K % 256 == 0 && (T > 8 * P8_CUS_PER_XCD || persist == 2) && ((((uintptr_t)epi.out) & 15) == 0) && (epi.N * 2) % 16 == 0 &&
+                epi.N * 2 < (int64_t(1) << 24)) {
+                const int64_t grid = T < 8 * P8_CUS_PER_XCD ? T : 8 * P8_CUS_PER_XCD;
+                static const int skew = [] { const char *e = getenv("ASQ_P16P_SKEW"); return e ? atoi(e) : 0; }();
+                rc = launch_tiled(gemm_i8_p16p<Epi>, P16P_LDS_BYTES, P16P_LDS_BYTES, grid, 512, (int)tm256, (int)tn256, T >= 4 * grid ? skew : 0, epi, off);
+                done = true;
+            }
+        }
+        if constexpr (kP16) if (!done) rc = launch_tiled(gemm_i8_p16<Epi>, P16_LDS_BYTES, off.row ? P16_LDS_BYTES : P8_LDS_BYTES, tm256 * tn256, 512, (int)tm256, (int)tn256, epi, off);
     } else if (kern == KERN_P8) {
         const int ksplit = ws_ok ? pick_ksplit(tm256 * tn256, K, M, N, ws_bytes) : 1;
         if (ksplit > 1) {
@@ -1537,14 +1568,16 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
         if (ksplit > 1) {
             if constexpr (kInt) {
                 rc = mma32_forced() ? launch_tiled(gemm_i8_p8q<EpiI32>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128 * ksplit, 512, (int)tm128, (int)tn128, ksplit, slab, no_mx, no_mx)
-                                    : launch_tiled(gemm_i8_p8q<EpiI32, false, true>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128 * ksplit, 512, (int)tm128, (int)tn128, ksplit, slab, no_mx, no_mx);
+                     : p8q2_enabled() ? launch_tiled(gemm_i8_p8q2<EpiI32>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128 * ksplit, 512, (int)tm128, (int)tn128, ksplit, slab)
+                                      : launch_tiled(gemm_i8_p8q<EpiI32, false, true>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128 * ksplit, 512, (int)tm128, (int)tn128, ksplit, slab, no_mx, no_mx);
                 if (rc == ASQ_OK) reduce_slabs(ksplit);
             }
         } else {
             bool done = false;
             if constexpr (kInt) {
                 if (!mma32_forced()) {
-                    rc = launch_tiled(gemm_i8_p8q<Epi, false, true>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128, 512, (int)tm128, (int)tn128, 1, epi, no_mx, no_mx);
+                    rc = p8q2_enabled() ? launch_tiled(gemm_i8_p8q2<Epi>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128, 512, (int)tm128, (int)tn128, 1, epi)
+                                        : launch_tiled(gemm_i8_p8q<Epi, false, true>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128, 512, (int)tm128, (int)tn128, 1, epi, no_mx, no_mx);
                     done = true;
                 }
             }

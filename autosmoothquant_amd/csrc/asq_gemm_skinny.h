@@ -58,8 +58,9 @@ template <bool NT = false> __device__ __forceinline__ void sk_dma16(const int8_t
 template <int N> __device__ __forceinline__ void sk_wait_vm()
 {
     static_assert(N >= 0 && N <= 63 && N % 2 == 0, "vmcnt is a 6-bit counter; unit sizes are even");
+    static_assert(N == 0 || N == 2 || (N >= 4 && N <= 20) || N == 24 || N == 28 || N == 32 || N == 36, "no s_waitcnt case for this count (a missing case would wait for nothing)");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    SK_VM_CASE(4); SK_VM_CASE(6); SK_VM_CASE(8); SK_VM_CASE(10); SK_VM_CASE(12); SK_VM_CASE(14); SK_VM_CASE(16); SK_VM_CASE(18);
+    SK_VM_CASE(2); SK_VM_CASE(4); SK_VM_CASE(6); SK_VM_CASE(8); SK_VM_CASE(10); SK_VM_CASE(12); SK_VM_CASE(14); SK_VM_CASE(16); SK_VM_CASE(18);
     SK_VM_CASE(20); SK_VM_CASE(24); SK_VM_CASE(28); SK_VM_CASE(32); SK_VM_CASE(36);
 }
 #undef SK_VM_CASE

@@ -205,6 +205,34 @@ def offsets_supported(M, N, K, out_dtype):
     return out_dtype in _DT and bool(L.lib().asq_offsets_supported(M, N, K, _DT[out_dtype]))
 
 
+def forward_is_fused(M, N, K, dtype):
+    """True when linear_w8a8_forward runs this shape as ONE launch (activation quantiser = the GEMM's prologue; asq_forward_fused_supported)."""
+    return dtype in _DT and bool(L.lib().asq_forward_fused_supported(int(M), int(N), int(K), _DT[dtype]))
+
+
+def linear_w8a8_forward_fused(x2d, w, act_mode, quant_scale, s_scalar, s_col=None, bias=None):
+    """linear_w8a8_forward as ONE launch, on request (asq_linear_w8a8_forward_fused): any shape the fused kernel can run (<= 16 rows, K % 128 == 0, the int8 activation
+    image fits 64 KiB of LDS), also where linear_w8a8_forward itself would take two launches.  Raises on shapes outside the kernel's limits."""
+    _dev(x2d, "x"), _dev(w, "weight")
+    if x2d.dtype not in _DT:
+        raise ValueError(f"unsupported activation dtype {x2d.dtype}")
+    if w.dtype != torch.int8 or x2d.dim() != 2 or w.dim() != 2 or x2d.shape[1] != w.shape[1] or not x2d.is_contiguous() or not w.is_contiguous():
+        raise ValueError(f"shape/dtype mismatch: x {tuple(x2d.shape)} {x2d.dtype}, weight {tuple(w.shape)} {w.dtype} (both contiguous)")
+    M, K = x2d.shape
+    N = w.shape[0]
+    for name, t in (("s_col", s_col), ("bias", bias)):
+        if t is not None:
+            _dev(t, name)
+            if t.dtype != torch.float32 or t.numel() != N:
+                raise ValueError(f"{name} must be float32 with {N} elements")
+    dev = _same_device(x2d, w, s_col, bias)
+    out = torch.empty((M, N), dtype=x2d.dtype, device=dev)
+    with _on(dev):
+        L.check(L.lib().asq_linear_w8a8_forward_fused(x2d.data_ptr(), _DT[x2d.dtype], w.data_ptr(), out.data_ptr(), M, N, K, _ACT[act_mode], float(quant_scale), float(s_scalar),
+                                                      _ptr(s_col), _ptr(bias), _stream(x2d)), "asq_linear_w8a8_forward_fused")
+    return out
+
+
 def _check_image(image, N, K, device):
     """an offset operand image handed to a C-ABI call: int8 [N,K] + int32 [N,2], contiguous, on `device` (the kernels read both through raw pointers)"""
     w_off, col_off = image

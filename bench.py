@@ -638,6 +638,11 @@ def cpu_baseline(spec, M_sample, dtype_tag, budget_s=20.0, mods=None, xs=None):
         np.savez(path, **arrs)
         for backend, n, places, share in plan:
             env = dict(os.environ, OMP_NUM_THREADS=str(n), OMP_PLACES=places, OMP_PROC_BIND="close", MKL_NUM_THREADS=str(n), CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+            if backend == "torch_eager":
+                # every eager op allocates its output; glibc hands blocks >= 128 KiB back to the kernel on free, so each op page-faults a fresh 32-64 MB (serial in
+                # the kernel: the first r5 run measured 1.10 TOPS whole-forward beside 10.5 TOPS for the GEMM alone).  Keeping freed blocks in the heap is what any
+                # CPU deployment of an eager model does (or tcmalloc / jemalloc); the op sequence is untouched.
+                env.update(MALLOC_MMAP_MAX_="0", MALLOC_TRIM_THRESHOLD_="100000000000", MALLOC_TOP_PAD_="268435456")
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", json.dumps([path, backend, n, budget_s * share])], env=env, capture_output=True,
                                    text=True, timeout=max(120.0, 20 * budget_s))

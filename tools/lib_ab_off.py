@@ -17,6 +17,9 @@ ap.add_argument("--rounds", type=int, default=12)
 ap.add_argument("--settle", type=int, default=1500, help="launches per library before the timed rounds")
 ap.add_argument("--per-token", action="store_true")
 ap.add_argument("--plain", action="store_true", help="third arm: library B's asq_linear_w8a8 on the plain operands")
+ap.add_argument("--env-a", default="", help="KEY=VALUE[,KEY=VALUE] put into the environment before library A's FIRST GEMM launch (switches the library reads once, e.g. ASQ_P16_PERSIST=0)")
+ap.add_argument("--env-b", default="", help="the same for library B: with --a and --b the same file this is an A/B of one build's switch")
+ap.add_argument("--no-images", action="store_true", help="both arms on the plain operands (asq_linear_w8a8)")
 args = ap.parse_args()
 vp, i64, f32, sz, cint = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t, ctypes.c_int
 
@@ -77,14 +80,26 @@ for sh in args.shapes.split(","):
     sr = s_row.data_ptr() if args.per_token else None
     outs = {k: torch.empty((M, N), dtype=tdt, device=dev) for k in ("A", "B", "P")}
 
+    def setenv(spec):
+        for kv in filter(None, spec.split(",")):
+            k_, v_ = kv.split("=", 1)
+            os.environ[k_] = v_
+
     def run(k):
+        if args.no_images and k != "P":
+            h = libs[k]
+            return ck(h, h.asq_linear_w8a8(xq.data_ptr(), w.data_ptr(), outs[k].data_ptr(), DT, M, N, K, 0.001, sr, None, None, 0, None, 0, st), "plain " + k)
         if k == "P":   # library B on the plain operands
             B = libs["B"]
             return ck(B, B.asq_linear_w8a8(xq.data_ptr(), w.data_ptr(), outs["P"].data_ptr(), DT, M, N, K, 0.001, sr, None, None, 0, None, 0, st), "plain")
         h = libs[k]
         ck(h, h.asq_linear_w8a8_off(xq_off.data_ptr(), w_off.data_ptr(), outs[k].data_ptr(), DT, M, N, K, 0.001, sr, None, None, 0, row_off.data_ptr(), col_off.data_ptr(), st), "off " + k)
 
-    run("A"), run("B")
+    setenv(args.env_a)
+    run("A")
+    torch.cuda.synchronize()
+    setenv(args.env_b)
+    run("B")
     ck(A, A.asq_linear_w8a8(xq.data_ptr(), w.data_ptr(), outs["P"].data_ptr(), DT, M, N, K, 0.001, sr, None, None, 0, None, 0, st), "plain")
     torch.cuda.synchronize()
     same = torch.equal(outs["A"].view(torch.uint8), outs["B"].view(torch.uint8)), torch.equal(outs["A"].view(torch.uint8), outs["P"].view(torch.uint8))
