@@ -1077,6 +1077,16 @@ __global__ void __launch_bounds__(256) splitk_reduce(const int32_t *__restrict__
 // ---------------------------------------------------------------------------------
 enum GemmKernel { KERN_GENERIC = 0, KERN_SKINNY = 1, KERN_P8 = 2, KERN_P8H = 3, KERN_P4 = 4, KERN_P8Q = 5, KERN_P16 = 6, KERN_P4X16 = 7 };
 
+// ASQ_P8Q2=0: the 128 x 128 int8 launches stay on gemm_i8_p8q (one barrier per K-tile) instead of gemm_i8_p8q2 (two staggered wave groups); A/B switch, read once
+static inline int p8q2_enabled()   // 0: gemm_i8_p8q; 1: gemm_i8_p8q2
+{
+    static const int on = [] {
+        const char *e = getenv("ASQ_P8Q2");
+        return e ? atoi(e) : 1;
+    }();
+    return on;
+}
+
 int forced_kernel();  // env ASQ_GEMM_KERNEL=generic|skinny|p8|p8h (development / A-B aid), asq_gemm.hip
 
 static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, int64_t N, int64_t K)
@@ -1112,8 +1122,10 @@ static inline GemmKernel pick_kernel(const void *x, const void *w, int64_t M, in
             // tiles at twice the L2->LDS bytes per MFMA.  Measured (tools/kbench.py, forced vs default, 48 shapes): -3 ... -22 % for 32..128
             // p8h tiles (512 x 4096 x 4096: 22.8 -> 17.7 us), +15 ... +35 % above 128.
             // (with its cost-model K split p8q also wins 5-13 % at 16..32 tiles and a long K -- 128x4096x11008 20.4 -> 19.0 us; between 40 and 80
-            // tiles at K >= 8192 the two are within 4 % either way and p8h keeps them; OPT's K = 20480 stays with p8h's deeper split)
-            if (th >= 16 && th <= 128 && K < 16384 && !(K >= 8192 && th >= 40 && th < 80)) return KERN_P8Q;
+            // tiles at K >= 8192 the two were within 4 % either way and p8h kept them -- round 5: with gemm_i8_p8q2 the 128 x 128 tiles are ahead there too,
+            // 512 x 4096 x 11008 32.6 -> 30.6 us, 384 rows 27.3 -> 26.7 (profiles/r5_midsize_forced_kernels.txt), so the exception only remains for the
+            // one-barrier kernel (ASQ_P8Q2=0); OPT's K = 20480 stays with p8h's deeper split)
+            if (th >= 16 && th <= 128 && K < 16384 && !(!p8q2_enabled() && K >= 8192 && th >= 40 && th < 80)) return KERN_P8Q;
             return KERN_P8H;
         }
         // 256 x 256 tiles: gemm_i8_p16, p8's schedule on v_mfma_i32_16x16x64_i8.  Under the socket power limit the GEMM's time is its energy, and the
@@ -1379,16 +1391,6 @@ static inline bool mma32_forced()
     return v;
 }
 
-// ASQ_P8Q2=0: the 128 x 128 int8 launches stay on gemm_i8_p8q (one barrier per K-tile) instead of gemm_i8_p8q2 (two staggered wave groups); A/B switch, read once
-static inline bool p8q2_enabled()
-{
-    static const bool on = [] {
-        const char *e = getenv("ASQ_P8Q2");
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
-
 // ASQ_GROUPED_SPLIT=0: grouped launches never split the K loop of their tail tiles (A/B switch; the default is on when a workspace is passed)
 static inline bool grouped_tail_split_enabled()
 {
@@ -1521,8 +1523,7 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
             if (persist && M % 256 == 0 && N % 256 == 0 && K % 256 == 0 && (T > 8 * P8_CUS_PER_XCD || persist == 2) && ((((uintptr_t)epi.out) & 15) == 0) && (epi.N * 2) % 16 == 0 &&
                 epi.N * 2 < (int64_t(1) << 24)) {
                 const int64_t grid = T < 8 * P8_CUS_PER_XCD ? T : 8 * P8_CUS_PER_XCD;
-                static const int skew = [] { const char *e = getenv("ASQ_P16P_SKEW"); return e ? atoi(e) : 0; }();
-                rc = launch_tiled(gemm_i8_p16p<Epi>, P16P_LDS_BYTES, P16P_LDS_BYTES, grid, 512, (int)tm256, (int)tn256, T >= 4 * grid ? skew : 0, epi, off);
+                rc = launch_tiled(gemm_i8_p16p<Epi>, P16P_LDS_BYTES, P16P_LDS_BYTES, grid, 512, (int)tm256, (int)tn256, epi, off);
                 done = true;
             }
         }

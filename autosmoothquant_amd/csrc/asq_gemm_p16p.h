@@ -61,16 +61,12 @@ template <class Epi> struct EpiTileLds {
 
 template <class Epi>
 __global__ void __launch_bounds__(512, 2) gemm_i8_p16p(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
-                                                       int tiles_m, int tiles_n, int skew, Epi epi_in, OffsetArgs off)
+                                                       int tiles_m, int tiles_n, Epi epi_in, OffsetArgs off)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int ABL = 0;   // (the P8_* macros' ablation parameter: none here)
-    // skew > 0 (ASQ_P16P_SKEW, development): the blocks of one XCD start (slot & 7) * skew * 64 cycles apart, so that their epilogues -- 256 simultaneous bursts of
-    // 128 KiB that the fabric drains in ~4 us -- do not coincide in every round
-    if (skew > 0) {
-        const int steps = ((int)(blockIdx.x >> 3) & 7) * skew;
-        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(1);
-    }
+    // (Measured and dropped, profiles/r5_p16p_skew_ab.txt: starting the blocks of an XCD up to 7 x 0.25 ... 1 us apart, so that the 256 epilogue bursts of a round do
+    // not coincide -- 16384 x 4096 x 4096 +1.6 % / -0.1 % / +1.6 % for 8 / 16 / 32 sleep units per step, 65536 x 4096 x 4096 within 0.4 %: nothing.)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;

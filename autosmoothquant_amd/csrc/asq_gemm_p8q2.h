@@ -22,6 +22,11 @@
 
 namespace asq {
 
+// Measured (profiles/r5_midsize_p8q2.txt, cold weights): 512 x 4096 x 4096 16.5 -> 15.0 us, 256 rows 16.2 -> 14.8, 1024 rows 20.4 -> 19.9, 1024 x 4096 x 11008 43.9 -> 42.4:
+// ~790 cycles per K-tile instead of ~950.  What is left is the load segment itself: 4 LDS-DMA instructions + 12 ds_read_b128 per wave take longer to ISSUE than the
+// 256 cycles of the partner's 16 MFMAs (the 128 x 128 tile moves twice p16's DMA bytes per MFMA: 32 one-KiB pieces per 512 cycles of matrix work per CU).  Two variants
+// changed nothing: warm instead of cold weights (15.3 vs 15.0: not the prefetch lead), and group A waiting for tile t+2 at the end of its compute segment
+// (half a K-tile more lead: 15.3 vs 15.0).
 template <class Epi>
 __global__ void __launch_bounds__(512, 2) gemm_i8_p8q2(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
                                                        int tiles_m, int tiles_n, int ksplit, Epi epi_in)

@@ -185,7 +185,7 @@ class LlamaLayer(torch.nn.Module):
         gate, up = concurrent_linears([self.gate_proj, self.up_proj], xi)
         if getattr(self, "fuse_act", False) or alt:  # SiLU * up quantised in one pass; the fp product never reaches HBM
             from .layers.nn.fused import silu_mul_q
-            d = self.down_proj(silu_mul_q(gate, up, self.down_proj, fast=getattr(self, "fast_silu", False)))
+            d = self.down_proj(silu_mul_q(gate, up, self.down_proj, fast=getattr(self, "fast_silu", None)))
             return DeferredResidual(h, d) if getattr(self, "defer_residual", False) else h + d
         g = F.silu(gate) * up
         if record is not None:

@@ -122,7 +122,7 @@ class LayerNormQ(_NormQ):
 
 
 @torch.no_grad()
-def silu_mul_q(gate, up, consumer, fast=False):
+def silu_mul_q(gate, up, consumer, fast=None):
     """silu(gate) * up quantised for `consumer` (a W8A8BFP32OFP32LinearWithQuantScale such as down_proj / w2):
     per-token, or per-tensor with the consumer's calibrated quant_scale.  Returns a QuantizedActivation.  fast: ops.silu_mul_quantize's opt-in
     hardware-transcendental variant."""

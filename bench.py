@@ -284,14 +284,15 @@ def time_cfg3(layers, x, world, sync_all, steps=2, warmup=1):
     lin_ops = 2.0 * tokens * (4 * 4096 * 4096 + 3 * 4096 * 11008) * len(layers)
     out = {"workload": f"{CFG3}: {WORKLOADS[CFG3][0]}", "tokens_per_step_per_gpu": tokens, "layers": len(layers), "steps": steps, "warmup": warmup,
            "linear_ops_per_step_per_gpu": lin_ops, "roofline_floor_s_at_5033_TOPS": lin_ops / 5033e12}
-    # fused_n1_fast_silu: the same with the opt-in hardware-transcendental SiLU*up quantiser (ASQ_SILU_FAST: +-1 int8 at rounding boundaries)
+    # fused_n1: the N1 fusions as the modules run them by default (SiLU*up -> int8 on the hardware transcendentals: within the same +-1-int8 bound of the torch path as the
+    # fixed-order form, tests/test_hip_harness.py); fused_n1_exact_silu: the same with the bit-reproducible SiLU (fast=False / ASQ_SILU_EXACT=1)
     # all_per_tensor_*: BASELINE configs[2] AS STATED ("per-tensor INT8": SURVEY 8d cfg3, linears all per-tensor) -- o_proj / down_proj quantise their inputs with the
     # calibrated per-tensor scales instead of per token (harness.all_per_tensor_view: the same int8 weights, twins of the two modules); the legs above keep the
     # reference's DEFAULT quant_config (out / fc2 per-token), which is the harder case (a row-wise absmax pass in front of two of the seven GEMMs)
     from autosmoothquant_amd import harness as _harness
     views = [_harness.all_per_tensor_view(l) for l in layers]
-    legs = (("reference_composition", layers, False, False), ("fused_n1", layers, True, False), ("fused_n1_fast_silu", layers, True, True),
-            ("all_per_tensor_reference_composition", views, False, False), ("all_per_tensor_fused_n1", views, True, False))
+    legs = (("reference_composition", layers, False, False), ("fused_n1", layers, True, True), ("fused_n1_exact_silu", layers, True, False),
+            ("all_per_tensor_reference_composition", views, False, False), ("all_per_tensor_fused_n1", views, True, True))
     for tag, layers, fused, fast in legs:
         for l in layers:
             l.use_fused = fused
@@ -313,7 +314,8 @@ def time_cfg3(layers, x, world, sync_all, steps=2, warmup=1):
                     "linear_TOPS": round(lin_ops * world * steps / el / 1e12, 1),
                     "linear_frac_of_peak_per_gpu": round(lin_ops * steps / el / 1e12 / PEAK_INT8_TOPS, 4)}
     for l in list(legs[0][1]) + views:
-        l.use_fused = l.defer_residual = l.fast_silu = False
+        l.use_fused = l.defer_residual = False
+        l.fast_silu = None
     out["quant_config"] = {"reference_composition / fused_n1*": "qkv, fc1 per-tensor; out, fc2 per-token (the reference's default)",
                            "all_per_tensor_*": "qkv, out, fc1, fc2 per-tensor (BASELINE configs[2] as stated)"}
     return out

@@ -102,6 +102,9 @@ def test_dispatcher_on_the_model_shapes():
     assert {k for k, v in streamk.items() if v} == {(16, 5120, 20480), (32, 5120, 20480), (64, 4096, 14336)}
     # cfg4 at 256 rows on one GPU and mid-size prefill: the 128-row tiles with a K split
     assert h.asq_gemm_kernel_name(256, 5120, 20480) == b"p8h" and h.asq_gemm_kernel_name(512, 4096, 4096) == b"p8q"
+    # round 5 (gemm_i8_p8q2): the 128 x 128 tiles also take 40..79 tiles of 128 x 256 at K >= 8192 (profiles/r5_midsize_forced_kernels.txt); wide-N shapes stay on 128 x 256
+    assert h.asq_gemm_kernel_name(512, 4096, 11008) == b"p8q" and h.asq_gemm_kernel_name(384, 4096, 11008) == b"p8q"
+    assert h.asq_gemm_kernel_name(512, 11008, 4096) == b"p8h" and h.asq_gemm_kernel_name(384, 11008, 4096) == b"p8h"
 
 
 def test_ops_refuse_cpu_tensors_loudly():

@@ -96,7 +96,7 @@ def test_which_shapes_fuse():
     assert not ops.forward_is_fused(4, 5120, 20480, f16)         # 4 x 20480 B does not fit the resident image
     x = torch.zeros(17, 4096, dtype=f16, device=DEV)
     w = torch.zeros(256, 4096, dtype=torch.int8, device=DEV)
-    with pytest.raises(RuntimeError):
+    with pytest.raises(ValueError):   # ASQ_ERR_DIM
         ops.linear_w8a8_forward_fused(x, w, "per-token", 1.0, 1.0)   # the explicit entry point refuses what the kernel cannot run
 
 
