@@ -11,7 +11,7 @@ ASQ_ACT_ROUND, ASQ_ACT_DIV, ASQ_ACT_PER_TOKEN = 0, 1, 2
 ASQ_EPI_SCALE_FIRST, ASQ_EPI_ACC_FIRST = 0, 1
 ASQ_FP8_PER_TOKEN, ASQ_FP8_PER_TENSOR, ASQ_FP8_STATIC = 0, 1, 2
 
-ASQ_VERSION = 110   # include/asq_hip.h: the C-ABI this loader was written against
+ASQ_VERSION = 120   # include/asq_hip.h: the C-ABI this loader was written against
 _lock = threading.Lock()
 _lib = None
 

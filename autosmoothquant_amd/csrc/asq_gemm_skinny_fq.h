@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny_fq(const void *__restrict_
     // ---- prologue: X -> int8 -> the resident unit image.  Group j (16 elements) of row m lands in unit j / 8, chunk j % 8.
     const int G = (int)(K / 16);            // 16-element groups per row
     const int nthr = wpb * 64;              // (the block has wpb waves)
-    const int ngroups = M * G;
+    const int ngroups = (div_fast & 0x100) ? 0 : M * G;   // (0x100: timing ablation ASQ_FQ_ABL=1 -- no activation loads, the image stays unwritten; results invalid)
     const char *const xb = (const char *)xv;
     auto image_addr = [&](int m, int j) { return lds + (j >> 3) * (mr * 128) + m * 128 + ((((j & 7) ^ ((m >> 1) & 7))) << 4); };
     if (tid < 16) rowmax[tid] = 0;
@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny_fq(const void *__restrict_
     if (mode == ASQ_ACT_PER_TOKEN) {
         __syncthreads();   // (rowmax is zeroed)
         const bool one_pass = ngroups <= batch;   // the rows stay in registers across the row-maximum reduction
+        const bool wave_rows = G % 64 == 0 && ngroups % 64 == 0;   // (block-uniform; then `idx < ngroups` is wave-uniform too)
         FqGroup<DT> g[KEEP];
         for (int base = 0; base < ngroups; base += batch) {   // row maxima as bit patterns (torch.max's NaN propagation: AbsMax)
 #pragma unroll
@@ -189,7 +190,14 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny_fq(const void *__restrict_
                     AbsMax<DT> am;
 #pragma unroll
                     for (int v = 0; v < FqGroup<DT>::NV; ++v) am.add(g[i].v[v]);
-                    atomicMax(&rowmax[idx / G], am.f32bits());
+                    uint32_t mb = am.f32bits();
+                    if (wave_rows) {   // the 64 lanes of a wave hold 64 consecutive groups of ONE row (G % 64 == 0, whole batches): one atomic per wave, not per lane
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) mb = umax32(mb, (uint32_t)__shfl_xor((int)mb, off, 64));
+                        if (lane == 0) atomicMax(&rowmax[idx / G], mb);
+                    } else {
+                        atomicMax(&rowmax[idx / G], mb);
+                    }
                 }
             }
         }
@@ -232,7 +240,7 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny_fq(const void *__restrict_
                     const int m = idx / G, j = idx - m * G;
                     v4i q;
                     if (mode == ASQ_ACT_ROUND) q = g[i].quant(QRound<DT>{});
-                    else if (div_fast) q = g[i].quant(QDivFast<DT>{quant_scale, 1.0f / quant_scale});
+                    else if (div_fast & 1) q = g[i].quant(QDivFast<DT>{quant_scale, 1.0f / quant_scale});
                     else q = g[i].quant(QDiv<DT>{quant_scale});
                     *(v4i *)image_addr(m, j) = q;
                 }
@@ -240,6 +248,10 @@ __global__ void __launch_bounds__(512) gemm_i8_skinny_fq(const void *__restrict_
         }
     }
     __syncthreads();   // the image (and the row scales) are visible to every wave; every compiler-issued load has been waited for: only the W DMAs are in flight
+    if (div_fast & 0x200) {   // (timing ablation ASQ_FQ_ABL=2: prologue only)
+        sk_wait_vm<0>();
+        return;
+    }
 
     // ---- fragment read addresses: lane (r, g) reads row r (mod mr), logical chunk 4h + g of a unit
     const int fr = lane & 15, fg = lane >> 4, xr = fr & (mr - 1);
@@ -349,9 +361,12 @@ int launch_skinny_fq_nt(const void *x, const int8_t *w, void *out, int64_t M, in
     const int64_t ximg = (int64_t)mr * K + 128;
     const int64_t ntiles = (N + 16 * NT - 1) / (16 * NT);
     const int64_t perwave = STG * NT * 2048 + NT * 1024;   // W ring + reduction slot
-    // the most waves per block (K parallelism inside a channel tile) that still gives every tile a resident block; at least 2 units of K per wave
+    // Waves per block.  Up to 4 rows (a 16-44 KiB image, one load batch per thread): gemm_i8_skinny's rule -- the most waves that still give every channel tile a
+    // resident block (4 x 11008 x 4096: 688 blocks of 4 waves 14.0 us, 512 blocks of 8 waves 15.1).  More rows (the explicit entry point): eight waves wherever
+    // they fit -- every block carries the image and its prologue, so few fat blocks that walk their tiles beat many thin ones (8 x 11008 x 4096: 688 blocks of 2 waves
+    // needed four dependent load batches per thread, prologue alone 13 us, forward 21.1 us; with 8 waves 16.2; two launches 14.8: profiles/r5_fused_forward_ablation.txt).
     int wpb = 8;
-    while (wpb > 1 && (ximg + wpb * perwave > LDS_CU || 256 * (LDS_CU / (ximg + wpb * perwave)) < ntiles || K / 128 < 2 * wpb)) wpb >>= 1;
+    while (wpb > 1 && (ximg + wpb * perwave > LDS_CU || K / 128 < 2 * wpb || (mr <= 4 && 256 * (LDS_CU / (ximg + wpb * perwave)) < ntiles))) wpb >>= 1;
     int64_t per_cu = LDS_CU / (ximg + wpb * perwave);
     if (per_cu * wpb > 16) per_cu = 16 / wpb;   // (<= 4 waves per SIMD: the kernel holds ~100 VGPRs)
     if (per_cu < 1) per_cu = 1;
@@ -364,7 +379,8 @@ int launch_skinny_fq_nt(const void *x, const int8_t *w, void *out, int64_t M, in
         asq_set_error("skinny_fq: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return (int)e;
     }
-    const int div_fast = (quant_scale > 0x1p-60f && quant_scale < 0x1p60f) ? 1 : 0;   // (as quantize_dt: the exact division without dividing, inside its validity range)
+    static const int abl = [] { const char *e = getenv("ASQ_FQ_ABL"); return e ? atoi(e) : 0; }();   // development: 1 = no activation loads, 2 = prologue only (timing only, results invalid)
+    const int div_fast = ((quant_scale > 0x1p-60f && quant_scale < 0x1p60f) ? 1 : 0) | (abl << 8);   // (bit 0 as quantize_dt: the exact division without dividing, inside its validity range)
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3((unsigned)(wpb * 64)), lds, s, x, w, (int)M, N, K, wpb, mr, mode, quant_scale, div_fast,
                        FqEpi<DT>{out, s_col, bias, s_scalar});
     return ASQ_OK;

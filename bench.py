@@ -461,6 +461,49 @@ def by_operands(mods, xs, dtype, settle_ms, iters=10, batch=50):
     return res
 
 
+def cfg1_block(device):
+    """BASELINE configs[0] on the device: one W8A8BFP32OFP32Linear 4096 x 4096, per-tensor, batch 4, fp32 activations (the reference's CPU-runnable case).  A decode-sized
+    forward is launch-bound, so what counts is the module call: since round 5 it is ONE kernel (gemm_i8_skinny_fq: the activation quantiser is the GEMM's prologue).
+    Reports the eager module-call period (Python loop, GPU drained at the end), the device period (HIP events), and the same with weights rotated through > 300 MB
+    (cold: the weight comes from HBM, as in a real decoder where 6.5 GB of weights pass between two uses of one)."""
+    from autosmoothquant_amd import ops
+    from autosmoothquant_amd.layers.nn.linear import W8A8BFP32OFP32Linear
+    g = torch.Generator(device=device).manual_seed(11)
+    N = K = 4096
+    M = 4
+    m = W8A8BFP32OFP32Linear(K, N, False, "per-tensor")
+    m.weight = torch.randint(-128, 128, (N, K), generator=g, device=device, dtype=torch.int8)
+    m.dequant_scale = torch.tensor(1e-4)
+    m = m.to(device)
+    x = (torch.randn(M, K, generator=g, device=device) * 3.0)
+    ws = [m._buffers["weight"]] + [m._buffers["weight"].clone() for _ in range(19)]
+    out = {"workload": "cfg1: W8A8BFP32OFP32Linear 4096x4096, per-tensor, batch 4, fp32", "one_launch_forward": bool(ops.forward_is_fused(M, N, K, torch.float32)),
+           "kernel": "gemm_i8_skinny_fq (quantiser prologue + GEMM + dequant epilogue)" if ops.forward_is_fused(M, N, K, torch.float32) else "quant_flat_vec + gemm_i8_skinny"}
+    for tag, rot in (("warm", 1), ("cold", 20)):
+        for _ in range(100):
+            m(x)
+        torch.cuda.synchronize()
+        n = 2000
+        t0 = time.perf_counter()
+        for i in range(n):
+            m._buffers["weight"] = ws[i % rot]
+            m(x)
+        torch.cuda.synchronize()
+        call_us = (time.perf_counter() - t0) / n * 1e6
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(400):
+            m._buffers["weight"] = ws[i % rot]
+            m(x)
+        b.record()
+        b.synchronize()
+        dev_us = a.elapsed_time(b) / 400 * 1e3
+        out[tag] = {"module_call_us": round(call_us, 2), "device_period_us": round(dev_us, 2), "tokens_per_s": round(M / call_us * 1e6, 1),
+                    "weight_stream_GBps": round(N * K / dev_us / 1e3, 1)}
+    m._buffers["weight"] = ws[0]
+    return out
+
+
 def pmc_traffic(kernel_key, M, N, K):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r*_pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc
@@ -950,6 +993,7 @@ def main():
             M_k = M
             if M >= 2304 and not args.no_plain_compare and not args.graph:
                 operand_table = by_operands(mods, xs, tdt, args.settle_ms)
+    cfg1 = cfg1_block(device) if (rank == 0 and args.workload == "llama7b_attn_linears" and not args.graph) else None
     cfg3 = time_cfg3(cfg3_layers, cfg3_x, world, sync_all) if cfg3_layers is not None else None
     del cfg3_layers, cfg3_x
 
@@ -1001,6 +1045,8 @@ def main():
             out["step_tokens_per_s"] = out["tokens_per_s"]
             out["tokens_per_s"] = cfg3["reference_composition"]["tokens_per_s"]
             out["config"]["workload"] += f"  +  {cfg3['workload']} (block 'cfg3': tokens_per_s = its whole-forward rate in the reference's module composition)"
+        if cfg1:
+            out["cfg1"] = cfg1
         if fused_qkv:
             out["step_fused_qkv"] = fused_qkv
         if bcast:

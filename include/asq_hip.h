@@ -32,8 +32,10 @@
 extern "C" {
 #endif
 
-#define ASQ_VERSION 110 /* 0.1.1: + offset operand images (asq_*_off); workspace sizes include the 8 KiB header (asq_workspace_init is mandatory for a
-                           * workspace handed to a GEMM entry point); asq_silu_mul_quantize's `per_token` is a bit field (bit 0 per-token, ASQ_SILU_FAST) */
+#define ASQ_VERSION 120 /* 0.1.2: + asq_forward_fused_supported, asq_linear_w8a8_forward_fused (the one-launch forward for decode-sized inputs; asq_linear_w8a8_forward takes it
+                           * by itself where it wins); ASQ_ROCTX=1 ranges.  0.1.1: + offset operand images (asq_*_off); workspace sizes include the 8 KiB header
+                           * (asq_workspace_init is mandatory for a workspace handed to a GEMM entry point); asq_silu_mul_quantize's `per_token` is a bit field (bit 0
+                           * per-token, ASQ_SILU_FAST) */
 
 /* element types of floating tensors crossing the boundary */
 #define ASQ_F32 0

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(h, n), f"libasq_hip.so lacks {n}"
         assert n in _lib.SIGNATURES, f"_lib.SIGNATURES lacks {n}"
     assert sorted(_lib.SIGNATURES) == names
-    assert h.asq_version() == _lib.ASQ_VERSION == 110
+    assert h.asq_version() == _lib.ASQ_VERSION == 120
 
 
 def test_argument_errors_without_gpu():
@@ -57,7 +57,7 @@ def test_argument_errors_without_gpu():
     assert h.asq_gemm_kernel_name(128, 11008, 4096) == b"skinny"         # wide-N weight: streaming stays ahead up to work 5.8e9
     assert h.asq_gemm_kernel_name(192, 11008, 4096) == b"p8q"
     assert h.asq_gemm_kernel_name(96, 4096, 11008) == b"p8q"             # measured crossover: work > 4e9 leaves the weight-streaming kernel
-    assert h.asq_gemm_kernel_name(512, 4096, 11008) == b"p8h"            # 64 tiles at a long K: p8h's split-K is as good, kept
+    assert h.asq_gemm_kernel_name(512, 4096, 11008) == b"p8q"            # 64 tiles at a long K: round 5, the staggered 128 x 128 kernel is ahead here too (32.6 -> 30.6 us)
     assert h.asq_gemm_kernel_name(64, 5120, 20480) == b"p8h"
     assert h.asq_gemm_kernel_name(2048, 4096, 4096) == b"p8h"            # 128 tiles of 256 rows
     assert h.asq_gemm_kernel_name(2048, 5120, 5120) == b"p16"            # 160 tiles: the 256-row kernel is the more efficient one

@@ -21,4 +21,7 @@ for F in "" "--fuse-norm --fuse-qkv"; do
   T=cfg3$( [ -n "$F" ] && echo _fused )
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$T" -o cfg3 -- python "$ROOT/bench.py" --workload llama7b_decoder_b32_s2048 $F --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/$T.json" 2> "$OUT/$T.err"
 done
-ls -R "$OUT" | head -40
+# BASELINE configs[0] (4 x 4096 x 4096, fp32): the whole module forward must be ONE kernel per call (gemm_i8_skinny_fq), and the roctx ranges of the C-ABI (ASQ_ROCTX=1)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg1" -o cfg1 -- python "$ROOT/bench.py" --workload cfg1_int8linear_m4 --dtype f32 --no-cpu-baseline --steps 200 --warmup 20 > "$OUT/cfg1.json" 2> "$OUT/cfg1.err"
+ASQ_ROCTX=1 rocprofv3 --kernel-trace --marker-trace --stats --output-format csv -d "$OUT/cfg1_roctx" -o cfg1 -- python "$ROOT/bench.py" --workload cfg1_int8linear_m4 --dtype f32 --no-cpu-baseline --steps 50 --warmup 5 > "$OUT/cfg1_roctx.json" 2> "$OUT/cfg1_roctx.err"
+ls -R "$OUT" | head -60
