@@ -1,0 +1,90 @@
+// gate || up as ONE GEMM whose epilogue writes SiLU(gate) * up: the two projections of a gated MLP (reference models/llama.py:206-211,
+// HF LlamaMLP: down_proj(act_fn(gate_proj(x)) * up_proj(x)); both W8A8BFP32OFP32Linear over the SAME quantised input) read one activation and their outputs
+// meet elementwise, so the [M, F] gate and up tensors need never reach HBM: today the two GEMMs write 2 x M x F x 2 bytes and asq_silu_mul_quantize reads them
+// back.  Here the weights are ROW-INTERLEAVED in blocks of 16 channels -- rows 32 j .. 32 j + 15 of w_gu are gate channels 16 j .. 16 j + 15, rows 32 j + 16 ..
+// 32 j + 31 the same channels of up -- so that in the 16 x 16 accumulator layout of v_mfma_i32_16x16x64_i8 (lane = token l & 15, channels 4 (l >> 4) .. + 3 of a
+// 16-channel tile) a lane holds gate AND up of the same (token, 4 channels) in adjacent accumulator tiles, and the epilogue is elementwise per lane:
+//     y_g = dt(s_g [* s_row[m]] * acc_g)      y_u = dt(s_u [* s_row[m]] * acc_u)           exactly what EpiDequant<DT> would have stored for the two linears
+//     a   = dt(dt(silu(y_g)) * y_u)                                                         asq_silu_core.h: the arithmetic of asq_silu_mul_quantize
+// out[M, F] in the activation dtype (the consumer's quantiser -- per-token absmax needs the whole row -- follows as its own pass over HALF the bytes).
+// Bit-identical to asq_linear_w8a8 (gate), asq_linear_w8a8 (up), then the SiLU * up of asq_silu_mul_quantize with the same `fast` flag.
+// Runs on the persistent 256 x 256 kernel (gemm_i8_p16p) only: multi-round prefill launches, M % 256 == 0, F % 128 == 0, K % 256 == 0.
+#pragma once
+#include "asq_silu_core.h"
+
+namespace asq {
+
+template <int DT, bool HAS_ROW> struct EpiGateUp {
+    using Mma = MmaI8;
+    static constexpr bool kHasRow = HAS_ROW, kHasCol = false, kHasBias = false, kGateUp = true;
+    static constexpr int kOutBytes = 2;
+    static_assert(DT == ASQ_F16 || DT == ASQ_BF16, "2-byte activations");
+    void *out;           // [M, F]
+    int64_t N;           // F: the output's row stride in elements (the GEMM itself runs over 2 F interleaved weight rows)
+    const float *s_row;  // [M]  (HAS_ROW: per-token activation scales)
+    float s_gate, s_up, s_scalar;   // dequant scales of the two projections (s_scalar: unused, keeps the functor interface)
+    int fast;
+    __device__ __forceinline__ EpiGateUp rebased(int, int, int64_t, int64_t) const { return *this; }
+    // 4 outputs (channels c .. c + 3 of one token) from the lane's 4 gate and 4 up accumulators
+    __device__ __forceinline__ v2u pack_gate_up(const v4i &g, const v4i &u, float sr) const
+    {
+        const float dg = HAS_ROW ? __fmul_rn(s_gate, sr) : s_gate, du = HAS_ROW ? __fmul_rn(s_up, sr) : s_up;
+        float yg[4], yu[4];
+        uint32_t uh[2] = {0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float vg = __fmul_rn(dg, (float)g[i]), vu = __fmul_rn(du, (float)u[i]);
+            asm("" : "+v"(vg), "+v"(vu));   // (the conversion below is its own rounding: EpiDequant::pack's barrier)
+            if constexpr (DT == ASQ_F16) {
+                const _Float16 hg = (_Float16)vg, hu = (_Float16)vu;
+                yg[i] = (float)hg;
+                uh[i >> 1] |= (uint32_t)__builtin_bit_cast(uint16_t, hu) << (16 * (i & 1));
+            } else {
+                yg[i] = ElemT<DT>::round(vg);
+                yu[i] = ElemT<DT>::round(vu);
+            }
+        }
+        uint32_t o[2];
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            const v2f sl = fast ? silu2<true>(yg[i], yg[i + 1]) : silu2<false>(yg[i], yg[i + 1]);
+            if constexpr (DT == ASQ_F16) {
+                o[i >> 1] = silu_times_up_h(sl, uh[i >> 1]);
+            } else {
+                const v2f a = silu_times_up<DT>(sl, yu[i], yu[i + 1]);
+                o[i >> 1] = (uint32_t)ElemT<DT>::store(a[0]) | ((uint32_t)ElemT<DT>::store(a[1]) << 16);
+            }
+        }
+        return (v2u){o[0], o[1]};
+    }
+};
+
+template <class Epi, class = void> struct IsGateUp : std::false_type {};
+template <class Epi> struct IsGateUp<Epi, std::enable_if_t<Epi::kGateUp>> : std::true_type {};
+
+// Epilogue of one wave tile (128 tokens x 64 interleaved channels = 32 output channels) of gemm_i8_p16p: interior tiles only, per-token scales from the tile's
+// LDS operand area (EL = EpiTileLds<EpiGateUp>), direct 8-byte stores (a store instruction covers 16 rows x 32 bytes; the output is half a plain tile's bytes).
+// The vmcnt(0) that retires the next tile's in-flight operand DMAs sits between the first conversions and the first store, as in epilogue_wave_rows<.., DRAIN>.
+template <class EL, class Get> __device__ __forceinline__ void epilogue_gate_up(const EL &el, Get get, int64_t mw0, int64_t nw0, int lane)
+{
+    const auto &e = el.e;
+    const int t = lane & 15, q = lane >> 4;
+    const unsigned ldb = __builtin_amdgcn_readfirstlane((unsigned)(e.N * 2));   // output row pitch in bytes (128 * ldb < 2^31: the launcher checks)
+    const uint64_t tile = (uint64_t)(uintptr_t)uniform_ptr((const int8_t *)e.out + (mw0 * e.N + (nw0 >> 1)) * 2);
+    const unsigned voff = (unsigned)t * ldb + (unsigned)q * 8;
+    typedef __attribute__((address_space(1))) v2u *glb_v2u;
+    float sr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sr[i] = el.row(mw0 + i * 16 + t);
+    v2u first = e.pack_gate_up(get(0, 0), get(1, 0), sr[0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int im16 = 0; im16 < 8; ++im16)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const v2u o = (im16 == 0 && p == 0) ? first : e.pack_gate_up(get(2 * p, im16), get(2 * p + 1, im16), sr[im16]);
+            *(glb_v2u)(uintptr_t)(tile + (uint64_t)((unsigned)(im16 * 16) * ldb + (unsigned)(p * 32)) + voff) = o;
+        }
+}
+
+}  // namespace asq

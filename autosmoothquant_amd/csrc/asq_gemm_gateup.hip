@@ -1,0 +1,53 @@
+// C-ABI of the gate || up GEMM with the SiLU(gate) * up epilogue (asq_gemm_gateup.h) on the persistent 256 x 256 kernel.
+#include "asq_gemm_kernels.h"
+
+using namespace asq;
+
+static bool gate_up_shape(int64_t M, int64_t F, int64_t K, int out_dtype)
+{
+    static const bool on = [] { const char *e = getenv("ASQ_GATE_UP"); return !(e && e[0] == '0'); }();   // ASQ_GATE_UP=0: callers fall back to two GEMMs + asq_silu_mul_quantize (A/B)
+    if (!on || !(out_dtype == ASQ_F16 || out_dtype == ASQ_BF16)) return false;
+    if (M < 256 || M % 256 != 0 || F < 128 || F % 128 != 0 || K < 256 || K % 256 != 0 || K > OFFSET_MAX_K) return false;
+    const int64_t T = (M / 256) * (2 * F / 256);
+    return T > 8 * P8_CUS_PER_XCD && F * 2 * 128 < (int64_t(1) << 31) && M * K < (int64_t(1) << 40);
+}
+
+extern "C" int asq_gate_up_supported(int64_t M, int64_t F, int64_t K, int out_dtype) { return gate_up_shape(M, F, K, out_dtype) ? 1 : 0; }
+
+template <int DT, bool ROW>
+static int launch_gate_up(const int8_t *xq, const int8_t *w_gu, void *out, int64_t M, int64_t F, int64_t K, float s_gate, float s_up, const float *s_row, int fast,
+                          OffsetArgs off, hipStream_t s)
+{
+    using Epi = EpiGateUp<DT, ROW>;
+    auto kfn = gemm_i8_p16p<Epi>;
+    const hipError_t e = ensure_dynamic_lds((const void *)kfn, P16P_LDS_BYTES);
+    if (e != hipSuccess) {
+        asq_set_error("asq_linear_w8a8_gate_up: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    const int64_t N = 2 * F, tm = M / 256, tn = N / 256, T = tm * tn;
+    const int64_t grid = T < 8 * P8_CUS_PER_XCD ? T : 8 * P8_CUS_PER_XCD;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), P16P_LDS_BYTES, s, xq, w_gu, M, N, K, (int)tm, (int)tn, Epi{out, F, s_row, s_gate, s_up, 1.0f, fast}, off);
+    return asq_after_launch(s, "asq_linear_w8a8_gate_up");
+}
+
+extern "C" int asq_linear_w8a8_gate_up(const int8_t *xq, const int8_t *w_gu, void *out, int out_dtype, int64_t M, int64_t F, int64_t K, float s_gate, float s_up,
+                                       const float *s_row, int flags, const int32_t *row_off, const int32_t *col_off, void *stream)
+{
+    const AsqRange range_("asq_linear_w8a8_gate_up");
+    ASQ_REQUIRE(M >= 0 && F >= 0 && K >= 0, ASQ_ERR_DIM, "asq_linear_w8a8_gate_up: bad dims");
+    if (M == 0 || F == 0) return ASQ_OK;
+    ASQ_REQUIRE(xq != nullptr && w_gu != nullptr && out != nullptr, ASQ_ERR_NULL, "asq_linear_w8a8_gate_up: NULL xq / w_gu / out");
+    ASQ_REQUIRE(out_dtype == ASQ_F16 || out_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_linear_w8a8_gate_up: out_dtype must be ASQ_F16 or ASQ_BF16 (got %d)", out_dtype);
+    ASQ_REQUIRE((flags & ~ASQ_SILU_FAST) == 0, ASQ_ERR_DTYPE, "asq_linear_w8a8_gate_up: flags is a bit field (ASQ_SILU_FAST), got %d", flags);
+    ASQ_REQUIRE(gate_up_shape(M, F, K, out_dtype), ASQ_ERR_DIM,
+                "asq_linear_w8a8_gate_up: needs M %% 256 == 0, F %% 128 == 0, K %% 256 == 0, K <= 65536 and more than 256 tiles of 256 x 256 over [M, 2 F] (asq_gate_up_supported)");
+    ASQ_REQUIRE((((uintptr_t)xq | (uintptr_t)w_gu | (uintptr_t)out) & 15) == 0 && (((uintptr_t)s_row) & 3) == 0, ASQ_ERR_ALIGN, "asq_linear_w8a8_gate_up: xq / w_gu / out must be 16-byte aligned");
+    ASQ_REQUIRE((row_off == nullptr) == (col_off == nullptr) && ((((uintptr_t)row_off | (uintptr_t)col_off) & 7) == 0), ASQ_ERR_ALIGN,
+                "asq_linear_w8a8_gate_up: row_off and col_off come together (offset operand images), 8-byte aligned");
+    const OffsetArgs off{row_off, col_off};
+    const int fast = (flags & ASQ_SILU_FAST) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == ASQ_F16) return s_row ? launch_gate_up<ASQ_F16, true>(xq, w_gu, out, M, F, K, s_gate, s_up, s_row, fast, off, s) : launch_gate_up<ASQ_F16, false>(xq, w_gu, out, M, F, K, s_gate, s_up, s_row, fast, off, s);
+    return s_row ? launch_gate_up<ASQ_BF16, true>(xq, w_gu, out, M, F, K, s_gate, s_up, s_row, fast, off, s) : launch_gate_up<ASQ_BF16, false>(xq, w_gu, out, M, F, K, s_gate, s_up, s_row, fast, off, s);
+}

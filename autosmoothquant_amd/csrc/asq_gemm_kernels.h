@@ -1025,6 +1025,7 @@ constexpr int64_t OFFSET_MAX_K = 65536;   // the start values are formed with 24
 #include "asq_gemm_p8.h"
 #include "asq_gemm_p4.h"
 #include "asq_gemm_p16.h"
+#include "asq_gemm_gateup.h"
 #include "asq_gemm_p16p.h"
 #include "asq_gemm_p4x16.h"
 #include "asq_gemm_p8h.h"

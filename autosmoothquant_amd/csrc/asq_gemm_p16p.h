@@ -281,6 +281,10 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16p(const int8_t *__restrict_
         const unsigned stage = lds0 + P8_STAGE + wave * 8192;
         int le = lane;   // an opaque copy per tile: every lane-derived address of the epilogue is tile-invariant, and hoisted out of the tile loop it would live through the K loop
         asm volatile("" : "+v"(le));
+        auto emit = [&](auto getter) {
+            if constexpr (IsGateUp<Epi>::value) epilogue_gate_up(el, getter, mw0, nw0, le);   // gate || up GEMM: SiLU(gate) * up, half the output bytes (asq_gemm_gateup.h)
+            else epilogue_wave_rows<4, 2, true, 2, true>(el, getter, mw0, nw0, le, stage, false);
+        };
         if (offs) {
             const int t16i = le & 15, q16i = le >> 4;
             int cp[4][4], rw[8];   // column pairs packed cw << 24 | wsum & 0xFFFFFF (0 <= cw <= 64, |wsum| <= 2^23: v_mad_i32_i24 takes the low 24 bits of a factor, sign-extended)
@@ -313,10 +317,10 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16p(const int8_t *__restrict_
                 for (int e = 0; e < 4; ++e) o[e] = mad24(cp[in16][e] >> 24, r, mad24(ncx, cp[in16][e], a[e]));
                 return o;
             };
-            epilogue_wave_rows<4, 2, true, 2, true>(el, getc, mw0, nw0, le, stage, false);
+            emit(getc);
         } else {
             auto get = [&](int in16, int im16) -> const v4i & { return acc[im16 >> 2][in16 >> 1][im16 & 3][in16 & 1]; };
-            epilogue_wave_rows<4, 2, true, 2, true>(el, get, mw0, nw0, le, stage, false);
+            emit(get);
         }
         if (!has_next) break;
         P8_BAR();   // every wave's staging reads are done: the next tile's K-tile 1 may be prefetched into stage 1

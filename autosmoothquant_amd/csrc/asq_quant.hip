@@ -6,6 +6,7 @@
 // cast, div, round, clamp, cast as separate ATen launches).
 #include "asq_common.h"
 #include "asq_quant_core.h"
+#include "asq_silu_core.h"
 #include <type_traits>
 #include <algorithm>
 #include <cstdlib>
@@ -529,59 +530,6 @@ static int offset_cw() { static const int v = offset_const("ASQ_OFF_CW", 64, 127
 // (sqrtf, not __fsqrt_rn: the HIP header maps the latter to the NATIVE square root unless OCML_BASIC_ROUNDED_OPERATIONS is set)
 __device__ __forceinline__ float rsqrt_exact(float v) { return __fdiv_rn(1.0f, sqrtf(v)); }
 
-// exp(x) as a fixed sequence of IEEE fp32 operations (no FMA, no library call): Cody-Waite reduction by ln 2,
-// degree-7 Taylor polynomial in Horner form, scaling by two exact powers of two.  <= ~2 ulp from the true value
-// on [-87, 88]; +inf above 88.8, 0 below -104; NaN propagates.  oracle/n1.py::exp_det repeats it step by step, so
-// every kernel that uses it is compared with the oracle bit for bit (libm / ocml exp differ in the last ulp between
-// implementations, which is what made the r1 silu test a +-1 comparison).
-__device__ __forceinline__ float pow2i(int k) { return __int_as_float((k + 127) << 23); }  // 2^k, -126 <= k <= 127
-__device__ __forceinline__ float exp_det(float x)
-{
-    if (!(x == x)) return x;
-    x = fminf(fmaxf(x, -104.0f), 89.0f);
-    const float n = rintf(__fmul_rn(x, 1.44269502162933349609375f));          // round-half-even(x * log2 e)
-    float r = __fadd_rn(x, -__fmul_rn(n, 0.693138122558593750f));             // ln2_hi (17 significant bits)
-    r = __fadd_rn(r, -__fmul_rn(n, 9.05800061445916071534156799316e-06f));    // ln2_lo
-    float p = 1.0f / 5040.0f;
-    p = __fadd_rn(__fmul_rn(p, r), 1.0f / 720.0f);
-    p = __fadd_rn(__fmul_rn(p, r), 1.0f / 120.0f);
-    p = __fadd_rn(__fmul_rn(p, r), 1.0f / 24.0f);
-    p = __fadd_rn(__fmul_rn(p, r), 1.0f / 6.0f);
-    p = __fadd_rn(__fmul_rn(p, r), 0.5f);
-    p = __fadd_rn(__fmul_rn(p, r), 1.0f);
-    p = __fadd_rn(__fmul_rn(p, r), 1.0f);
-    const int ni = (int)n, n1 = ni >> 1, n2 = ni - n1;                          // |n1|, |n2| <= 75
-    return __fmul_rn(__fmul_rn(p, pow2i(n1)), pow2i(n2));
-}
-
-// The same function on a PAIR of values: every multiply / add is one v_pk_mul_f32 / v_pk_add_f32 (gfx950 issues two IEEE fp32
-// operations per lane per instruction), operation for operation the sequence of exp_det -- the SiLU kernel is VALU-bound on exactly
-// this polynomial.  Two shortcuts that cannot change a result the caller sees:
-//  * the final scaling p * 2^n1 * 2^n2 is one v_ldexp_f32: identical whenever the result is a normal number or overflows (the
-//    first product is exact, the second rounds once, as ldexp does); for subnormal results both round once from the same exact
-//    value;
-//  * NAN_SELECT = false skips the "NaN in, NaN out" select: the caller's g / (1 + e) is NaN through g anyway.
-typedef float v2f __attribute__((ext_vector_type(2)));
-template <bool NAN_SELECT = true> __device__ __forceinline__ v2f exp_det2(v2f x0)
-{
-    const v2f x = {__builtin_amdgcn_fmed3f(x0[0], -104.0f, 89.0f), __builtin_amdgcn_fmed3f(x0[1], -104.0f, 89.0f)};  // (a NaN lane computes on -104)
-    const v2f t = x * 1.44269502162933349609375f;
-    const v2f n = {rintf(t[0]), rintf(t[1])};
-    v2f r = x - n * 0.693138122558593750f;
-    r = r - n * 9.05800061445916071534156799316e-06f;
-    v2f p = {1.0f / 5040.0f, 1.0f / 5040.0f};
-    p = p * r + 1.0f / 720.0f;
-    p = p * r + 1.0f / 120.0f;
-    p = p * r + 1.0f / 24.0f;
-    p = p * r + 1.0f / 6.0f;
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
-    const v2f e = {__builtin_ldexpf(p[0], (int)n[0]), __builtin_ldexpf(p[1], (int)n[1])};
-    if constexpr (!NAN_SELECT) return e;
-    else return (v2f){x0[0] == x0[0] ? e[0] : x0[0], x0[1] == x0[1] ? e[1] : x0[1]};
-}
-
 __device__ __forceinline__ float block_sum_256(float v, float *red)
 {
 #pragma unroll
@@ -808,24 +756,15 @@ __global__ void __launch_bounds__(256) silu_mul_quant_cached(const void *__restr
             if constexpr (!H) vec_unpack<DT>(uw, u);
 #pragma unroll
             for (int j = 0; j < VEC; j += 2) {  // two elements per packed instruction
-                float q0, q1;
-                if constexpr (FAST) {
-                    q0 = g[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g[j] * -1.4426950408889634f));
-                    q1 = g[j + 1] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g[j + 1] * -1.4426950408889634f));
-                } else {
-                    const v2f den = exp_det2<false>((v2f){-g[j], -g[j + 1]}) + 1.0f;
-                    q0 = __fdiv_rn(g[j], den[0]);
-                    q1 = __fdiv_rn(g[j + 1], den[1]);
-                }
+                const v2f sl = silu2<FAST>(g[j], g[j + 1]);   // (asq_silu_core.h: the arithmetic the gate||up GEMM's epilogue shares)
                 if constexpr (H) {
-                    const v2h sl = {(_Float16)q0, (_Float16)q1};
-                    const uint32_t pr = __builtin_bit_cast(uint32_t, sl * __builtin_bit_cast(v2h, (uint32_t)uw[j / 2]));
+                    const uint32_t pr = silu_times_up_h(sl, (uint32_t)uw[j / 2]);
                     ah[i][j / 2] = pr;
                     if constexpr (PER_TOKEN) amax = pk_max_u16(amax, pr & 0x7FFF7FFFu);
                 } else {
-                    const v2f pr = (v2f){ElemT<DT>::round(q0), ElemT<DT>::round(q1)} * (v2f){u[j], u[j + 1]};
-                    a[i][j] = ElemT<DT>::round(pr[0]);
-                    a[i][j + 1] = ElemT<DT>::round(pr[1]);
+                    const v2f pr = silu_times_up<DT>(sl, u[j], u[j + 1]);
+                    a[i][j] = pr[0];
+                    a[i][j + 1] = pr[1];
                     if constexpr (PER_TOKEN) amax = umax32(amax, umax32(absbits(a[i][j]), absbits(a[i][j + 1])));
                 }
             }

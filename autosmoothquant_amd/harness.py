@@ -171,6 +171,13 @@ class LlamaLayer(torch.nn.Module):
         alt = getattr(self, "use_fused", False)
         norm = self.post_attention_layernorm_q if alt else self.post_attention_layernorm
         readers = (self.gate_proj, self.up_proj)
+        gu = getattr(self, "gate_up", None) if (alt and getattr(self, "fuse_gate_up", True)) else None
+        if gu is not None:
+            hb = h.base if isinstance(h, DeferredResidual) else h
+            if gu.supported(hb.numel() // hb.shape[-1], hb.dtype):
+                readers = (gu,)   # gate || up as ONE GEMM with the SiLU * up epilogue (layers/nn/fused.py::GateUpSiLU)
+            else:
+                gu = None
         if isinstance(h, DeferredResidual):
             if hasattr(norm, "add_forward"):
                 h, x = norm.add_forward(h.delta, h.base, consumers=readers)
@@ -181,6 +188,14 @@ class LlamaLayer(torch.nn.Module):
             x = norm(h, consumers=readers) if hasattr(norm, "add_forward") else norm(h)
         if record is not None:
             record["mlp_in"] = x
+        if gu is not None:
+            from .layers.nn.fused import QuantizedActivation
+            qa = x if isinstance(x, QuantizedActivation) else self.gate_proj.quantize_input(x, consumers=(gu,))
+            a = gu(qa, fast=getattr(self, "fast_silu", None))
+            if a is not None:
+                d = self.down_proj(a)
+                return DeferredResidual(h, d) if getattr(self, "defer_residual", False) else h + d
+            x = qa
         xi = shared_input(x, self.gate_proj, self.up_proj)
         gate, up = concurrent_linears([self.gate_proj, self.up_proj], xi)
         if getattr(self, "fuse_act", False) or alt:  # SiLU * up quantised in one pass; the fp product never reaches HBM
@@ -286,6 +301,8 @@ def to_w8a8(layer, scales, quant_config=None, fuse_norm=False, fuse_qkv=False, b
         q.post_attention_layernorm_q = RMSNormQ.from_float(layer.post_attention_layernorm, scales["mlp_in"], per_token=cfg["fc1"] == "per-token")
         if not fuse_qkv:
             q.qkv_proj = qkv_from_parts(q.q_proj, q.k_proj, q.v_proj)
+        from .layers.nn.fused import GateUpSiLU
+        q.gate_up = GateUpSiLU(q.gate_proj, q.up_proj)   # (round 5) gate || up as one GEMM with the SiLU * up epilogue, where the shape runs on it
         q.use_fused = False
     return q
 

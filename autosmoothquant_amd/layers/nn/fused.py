@@ -134,3 +134,83 @@ def silu_mul_q(gate, up, consumer, fast=None):
     qs = 1.0 if per_token else float(consumer.quant_scale)
     r = ops.silu_mul_quantize(g2, u2, per_token, qs, fast, offsets=wants_offsets((consumer,), g2.shape[0], gate.dtype))
     return QuantizedActivation(r[0], r[1], gate.dtype, lead, r[2] if len(r) > 2 else None)
+
+
+class GateUpSiLU(torch.nn.Module):
+    """SiLU(gate_proj(x)) * up_proj(x) as ONE GEMM over the two projections' interleaved int8 rows (ops.linear_w8a8_gate_up; reference models/llama.py:206-211 /
+    HF LlamaMLP).  A VIEW of two existing W8A8BFP32OFP32Linear modules: they stay the source of truth (state_dict, load_state_dict, the arena broadcast act on THEIR
+    buffers); this module derives the interleaved operand -- one more int8 copy of the two weights, plus its offset image where the shape runs on images -- on
+    the first forward that can use it and rebuilds it (into the same buffers) when either weight changes.
+    forward(qa) -> the [.., F] activation in qa.out_dtype, or None when the shape does not run on the fused kernel (the caller then runs the two linears and
+    silu_mul_q).  Bit-identical to that two-linear + asq_silu_mul_quantize composition (same `fast` flag)."""
+
+    offsets = True
+
+    def __init__(self, gate, up):
+        super().__init__()
+        if gate.use_bias or up.use_bias or gate.act_quant != up.act_quant or gate.in_features != up.in_features or gate.out_features != up.out_features:
+            raise ValueError("GateUpSiLU: gate / up must be bias-free W8A8 linears of one shape and one act_quant")
+        self.__dict__["gate"], self.__dict__["up"] = gate, up      # (not registered: this module owns no checkpoint state)
+        self.in_features, self.out_features, self.act_quant = gate.in_features, gate.out_features, gate.act_quant
+
+    def input_signature(self):
+        return self.gate.input_signature()
+
+    def supported(self, M, dtype):
+        g, u = self.gate, self.up
+        return (g._buffers["weight"].is_cuda and g.input_signature() == u.input_signature() and self.out_features % 16 == 0
+                and ops.gate_up_supported(M, self.out_features, self.in_features, dtype))
+
+    def _key(self):
+        return tuple(m._weight_key(m._buffers["weight"]) for m in (self.gate, self.up))
+
+    def _operand(self):
+        key = self._key()
+        if any(k[1] is None for k in key):
+            return None   # a weight without a version counter: writes into it cannot be seen -> the unfused composition
+        hit = self.__dict__.get("_wgu")
+        if hit is None or hit[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            out = hit[1] if hit is not None and hit[1].device == self.gate.weight.device else None
+            hit = (key, ops.interleave_gate_up(self.gate._buffers["weight"], self.up._buffers["weight"], out=out))
+            self.__dict__["_wgu"] = hit
+            self.__dict__["_wgu_image_key"] = None
+        return hit[1]
+
+    def offset_image(self, M, dtype):
+        """the interleaved operand's offset image when a forward of M rows runs on images, else None (so a fused norm in front emits the activation's image for it)"""
+        if not (self.offsets and self.supported(M, dtype) and ops.offsets_supported(int(M), 2 * self.out_features, self.in_features, dtype)):
+            return None
+        w = self._operand()
+        if w is None:
+            return None
+        if self.__dict__.get("_wgu_image_key") != self._key():
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            old = self.__dict__.get("_wgu_image")
+            self.__dict__["_wgu_image"] = ops.weight_offset_image(w, out=old if old is not None and old[0].device == w.device else None)
+            self.__dict__["_wgu_image_key"] = self._key()
+        return self.__dict__["_wgu_image"]
+
+    @torch.no_grad()
+    def forward(self, qa, fast=None):
+        if not isinstance(qa, QuantizedActivation):
+            raise TypeError("GateUpSiLU takes the QuantizedActivation its projections share (mod.quantize_input / a fused norm)")
+        M = qa.xq.shape[0]
+        if not self.supported(M, qa.out_dtype) or (self.act_quant == "per-token") != (qa.s_row is not None):
+            return None
+        w = self._operand()
+        if w is None:
+            return None
+        sg, su = self.gate._scalar("dequant_scale"), self.up._scalar("dequant_scale")
+        if qa.row_off is not None:
+            image = self.offset_image(M, qa.out_dtype)
+            if image is not None:
+                out = ops.linear_w8a8_gate_up(qa.xq, image[0], qa.out_dtype, sg, su, qa.s_row, fast, qa.row_off, image[1])
+                return out.view(*qa.lead, self.out_features)
+            xq = qa.plain_xq()
+        else:
+            xq = qa.xq
+        out = ops.linear_w8a8_gate_up(xq, w, qa.out_dtype, sg, su, qa.s_row, fast)
+        return out.view(*qa.lead, self.out_features)

@@ -235,6 +235,53 @@ def linear_w8a8_forward_fused(x2d, w, act_mode, quant_scale, s_scalar, s_col=Non
     return out
 
 
+def gate_up_supported(M, F, K, dtype):
+    """True when linear_w8a8_gate_up can run [M, K] x (gate || up of F channels each) with `dtype` outputs (asq_gate_up_supported)."""
+    return dtype in _DT and bool(L.lib().asq_gate_up_supported(int(M), int(F), int(K), _DT[dtype]))
+
+
+def interleave_gate_up(w_gate, w_up, out=None):
+    """[F, K] gate and up -> the [2 F, K] operand of linear_w8a8_gate_up: blocks of 16 gate channels alternate with the same 16 channels of up (include/asq_hip.h)."""
+    F_, K = w_gate.shape
+    if w_up.shape != w_gate.shape or w_gate.dtype != torch.int8 or w_up.dtype != torch.int8 or F_ % 16 != 0:
+        raise ValueError("gate / up must be int8 [F, K] with F % 16 == 0")
+    if out is None:
+        out = torch.empty((2 * F_, K), dtype=torch.int8, device=w_gate.device)
+    v = out.view(F_ // 16, 2, 16, K)
+    v[:, 0].copy_(w_gate.view(F_ // 16, 16, K))
+    v[:, 1].copy_(w_up.view(F_ // 16, 16, K))
+    return out
+
+
+def linear_w8a8_gate_up(xq, w_gu, out_dtype, s_gate, s_up, s_row=None, fast=None, row_off=None, col_off=None, out=None):
+    """SiLU(gate(x)) * up(x) in ONE GEMM over the interleaved weight (asq_linear_w8a8_gate_up): out [M, F] in out_dtype, bit-identical to
+    linear_w8a8 (gate), linear_w8a8 (up) and the SiLU * up of silu_mul_quantize(fast=...).  row_off / col_off: offset operand images of xq and w_gu."""
+    _dev(xq, "xq"), _dev(w_gu, "w_gu")
+    if xq.dtype != torch.int8 or w_gu.dtype != torch.int8 or xq.dim() != 2 or w_gu.dim() != 2 or xq.shape[1] != w_gu.shape[1] or w_gu.shape[0] % 2:
+        raise ValueError("xq [M,K] and w_gu [2F,K] must be int8 with equal K")
+    if not (xq.is_contiguous() and w_gu.is_contiguous()):
+        raise ValueError("xq / w_gu must be contiguous")
+    M, K = xq.shape
+    F_ = w_gu.shape[0] // 2
+    if s_row is not None:
+        _dev(s_row, "s_row")
+        if s_row.dtype != torch.float32 or s_row.numel() != M:
+            raise ValueError(f"s_row must be float32 with {M} elements")
+    if (row_off is None) != (col_off is None):
+        raise ValueError("row_off and col_off come together")
+    if row_off is not None and (row_off.dtype != torch.int32 or row_off.numel() != 2 * M or col_off.dtype != torch.int32 or col_off.numel() != 4 * F_):
+        raise ValueError("row_off must be int32 [M,2] and col_off int32 [2F,2]")
+    if fast is None:
+        fast = not SILU_EXACT_DEFAULT
+    if out is None:
+        out = torch.empty((M, F_), dtype=out_dtype, device=xq.device)
+    dev = _same_device(xq, w_gu, out, s_row, row_off, col_off)
+    with _on(dev):
+        L.check(L.lib().asq_linear_w8a8_gate_up(xq.data_ptr(), w_gu.data_ptr(), out.data_ptr(), _DT[out_dtype], M, F_, K, float(s_gate), float(s_up), _ptr(s_row),
+                                                L.ASQ_SILU_FAST if fast else 0, _ptr(row_off), _ptr(col_off), _stream(xq)), "asq_linear_w8a8_gate_up")
+    return out
+
+
 def _check_image(image, N, K, device):
     """an offset operand image handed to a C-ABI call: int8 [N,K] + int32 [N,2], contiguous, on `device` (the kernels read both through raw pointers)"""
     w_off, col_off = image

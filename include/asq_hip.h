@@ -261,6 +261,17 @@ int asq_norm_quantize_off(const void *x, int x_dtype, const void *weight, const 
                           int8_t *xq_off, float *s_row, int32_t *row_off, int64_t M, int64_t K, void *stream);
 int asq_add_norm_quantize_off(const void *x, const void *residual, void *h_out, int x_dtype, const void *weight, const void *bias,
                               float eps, int per_token, int8_t *xq_off, float *s_row, int32_t *row_off, int64_t M, int64_t K, void *stream);
+/* gate || up as ONE GEMM whose epilogue writes SiLU(gate) * up (round 5): the two projections of a gated MLP -- reference models/llama.py:206-211 (HF LlamaMLP:
+ * down_proj(act_fn(gate_proj(x)) * up_proj(x))), both W8A8BFP32OFP32Linear over the same quantised input -- with the [M, F] gate and up tensors never reaching HBM.
+ *   w_gu int8 [2 F, K]: gate and up ROW-INTERLEAVED in blocks of 16 channels (rows 32 j .. 32 j + 15 = gate channels 16 j .. 16 j + 15, rows 32 j + 16 .. 32 j + 31 =
+ *   the same channels of up); out [M, F] in out_dtype (ASQ_F16 / ASQ_BF16) = dt(dt(silu(y_g)) * y_u) with y = dt(s [* s_row[m]] * acc): bit-identical to
+ *   asq_linear_w8a8 (gate), asq_linear_w8a8 (up) and the SiLU * up of asq_silu_mul_quantize with the same ASQ_SILU_FAST flag.  s_row: per-token activation scales or NULL.
+ *   row_off / col_off: both NULL (plain operands) or the activation's row vector and asq_weight_offset_image(w_gu)'s column vector (offset operand images).
+ * Runs on the persistent 256 x 256 kernel only: asq_gate_up_supported(M, F, K, out_dtype) = M % 256 == 0, F % 128 == 0, K % 256 == 0, K <= 65536, more than 256
+ * tiles of 256 x 256 over [M, 2 F]; other shapes return ASQ_ERR_DIM (callers run the two linears + asq_silu_mul_quantize).  ASQ_GATE_UP=0 makes the query return 0. */
+int asq_gate_up_supported(int64_t M, int64_t F, int64_t K, int out_dtype);
+int asq_linear_w8a8_gate_up(const int8_t *xq, const int8_t *w_gu, void *out, int out_dtype, int64_t M, int64_t F, int64_t K,
+                            float s_gate, float s_up, const float *s_row, int flags, const int32_t *row_off, const int32_t *col_off, void *stream);
 int asq_silu_mul_quantize_off(const void *gate, const void *up, int x_dtype, int per_token, float quant_scale,
                               int8_t *xq_off, float *s_row, int32_t *row_off, int64_t M, int64_t K, void *stream);
 int asq_linear_w8a8_forward_off(const void *x, int x_dtype, const int8_t *w, const int8_t *w_off, const int32_t *col_off, void *out,

@@ -144,6 +144,17 @@ def silu_mul_quant_kernel_order(gate, up, dt: str, per_token: bool = True, quant
     return O.act_quant_div(a, dt, quant_scale), None
 
 
+def gate_up_silu_kernel_order(xq, w_gate, w_up, dt: str, s_gate: float, s_up: float, s_row=None) -> np.ndarray:
+    """asq_linear_w8a8_gate_up with the fixed-operation-order SiLU (flags = 0): the two projections' dequantised outputs in `dt` -- exactly the epilogue of
+    W8A8BFP32OFP32Linear (oracle/w8a8.py::dequant_epilogue, reference layers/nn/linear.py:93-104) -- then a = dt(dt(g / (1 + exp_det(-g))) * u)
+    (silu_mul_quant_kernel_order above; reference models/llama.py:206-211 computes the same expression with torch's silu)."""
+    g = O.dequant_epilogue(O.igemm(xq, w_gate), F32(s_gate), s_row, None, dt)
+    u = O.dequant_epilogue(O.igemm(xq, w_up), F32(s_up), s_row, None, dt)
+    with np.errstate(over="ignore", invalid="ignore"):
+        sl = O.round_to((g / (F32(1.0) + exp_det(-g)).astype(F32)).astype(F32), dt)
+        return O.round_to((sl * u).astype(F32), dt)
+
+
 def linear_q8_forward(xq, wq, dt: str, s_scalar: float, s_row=None, s_col=None, bias=None, act: Optional[str] = None,
                       qmode: str = "per-tensor-round", quant_scale: float = 1.0) -> np.ndarray:
     """asq_linear_w8a8_q8: the linear's output in dt (oracle.w8a8.dequant_epilogue, layers/nn/linear.py:104-105), an optional ReLU
