@@ -171,7 +171,7 @@ class LlamaLayer(torch.nn.Module):
         alt = getattr(self, "use_fused", False)
         norm = self.post_attention_layernorm_q if alt else self.post_attention_layernorm
         readers = (self.gate_proj, self.up_proj)
-        gu = getattr(self, "gate_up", None) if (alt and getattr(self, "fuse_gate_up", True)) else None
+        gu = getattr(self, "gate_up", None) if ((alt or getattr(self, "fuse_act", False)) and getattr(self, "fuse_gate_up", True)) else None
         if gu is not None:
             hb = h.base if isinstance(h, DeferredResidual) else h
             if gu.supported(hb.numel() // hb.shape[-1], hb.dtype):
@@ -292,6 +292,8 @@ def to_w8a8(layer, scales, quant_config=None, fuse_norm=False, fuse_qkv=False, b
         q.input_layernorm = RMSNormQ.from_float(layer.input_layernorm, scales["attn_in"], per_token=cfg["qkv"] == "per-token")
         q.post_attention_layernorm = RMSNormQ.from_float(layer.post_attention_layernorm, scales["mlp_in"], per_token=cfg["fc1"] == "per-token")
         q.fuse_act = True
+        from .layers.nn.fused import GateUpSiLU
+        q.gate_up = GateUpSiLU(q.gate_proj, q.up_proj)   # (round 5) gate || up as one GEMM with the SiLU * up epilogue, where the shape runs on it
         return q
     q.input_layernorm = layer.input_layernorm.folded(scales["attn_in"]) if cfg["qkv"] == "per-tensor" else layer.input_layernorm
     q.post_attention_layernorm = layer.post_attention_layernorm.folded(scales["mlp_in"]) if cfg["fc1"] == "per-tensor" else layer.post_attention_layernorm
