@@ -43,7 +43,7 @@ SIGNATURES = {
     "asq_quantize_act_off": (_int, [_vp, _int, _int, _f32, _vp, _vp, _vp, _i64, _i64, _vp]),
     "asq_linear_w8a8_off": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
     "asq_offsets_supported": (_int, [_i64, _i64, _i64, _int]),
-    "asq_forward_fused_supported": (_int, [_i64, _i64, _i64, _int]),
+    "asq_forward_fused_supported": (_int, [_i64, _i64, _i64, _int, _int]),
     "asq_gate_up_supported": (_int, [_i64, _i64, _i64, _int]),
     "asq_linear_w8a8_gate_up": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _f32, _f32, _vp, _int, _vp, _vp, _vp]),
     "asq_linear_w8a8_forward_fused": (_int, [_vp, _int, _vp, _vp, _i64, _i64, _i64, _int, _f32, _f32, _vp, _vp, _vp]),

@@ -14,18 +14,19 @@ static bool fused_enabled()
     return on;
 }
 
-static bool fused_shape(const void *x, const void *w, int64_t M, int64_t N, int64_t K, int x_dtype)
+static bool fused_shape(const void *x, const void *w, int64_t M, int64_t N, int64_t K, int x_dtype, int act_mode)
 {
     if (!fused_enabled() || forced_kernel() >= 0) return false;
-    if (!skfq_supported(x, w, M, N, K, x_dtype)) return false;
+    if (!skfq_supported(x, w, M, N, K, x_dtype, act_mode)) return false;
     // only where the dispatcher streams the weight anyway (gemm_i8_skinny's region, outside the stream-K kernel's: those are long-K shapes whose X image would not fit)
     return pick_kernel(x, w, M, N, K) == KERN_SKINNY && plan_wstream(M, N, K).G == 0;
 }
 
-extern "C" int asq_forward_fused_supported(int64_t M, int64_t N, int64_t K, int x_dtype)
+extern "C" int asq_forward_fused_supported(int64_t M, int64_t N, int64_t K, int x_dtype, int act_mode)
 {
     if (!(x_dtype == ASQ_F32 || x_dtype == ASQ_F16 || x_dtype == ASQ_BF16)) return 0;
-    return fused_shape(nullptr, nullptr, M, N, K, x_dtype) ? 1 : 0;
+    if (!(act_mode == ASQ_ACT_ROUND || act_mode == ASQ_ACT_DIV || act_mode == ASQ_ACT_PER_TOKEN)) return 0;
+    return fused_shape(nullptr, nullptr, M, N, K, x_dtype, act_mode) ? 1 : 0;
 }
 
 static int fused_launch(const void *x, int x_dtype, const int8_t *w, void *out, int64_t M, int64_t N, int64_t K, int act_mode, float quant_scale, float s_scalar,
@@ -36,7 +37,7 @@ int asq_try_fused_forward(const void *x, int x_dtype, const int8_t *w, void *out
                           const float *s_col, const float *bias, void *stream, int *launched)
 {
     *launched = 0;
-    if (!fused_shape(x, w, M, N, K, x_dtype)) return ASQ_OK;
+    if (!fused_shape(x, w, M, N, K, x_dtype, act_mode)) return ASQ_OK;
     return fused_launch(x, x_dtype, w, out, M, N, K, act_mode, quant_scale, s_scalar, s_col, bias, stream, launched);
 }
 

@@ -22,10 +22,11 @@ namespace asq {
 
 constexpr int SKFQ_STAGES = 3;       // gemm_i8_skinny's depth.  Measured (profiles/r5_fused_forward_sweep.txt): a 6-stage ring is no faster at one channel tile per block
                                      // (4 x 4096 x 4096: 8.9 vs 9.4 us) and slower as soon as a block walks several tiles (8 x 11008 x 4096: 29.4 vs 20.4 us)
-constexpr int SKFQ_MAX_ROWS = 4;     // Rows the fused launch takes by default.  Measured against quantiser + GEMM on the device (same file): <= 4 rows win everywhere up to ~700
+constexpr int SKFQ_MAX_ROWS = 4;     // Rows the fused launch takes by default IN EVERY MODE (5 .. 16 rows: skfq_supported's second rule).  Measured against quantiser + GEMM on the device (same file): <= 4 rows win everywhere up to ~700
                                      // channel tiles (4 x 4096 x 4096 8.9 vs 9.6 us, 4 x 11008 x 4096 14.0 vs 14.6, 2 x 4096 x 11008 12.7 vs 14.2) and save one launch of host time
                                      // (module call 10.3 vs 13.2 us); 8 and 16 rows LOSE (8 x 4096 x 4096 10.8 vs 10.3, 8 x 11008 x 4096 20.4 vs 15.3, 16 x 4096 x 4096 13.7 vs 10.2):
                                      // every block repeats the quantiser's work.  ASQ_FQ_MAXROWS (1..16) overrides it for A/B runs.
+constexpr int SKFQ_ONE_TILE_BLOCKS = 256;   // channel tiles of 16 that get a block each (one per CU) at 5 .. 16 rows
 constexpr int SKFQ_MAX_TILES = 1024; // ... and 4 x 32000 x 4096 (1000 tiles of 32 channels) loses too (31.7 vs 25.8 us): beyond this many 16-channel tiles the two-launch forward stays
 constexpr int SKFQ_XIMG_MAX = 64 * 1024;   // resident int8 X image (MR rows x K): leaves >= 96 KB for the W rings of 1-2 blocks per CU
 
@@ -346,10 +347,15 @@ static inline bool skfq_kernel_ok(const void *x, const void *w, int64_t M, int64
     return (int64_t)skfq_rows(M) * K <= SKFQ_XIMG_MAX;
 }
 // ... and what asq_linear_w8a8_forward hands to it by itself (where it was measured to win)
-static inline bool skfq_supported(const void *x, const void *w, int64_t M, int64_t N, int64_t K, int x_dtype)
+static inline bool skfq_supported(const void *x, const void *w, int64_t M, int64_t N, int64_t K, int x_dtype, int act_mode)
 {
     static const int max_rows = [] { const char *e = getenv("ASQ_FQ_MAXROWS"); const int v = e ? atoi(e) : SKFQ_MAX_ROWS; return v < 1 ? 1 : v > 16 ? 16 : v; }();
-    return skfq_kernel_ok(x, w, M, N, K) && M <= max_rows && (N + 15) / 16 <= SKFQ_MAX_TILES;
+    if (!skfq_kernel_ok(x, w, M, N, K)) return false;
+    if (M <= max_rows) return (N + 15) / 16 <= SKFQ_MAX_TILES;
+    // 5 .. 16 rows: only the per-tensor modes (no row-maximum pass in the prologue) at ONE channel tile per block -- there the module call, which is host-bound at
+    // these sizes, gains a launch (8 x 4096 x 4096 10.6 vs 12.7 us, 16 rows 13.3 vs 14.0-16.9) while the device period is within 0.5 us; per-token rows
+    // (13.8 vs 12.9) and several tiles per block (8 x 11008 x 4096 16.5 vs 14.4) lose: profiles/r5_fused_forward_module_call.txt
+    return max_rows >= 4 && act_mode != ASQ_ACT_PER_TOKEN && (N + 15) / 16 <= SKFQ_ONE_TILE_BLOCKS;
 }
 
 template <int DT, int NT, int STG>

@@ -207,9 +207,9 @@ def offsets_supported(M, N, K, out_dtype):
     return out_dtype in _DT and bool(L.lib().asq_offsets_supported(M, N, K, _DT[out_dtype]))
 
 
-def forward_is_fused(M, N, K, dtype):
-    """True when linear_w8a8_forward runs this shape as ONE launch (activation quantiser = the GEMM's prologue; asq_forward_fused_supported)."""
-    return dtype in _DT and bool(L.lib().asq_forward_fused_supported(int(M), int(N), int(K), _DT[dtype]))
+def forward_is_fused(M, N, K, dtype, mode="per-tensor-round"):
+    """True when linear_w8a8_forward runs this shape / quantiser mode as ONE launch (activation quantiser = the GEMM's prologue; asq_forward_fused_supported)."""
+    return dtype in _DT and bool(L.lib().asq_forward_fused_supported(int(M), int(N), int(K), _DT[dtype], _ACT[mode]))
 
 
 def linear_w8a8_forward_fused(x2d, w, act_mode, quant_scale, s_scalar, s_col=None, bias=None):

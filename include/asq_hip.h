@@ -240,15 +240,16 @@ int asq_linear_w8a8_off(const int8_t *xq_off, const int8_t *w_off, void *out, in
                         float s_scalar, const float *s_row, const float *s_col, const float *bias, int epi_order,
                         const int32_t *row_off, const int32_t *col_off, void *stream);
 int asq_offsets_supported(int64_t M, int64_t N, int64_t K, int out_dtype);
-/* 1 when asq_linear_w8a8_forward runs (M, N, K) with x_dtype activations as ONE launch -- the activation quantiser (reference layers/nn/linear.py:88-96,
- * :283-292) as the GEMM's prologue, the dequant / bias (linear.py:93-104) as its epilogue: <= 4 rows (more rows lose to the two launches -- every block repeats the
- * quantiser's work; measured: profiles/r5_fused_forward_sweep.txt) on the dispatcher's weight-streaming shapes with <= 1024 tiles of 16 channels whose int8 activation
- * image (4 rows x K bytes) fits in 64 KiB of LDS, K % 128 == 0, 16-byte aligned x and w (assumed here; checked per call).  Bit-identical
- * to asq_quantize_act + asq_linear_w8a8.  ASQ_FUSED_FORWARD=0 in the environment switches it off (A/B). */
-int asq_forward_fused_supported(int64_t M, int64_t N, int64_t K, int x_dtype);
+/* 1 when asq_linear_w8a8_forward runs (M, N, K) with x_dtype activations and quantiser mode act_mode as ONE launch -- the activation quantiser (reference
+ * layers/nn/linear.py:88-96, :283-292) as the GEMM's prologue, the dequant / bias (linear.py:93-104) as its epilogue -- on the dispatcher's weight-streaming shapes
+ * whose int8 activation image (4 / 8 / 16 rows x K bytes) fits in 64 KiB of LDS, K % 128 == 0, 16-byte aligned x and w (assumed here; checked per call):
+ *   <= 4 rows: every mode, up to 1024 tiles of 16 channels;   5 .. 16 rows: the per-tensor modes at <= 256 tiles (N <= 4096).
+ * Elsewhere the two launches are faster (every block repeats the quantiser's work; measured: profiles/r5_fused_forward_*.txt).  Bit-identical to asq_quantize_act +
+ * asq_linear_w8a8.  ASQ_FUSED_FORWARD=0 in the environment switches it off (A/B). */
+int asq_forward_fused_supported(int64_t M, int64_t N, int64_t K, int x_dtype, int act_mode);
 /* The one-launch forward on request, for any shape its kernel can run: 1 <= M <= 16, K % 128 == 0, rows(M) x K <= 65536 (rows = 4 / 8 / 16: the resident int8
  * activation image), N x K < 2^32, 16-byte aligned x and w; no workspace.  asq_linear_w8a8_forward takes it by itself only where it was measured to win
- * (<= 4 rows, <= 1024 tiles of 16 channels: asq_forward_fused_supported); this entry point exists for callers that prefer one launch regardless (hipGraph
+ * (asq_forward_fused_supported); this entry point exists for callers that prefer one launch regardless (hipGraph
  * node count, stream ordering) and for the parity tests.  Same arguments and results as asq_linear_w8a8_forward.  ASQ_ERR_DIM outside the limits above. */
 int asq_linear_w8a8_forward_fused(const void *x, int x_dtype, const int8_t *w, void *out, int64_t M, int64_t N, int64_t K,
                                   int act_mode, float quant_scale, float s_scalar, const float *s_col, const float *bias, void *stream);

@@ -28,7 +28,8 @@ def test_fused_equals_two_launches_and_the_oracle(dt, mode):
     rng = np.random.default_rng(7)
     for (M, N, K) in ((1, 4096, 4096), (4, 4096, 4096), (3, 256, 512), (5, 11008, 4096), (8, 4096, 4096), (9, 1000, 1024), (16, 4096, 4096), (16, 12288, 4096),
                       (4, 4096, 11008), (2, 5120, 13824), (13, 100, 256), (7, 20, 128), (4, 36, 2048)):
-        assert ops.forward_is_fused(M, N, K, TDT[dt]) == (M <= 4), (M, N, K)   # (the default forward fuses <= 4 rows; the explicit entry point below runs every case)
+        takes = M <= 4 or (mode != "per-token" and (N + 15) // 16 <= 256)   # what the default forward fuses by itself; the explicit entry point below runs every case
+        assert ops.forward_is_fused(M, N, K, TDT[dt], mode) == takes, (M, N, K, mode)
         w = rng.integers(-128, 128, (N, K), dtype=np.int8)
         wt = torch.from_numpy(w).to(DEV)
         x, xt = _x(1000 + M + N, M, K, dt, scale=2.5 if mode == "per-tensor-round" else 30.0)
@@ -42,7 +43,7 @@ def test_fused_equals_two_launches_and_the_oracle(dt, mode):
             bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(DEV) if has_bias else None
             ds = 1.0 if has_col else 1.37e-4
             got = ops.linear_w8a8_forward_fused(xt, wt, mode, qs, ds, s_col, bias)
-            if M <= 4:
+            if takes:
                 assert torch.equal(got.view(torch.uint8), ops.linear_w8a8_forward(xt, wt, mode, qs, ds, s_col, bias).view(torch.uint8))
             xq, s_row = ops.quantize_act(xt, mode, qs)
             want = ops.linear_w8a8(xq, wt, TDT[dt], ds, s_row, s_col, bias)
@@ -90,7 +91,10 @@ def test_which_shapes_fuse():
     f16 = torch.float16
     assert ops.forward_is_fused(4, 4096, 4096, torch.float32) and ops.forward_is_fused(4, 11008, 4096, f16) and ops.forward_is_fused(1, 16384, 4096, f16)
     assert ops.forward_is_fused(2, 4096, 11008, f16)
-    assert not ops.forward_is_fused(5, 4096, 4096, f16)          # more rows: every block repeats the quantiser's work -- measured slower than two launches
+    assert ops.forward_is_fused(8, 4096, 4096, f16) and ops.forward_is_fused(16, 4096, 4096, f16, "per-tensor-div")   # 5 .. 16 rows: per-tensor modes, one tile per block
+    assert not ops.forward_is_fused(8, 4096, 4096, f16, "per-token")   # ... a row-maximum pass in every block loses
+    assert not ops.forward_is_fused(8, 11008, 4096, f16)         # ... and so do several channel tiles per block
+    assert not ops.forward_is_fused(17, 4096, 4096, f16)
     assert not ops.forward_is_fused(4, 32000, 4096, f16)         # more than 1024 channel tiles: measured slower
     assert not ops.forward_is_fused(4, 4096, 4000, f16)          # K % 128
     assert not ops.forward_is_fused(4, 5120, 20480, f16)         # 4 x 20480 B does not fit the resident image

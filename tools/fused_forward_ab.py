@@ -5,8 +5,10 @@ import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CASES = [(4, 4096, 4096, "f32", "per-tensor", "linear"), (4, 4096, 4096, "f16", "per-tensor", "linear"), (1, 4096, 4096, "f16", "per-token", "quantscale"),
-         (16, 4096, 4096, "f16", "per-token", "quantscale"), (16, 4096, 4096, "f16", "per-tensor", "linear"), (8, 11008, 4096, "f16", "per-tensor", "linear"),
-         (16, 11008, 4096, "f16", "per-tensor", "linear"), (4, 4096, 11008, "f16", "per-token", "quantscale"), (4, 5120, 20480, "f16", "per-token", "quantscale"),
+         (8, 4096, 4096, "f16", "per-tensor", "linear"), (8, 4096, 4096, "f16", "per-token", "quantscale"), (8, 11008, 4096, "f16", "per-tensor", "linear"),
+         (8, 4096, 11008, "f16", "per-token", "quantscale"),
+         (16, 4096, 4096, "f16", "per-token", "quantscale"), (16, 4096, 4096, "f16", "per-tensor", "linear"),
+         (16, 11008, 4096, "f16", "per-tensor", "linear"), (4, 4096, 11008, "f16", "per-token", "quantscale"), (4, 11008, 4096, "f16", "per-tensor", "linear"),
          (32, 4096, 4096, "f16", "per-tensor", "linear")]
 
 
@@ -47,7 +49,7 @@ def child():
             m(x)
         b.record()
         b.synchronize()
-        res.append({"shape": [M, N, K], "dtype": dt, "act_quant": aq, "fused": bool(ops.forward_is_fused(M, N, K, tdt[dt])), "eager_us": round(eager, 2),
+        res.append({"shape": [M, N, K], "dtype": dt, "act_quant": aq, "fused": bool(ops.forward_is_fused(M, N, K, tdt[dt], "per-token" if aq == "per-token" else "per-tensor-round")), "eager_us": round(eager, 2),
                     "event_us": round(a.elapsed_time(b) / 200 * 1e3, 2)})
     print(json.dumps(res))
 
