@@ -71,6 +71,12 @@ def lib():
                     raise RuntimeError(
                         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "or `make -C autosmoothquant_amd/csrc`.  autosmoothquant_amd has no CPU/eager fallback.")
+                # torch first: its wheel ships its own libamdhip64.so (soname libamdhip64.so.7, requested by libtorch_hip as "libamdhip64.so"),
+                # libasq_hip.so asks for "libamdhip64.so.7".  Loaded after torch, this library binds to the runtime already in the process; loaded
+                # BEFORE torch it would pull /opt/rocm's copy and torch a second one -- two HIP runtimes, and the one that initialises second finds
+                # no device (hipError 100; seen with `python __graft_entry__.py smoke`, where build() used to load the library before smoke()
+                # imported torch).  The host side above the C-ABI is torch plumbing anyway (ops.py).
+                import torch  # noqa: F401
                 h = ctypes.CDLL(LIB_PATH)
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(h, name)  # AttributeError if the .so lacks a declared symbol
