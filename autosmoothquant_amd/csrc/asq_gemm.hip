@@ -69,6 +69,12 @@ extern "C" size_t asq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K)
                       : kern == KERN_P8H ? pick_ksplit_p8h(((M + 127) / 128) * ((N + 255) / 256), K, M, N, (size_t)-1)
                                          : pick_ksplit_p8q(((M + 127) / 128) * ((N + 127) / 128), K, M, N, (size_t)-1);
         scratch = s > 1 ? (size_t)s * (size_t)M * (size_t)N * 4 : 0;
+        if (kern == KERN_P8Q) {   // the in-launch reduction of gemm_i8_p8q2<Epi, true> keeps one 64 KiB register image per (tile, split): whole tiles, and its own split count
+            const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+            const int sf = tiles <= WS_MAX_GROUPS ? pick_ksplit_p8q(tiles, K, M, N, (size_t)-1, true) : 1;
+            const size_t fb = sf > 1 ? p8q_fix_bytes(tiles, sf) : 0;
+            scratch = fb > scratch ? fb : scratch;
+        }
     }
     return scratch ? scratch + WS_HEADER_BYTES : 0;
 }
@@ -79,6 +85,10 @@ extern "C" int asq_workspace_init(void *workspace, size_t workspace_bytes, void 
     ASQ_REQUIRE(workspace_bytes >= (size_t)WS_HEADER_BYTES, ASQ_ERR_WORKSPACE, "asq_workspace_init: workspace %zu B < header %d B (asq_workspace_header_bytes)", workspace_bytes, WS_HEADER_BYTES);
     ASQ_REQUIRE((((uintptr_t)workspace) & 255) == 0, ASQ_ERR_ALIGN, "asq_workspace_init: workspace must be 256-B aligned");
     hipLaunchKernelGGL(ws_init_header, dim3(1), dim3(256), 0, (hipStream_t)stream, (unsigned *)workspace);
+    // placement probe (WS_XCC_TABLE_OFF): which XCD do blocks b = 0 .. 63 of a launch land on?  Three tiny launches once per workspace, no host round trip:
+    // the kernels that care read the verdict from the header.
+    hipLaunchKernelGGL(ws_probe_xcc, dim3(64), dim3(64), 0, (hipStream_t)stream, (unsigned *)workspace);
+    hipLaunchKernelGGL(ws_probe_eval, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned *)workspace);
     return asq_after_launch((hipStream_t)stream, "asq_workspace_init");
 }
 

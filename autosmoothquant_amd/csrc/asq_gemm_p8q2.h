@@ -27,9 +27,29 @@ namespace asq {
 // 256 cycles of the partner's 16 MFMAs (the 128 x 128 tile moves twice p16's DMA bytes per MFMA: 32 one-KiB pieces per 512 cycles of matrix work per CU).  Two variants
 // changed nothing: warm instead of cold weights (15.3 vs 15.0: not the prefetch lead), and group A waiting for tile t+2 at the end of its compute segment
 // (half a K-tile more lead: 15.3 vs 15.0).
-template <class Epi>
+//
+// FIX = true (round 5, "XCD-affine split-K"): the K splits of a tile are reduced INSIDE the launch, and all of them run on ONE XCD.  Round 4 had built
+// the in-launch reduction with write-through images + an agent-scope ticket + sc1 reads and dropped it (no gain over slab launch + reduce launch,
+// profiles/r4_splitk_in_launch_dropped.txt): a whole chip of blocks ending together pushes S x tiles x 64 KiB of write-through stores through the fabric at
+// once.  Here blockIdx b = 8 * slot + xcd takes item `slot` of XCD xcd's own share of the tiles (splits of a tile are consecutive slots), so a tile's
+// contributors share an L2 (MI355X deals workgroups to its 8 XCDs round-robin; `fix_local` is only set when the workspace header's placement probe --
+// asq_workspace_init -- confirmed that on this device, and every block checks its own XCC_ID against the probe's table and traps on a mismatch: loud,
+// never wrong):
+//   * the 64 KiB register image is stored with PLAIN stores (dirty lines in the XCD's L2, tools/ubench/xcd_local: drain 0.6 us instead of 1.2-1.4),
+//   * the tile's ticket is a workgroup-scope atomic: performed in that L2,
+//   * the last arriver reads the other images with sc1 loads (TCP bypass), L2 hits: 0.36 us per image instead of 0.6,
+//   * and runs the caller's epilogue: no reduce launch, no slab round trip through HBM.
+// fix_local == 0 (placement not confirmed): write-through images, agent-scope ticket, sc1 reads -- correct on any placement.
+__device__ __forceinline__ unsigned p8q2_xcc_id()
+{
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xF;
+}
+
+template <class Epi, bool FIX = false>
 __global__ void __launch_bounds__(512, 2) gemm_i8_p8q2(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
-                                                       int tiles_m, int tiles_n, int ksplit, Epi epi_in)
+                                                       int tiles_m, int tiles_n, int ksplit, Epi epi_in, char *__restrict__ gws, int fix_local)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     static_assert(Epi::Mma::kIsInt, "int8 operands");
@@ -41,8 +61,23 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8q2(const int8_t *__restrict_
 
     constexpr int GM = 8;
     const int nwg = tiles_m * tiles_n;
-    const int lid = xcd_remap(blockIdx.x, nwg * ksplit);
-    const int split = lid / nwg, id = lid - split * nwg;
+    int split, id;
+    [[maybe_unused]] unsigned long long ws_magic = 0;
+    if constexpr (FIX) {
+        // XCD xcd owns tiles [base, base + cnt) (xcd_remap's shares); its blocks take (tile, split) = (base + slot / ksplit, slot % ksplit)
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int cnt = q + (xcd < r ? 1 : 0), base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        if (slot >= cnt * ksplit) return;   // (block-uniform; the grid is 8 x the largest share)
+        id = base + slot / ksplit;
+        split = slot - (slot / ksplit) * ksplit;
+        ws_magic = *(const volatile unsigned long long *)gws;   // checked at the ticket
+        fix_local = fix_local && ((const volatile unsigned *)(gws + WS_XCC_TABLE_OFF))[8] == 1u;   // (block-uniform: the probe's verdict for this workspace's device)
+    } else {
+        const int lid = xcd_remap(blockIdx.x, nwg * ksplit);
+        split = lid / nwg;
+        id = lid - split * nwg;
+    }
     const Epi epi = epi_in.rebased(0, split, M, N);
     const int per_group = GM * tiles_n;
     const int group = id / per_group, in_group = id - group * per_group;
@@ -155,6 +190,52 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8q2(const int8_t *__restrict_
     P8_WAIT_VM(0);    // drain the dead prefetches
     P8_WAIT_LGKM0();  // ... and the fragment reads past the last tile, before LDS becomes staging space
     if (grp == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier
+
+    if constexpr (FIX) if (ksplit > 1) {   // block-uniform: in-launch reduction of the tile's K splits (see the top of the kernel)
+        typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(gws + WS_HEADER_BYTES, 0, 0x7FFFFFFF, 0x00020000);
+        constexpr int PART = 128 * 128 * 4;   // one register image: 8 x (512 lanes x 16 B)
+        const int my = (id * ksplit + split) * PART + tid * 16;
+        // (offset in the VGPR, soffset 0 and a wait state after the stores: see the note on buffer stores in asq_gemm_wstream.h)
+        if (fix_local) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, acc16[i >> 2][i & 3]), rsrc, my + i * 8192, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, acc16[i >> 2][i & 3]), rsrc, my + i * 8192, 0, 16 /* sc1: write-through */);
+        }
+        asm volatile("s_nop 1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's image has been acknowledged before the block takes its ticket
+        unsigned *const flag = (unsigned *)lds;  // (the ring is dead)
+        if (tid == 0) {
+            unsigned *const tk = (unsigned *)gws + 4 + id;
+            if (ws_magic != WS_MAGIC) __builtin_trap();   // workspace never went through asq_workspace_init
+            unsigned old;
+            if (fix_local) {
+                if (p8q2_xcc_id() != ((const volatile unsigned *)(gws + WS_XCC_TABLE_OFF))[blockIdx.x & 7]) __builtin_trap();   // placement changed under us: the images would sit in different L2s
+                old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // performed in the XCD's L2
+                if (old == (unsigned)ksplit - 1) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == (unsigned)ksplit - 1) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next launch / replay
+            }
+            if (old >= (unsigned)ksplit) __builtin_trap();  // poisoned tickets: header not initialised / workspace shared by concurrent launches
+            *flag = old == (unsigned)ksplit - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool last = *flag != 0;
+        __syncthreads();  // (the staged epilogue reuses this LDS)
+        if (!last) return;
+        for (int sp = 0; sp < ksplit; ++sp) {
+            if (sp == split) continue;
+            const int src = (id * ksplit + sp) * PART + tid * 16;
+            v4u_ v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, src + i * 8192, 0, 16 /* sc1: past the TCP; an L2 hit on the local path */);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc16[i >> 2][i & 3] += __builtin_bit_cast(v4i, v[i]);
+        }
+    }
 
     // accumulator tile (in16 = 16-channel tile 0..3, im16 = 16-token tile 0..1) -> rows m0 + wm*32 + 16*im16, cols n0 + wn*64 + 16*in16
     auto get16 = [&](int in16, int im16) -> const v4i & { return acc16[im16][in16]; };
