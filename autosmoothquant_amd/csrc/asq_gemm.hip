@@ -85,10 +85,6 @@ extern "C" int asq_workspace_init(void *workspace, size_t workspace_bytes, void 
     ASQ_REQUIRE(workspace_bytes >= (size_t)WS_HEADER_BYTES, ASQ_ERR_WORKSPACE, "asq_workspace_init: workspace %zu B < header %d B (asq_workspace_header_bytes)", workspace_bytes, WS_HEADER_BYTES);
     ASQ_REQUIRE((((uintptr_t)workspace) & 255) == 0, ASQ_ERR_ALIGN, "asq_workspace_init: workspace must be 256-B aligned");
     hipLaunchKernelGGL(ws_init_header, dim3(1), dim3(256), 0, (hipStream_t)stream, (unsigned *)workspace);
-    // placement probe (WS_XCC_TABLE_OFF): which XCD do blocks b = 0 .. 63 of a launch land on?  Three tiny launches once per workspace, no host round trip:
-    // the kernels that care read the verdict from the header.
-    hipLaunchKernelGGL(ws_probe_xcc, dim3(64), dim3(64), 0, (hipStream_t)stream, (unsigned *)workspace);
-    hipLaunchKernelGGL(ws_probe_eval, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned *)workspace);
     return asq_after_launch((hipStream_t)stream, "asq_workspace_init");
 }
 

@@ -1004,10 +1004,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 // workspace header (asq_workspace_init): magic word + arrival tickets of the in-launch reductions (asq_gemm_wstream.h; grouped tail split of asq_gemm_p8.h)
 constexpr int WS_HEADER_BYTES = 8192;
 constexpr unsigned long long WS_MAGIC = 0x4153515753763031ull;  // "ASQWSv01"
-// The last 512 bytes of the header hold the PLACEMENT PROBE asq_workspace_init runs once (ws_probe_xcc / ws_probe_eval, asq_gemm_wstream.h): the hardware XCC_ID of 64
-// probe blocks, the table id[b & 7] and a flag "block b of a launch runs on XCD id[b & 7]" -- what gemm_i8_p8q2<Epi, true> needs to keep a tile's K splits in one L2.
-constexpr int WS_XCC_TABLE_OFF = WS_HEADER_BYTES - 512;    // u32 [0..7]: XCC_ID of blocks b = 0..7; [8]: 1 = the round-robin placement was observed; [16..79]: raw probe
-constexpr int WS_MAX_GROUPS = (WS_HEADER_BYTES - 16 - 512) / 4;
+constexpr int WS_MAX_GROUPS = (WS_HEADER_BYTES - 16) / 4;
 
 // OFFSET operands (asq_linear_w8a8_off; include/asq_hip.h "offset operand images").  Under the socket power limit the 256 x 256 GEMM's time is its
 // energy, and most of the matrix cores' data-dependent energy is two's-complement sign extension (profiles/r2_clock_power_evidence.md section 3,
@@ -1181,12 +1178,11 @@ static inline int pick_ksplit(int64_t tiles, int64_t K, int64_t M, int64_t N, si
     return s < 1 ? 1 : (int)s;
 }
 
-constexpr double P8Q_FIX_TAIL_US = 2.0, P8Q_FIX_PER_SPLIT_US = 0.4;   // in-launch tail of a split tile (first guess; tools/midsize_sweep.py)
+constexpr double P8Q_FIX_TAIL_US = 4.4, P8Q_FIX_PER_SPLIT_US = 0.5;   // in-launch tail of a tile split in two; per further split (fitted: profiles/r5_splitk_fix_sweep*.txt)
 // K splits for the 128 x 128 kernel, from a small cost model fitted to measurements (us): a block costs 3 + (K-tiles) x (0.40 + 0.20 x the
 // fraction of the 256 CUs that hold a block -- the L2->LDS path is shared), a split launch adds the reduce pass, 5 + S x M x N x 4 B at
 // 3 TB/s.  512x4096x4096: S = 1 (18.0 us measured; S = 2: 21.3); 512x4096x11008: S = 2 (37.3; S = 1: 40.1); 128x4096x11008: S = 7 (21.9).
-// ASQ_SPLITK_FIX=0: K splits of the 128 x 128 kernel go back to slab launch + reduce launch (A/B switch); =2: in-launch reduction with the placement-independent
-// protocol only (write-through images, agent-scope ticket).  Default 1: in-launch, XCD-local when the workspace's placement probe allows (asq_gemm_p8q2.h).
+// ASQ_SPLITK_FIX=0: K splits of the 128 x 128 kernel go back to slab launch + reduce launch (A/B switch).  Default 1: reduced inside the launch (asq_gemm_p8q2.h).
 static inline int splitk_fix_mode()
 {
     static const int m = [] {
@@ -1198,8 +1194,8 @@ static inline int splitk_fix_mode()
 // scratch bytes of the in-launch form: one 64 KiB register image per (tile, split)
 static inline size_t p8q_fix_bytes(int64_t tiles, int64_t s) { return (size_t)tiles * (size_t)s * 65536; }
 
-// `fix`: the caller can run the in-launch reduction (gemm_i8_p8q2<Epi, true>): a split then costs its tail (plain image stores into the XCD's L2, one L2 ticket,
-// S - 1 image reads by the last arriver) instead of a second launch and a round trip of the slabs.
+// `fix`: the caller can run the in-launch reduction (gemm_i8_p8q2<Epi, true>): a split then costs its tail (write-through image stores, one ticket, S - 1 image
+// reads by the last arriver) instead of a second launch and a round trip of the slabs.
 static inline int pick_ksplit_p8q(int64_t tiles, int64_t K, int64_t M, int64_t N, size_t ws_bytes, bool fix = false)
 {
     if (N % 4 != 0) return 1;
@@ -1214,8 +1210,9 @@ static inline int pick_ksplit_p8q(int64_t tiles, int64_t K, int64_t M, int64_t N
         for (int64_t c = 1; c <= (smax < 1 ? 1 : smax); ++c) {
             const int64_t nblk = fix ? 8 * ((tiles + 7) / 8) * c : tiles * c;   // (the XCD-affine grid rounds every XCD's share up)
             const double blocks = (double)nblk, waves = (double)((nblk + 255) / 256), fill = blocks < 256.0 ? blocks / 256.0 : 1.0;
-            double t = waves * (3.0 + (double)((nt + c - 1) / c) * (0.40 + 0.20 * fill));
-            if (c > 1) t += fix ? P8Q_FIX_TAIL_US + P8Q_FIX_PER_SPLIT_US * (double)(c - 1) : 5.0 + (double)c * (double)M * (double)N * 4.0 / 3.0e6;
+            double t = fix ? waves * (3.0 + (double)((nt + c - 1) / c) * (0.36 + 0.23 * (fill > 0.5 ? fill - 0.5 : 0.0)))   // (gemm_i8_p8q2's K-tile: flat up to half the chip)
+                           : waves * (3.0 + (double)((nt + c - 1) / c) * (0.40 + 0.20 * fill));
+            if (c > 1) t += fix ? P8Q_FIX_TAIL_US + P8Q_FIX_PER_SPLIT_US * (double)(c - 2) : 5.0 + (double)c * (double)M * (double)N * 4.0 / 3.0e6;
             if (t < best) { best = t; s = c; }
         }
     }
@@ -1595,12 +1592,11 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
         const int ksplit = ws_ok ? pick_ksplit_p8q(tm128 * tn128, K, M, N, ws_bytes, fix) : 1;
         if (ksplit > 1 && fix) {
             if constexpr (kInt && (Epi::kOutBytes == 2 || Epi::kOutBytes == 4))
-                rc = launch_tiled(gemm_i8_p8q2<Epi, true>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, 8 * ((tm128 * tn128 + 7) / 8) * ksplit, 512, (int)tm128, (int)tn128, ksplit, epi, (char *)ws_hdr,
-                                  splitk_fix_mode() == 1 ? 1 : 0);
+                rc = launch_tiled(gemm_i8_p8q2<Epi, true>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, 8 * ((tm128 * tn128 + 7) / 8) * ksplit, 512, (int)tm128, (int)tn128, ksplit, epi, (char *)ws_hdr);
         } else if (ksplit > 1) {
             if constexpr (kInt) {
                 rc = mma32_forced() ? launch_tiled(gemm_i8_p8q<EpiI32>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128 * ksplit, 512, (int)tm128, (int)tn128, ksplit, slab, no_mx, no_mx)
-                     : p8q2_enabled() ? launch_tiled(gemm_i8_p8q2<EpiI32>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128 * ksplit, 512, (int)tm128, (int)tn128, ksplit, slab, (char *)nullptr, 0)
+                     : p8q2_enabled() ? launch_tiled(gemm_i8_p8q2<EpiI32>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128 * ksplit, 512, (int)tm128, (int)tn128, ksplit, slab, (char *)nullptr)
                                       : launch_tiled(gemm_i8_p8q<EpiI32, false, true>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128 * ksplit, 512, (int)tm128, (int)tn128, ksplit, slab, no_mx, no_mx);
                 if (rc == ASQ_OK) reduce_slabs(ksplit);
             }
@@ -1608,7 +1604,7 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
             bool done = false;
             if constexpr (kInt) {
                 if (!mma32_forced()) {
-                    rc = p8q2_enabled() ? launch_tiled(gemm_i8_p8q2<Epi>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128, 512, (int)tm128, (int)tn128, 1, epi, (char *)nullptr, 0)
+                    rc = p8q2_enabled() ? launch_tiled(gemm_i8_p8q2<Epi>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128, 512, (int)tm128, (int)tn128, 1, epi, (char *)nullptr)
                                         : launch_tiled(gemm_i8_p8q<Epi, false, true>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, tm128 * tn128, 512, (int)tm128, (int)tn128, 1, epi, no_mx, no_mx);
                     done = true;
                 }

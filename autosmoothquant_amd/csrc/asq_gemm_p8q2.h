@@ -28,28 +28,18 @@ namespace asq {
 // changed nothing: warm instead of cold weights (15.3 vs 15.0: not the prefetch lead), and group A waiting for tile t+2 at the end of its compute segment
 // (half a K-tile more lead: 15.3 vs 15.0).
 //
-// FIX = true (round 5, "XCD-affine split-K"): the K splits of a tile are reduced INSIDE the launch, and all of them run on ONE XCD.  Round 4 had built
-// the in-launch reduction with write-through images + an agent-scope ticket + sc1 reads and dropped it (no gain over slab launch + reduce launch,
-// profiles/r4_splitk_in_launch_dropped.txt): a whole chip of blocks ending together pushes S x tiles x 64 KiB of write-through stores through the fabric at
-// once.  Here blockIdx b = 8 * slot + xcd takes item `slot` of XCD xcd's own share of the tiles (splits of a tile are consecutive slots), so a tile's
-// contributors share an L2 (MI355X deals workgroups to its 8 XCDs round-robin; `fix_local` is only set when the workspace header's placement probe --
-// asq_workspace_init -- confirmed that on this device, and every block checks its own XCC_ID against the probe's table and traps on a mismatch: loud,
-// never wrong):
-//   * the 64 KiB register image is stored with PLAIN stores (dirty lines in the XCD's L2, tools/ubench/xcd_local: drain 0.6 us instead of 1.2-1.4),
-//   * the tile's ticket is a workgroup-scope atomic: performed in that L2,
-//   * the last arriver reads the other images with sc1 loads (TCP bypass), L2 hits: 0.36 us per image instead of 0.6,
-//   * and runs the caller's epilogue: no reduce launch, no slab round trip through HBM.
-// fix_local == 0 (placement not confirmed): write-through images, agent-scope ticket, sc1 reads -- correct on any placement.
-__device__ __forceinline__ unsigned p8q2_xcc_id()
-{
-    unsigned v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return v & 0xF;
-}
-
+// FIX = true (round 5): the K splits of a tile are reduced INSIDE the launch (round 4's dropped experiment, profiles/r4_splitk_in_launch_dropped.txt, rebuilt on this
+// kernel and kept where it measures ahead): every block stores its 32 accumulator registers per lane as a 64 KiB write-through image, takes the tile's ticket in the
+// workspace header (one agent-scope atomic; tickets return to zero, so a captured graph replays), and the last arriver adds the other images -- the loads of up to
+// three images in flight together -- and runs the CALLER's epilogue: no reduce launch, no int32 slab round trip.  Correct on any placement of the blocks, no block
+// ever waits for another.  blockIdx b = 8 * slot + xcd takes item `slot` of XCD xcd's share of the tiles, (tile, split) = (base + slot / S, slot % S).
+// Measured and NOT kept (profiles/r5_splitk_fix_sweep_v1.txt, r5_xcd_local_probe.txt): an XCD-local protocol -- a tile's splits on one XCD, plain image stores
+// that stay dirty in that L2, a workgroup-scope ticket performed there, L2-hit reads (0.36 us per image instead of 0.6 in tools/ubench/xcd_local) behind a
+// placement probe in the workspace header -- was 3-5 % SLOWER than this form on every shape: the dirty images are written back at the end of the kernel, in
+// front of the next launch, instead of under the other blocks' K loops.
 template <class Epi, bool FIX = false>
 __global__ void __launch_bounds__(512, 2) gemm_i8_p8q2(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
-                                                       int tiles_m, int tiles_n, int ksplit, Epi epi_in, char *__restrict__ gws, int fix_local)
+                                                       int tiles_m, int tiles_n, int ksplit, Epi epi_in, char *__restrict__ gws)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     static_assert(Epi::Mma::kIsInt, "int8 operands");
@@ -72,13 +62,12 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8q2(const int8_t *__restrict_
         id = base + slot / ksplit;
         split = slot - (slot / ksplit) * ksplit;
         ws_magic = *(const volatile unsigned long long *)gws;   // checked at the ticket
-        fix_local = fix_local && ((const volatile unsigned *)(gws + WS_XCC_TABLE_OFF))[8] == 1u;   // (block-uniform: the probe's verdict for this workspace's device)
     } else {
         const int lid = xcd_remap(blockIdx.x, nwg * ksplit);
         split = lid / nwg;
         id = lid - split * nwg;
     }
-    const Epi epi = epi_in.rebased(0, split, M, N);
+    const Epi epi = epi_in.rebased(0, FIX ? 0 : split, M, N);   // (FIX: the last arriver writes the caller's output itself; slabs otherwise)
     const int per_group = GM * tiles_n;
     const int group = id / per_group, in_group = id - group * per_group;
     const int first_m = group * GM;
@@ -197,28 +186,16 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8q2(const int8_t *__restrict_
         constexpr int PART = 128 * 128 * 4;   // one register image: 8 x (512 lanes x 16 B)
         const int my = (id * ksplit + split) * PART + tid * 16;
         // (offset in the VGPR, soffset 0 and a wait state after the stores: see the note on buffer stores in asq_gemm_wstream.h)
-        if (fix_local) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, acc16[i >> 2][i & 3]), rsrc, my + i * 8192, 0, 0);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, acc16[i >> 2][i & 3]), rsrc, my + i * 8192, 0, 16 /* sc1: write-through */);
-        }
+        for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, acc16[i >> 2][i & 3]), rsrc, my + i * 8192, 0, 16 /* sc1: write-through */);
         asm volatile("s_nop 1\n\ts_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave's image has been acknowledged before the block takes its ticket
         unsigned *const flag = (unsigned *)lds;  // (the ring is dead)
         if (tid == 0) {
             unsigned *const tk = (unsigned *)gws + 4 + id;
             if (ws_magic != WS_MAGIC) __builtin_trap();   // workspace never went through asq_workspace_init
-            unsigned old;
-            if (fix_local) {
-                if (p8q2_xcc_id() != ((const volatile unsigned *)(gws + WS_XCC_TABLE_OFF))[blockIdx.x & 7]) __builtin_trap();   // placement changed under us: the images would sit in different L2s
-                old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // performed in the XCD's L2
-                if (old == (unsigned)ksplit - 1) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {
-                old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == (unsigned)ksplit - 1) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next launch / replay
-            }
+            const unsigned old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (unsigned)ksplit - 1) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next launch / replay
             if (old >= (unsigned)ksplit) __builtin_trap();  // poisoned tickets: header not initialised / workspace shared by concurrent launches
             *flag = old == (unsigned)ksplit - 1 ? 1u : 0u;
         }
@@ -226,15 +203,26 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8q2(const int8_t *__restrict_
         const bool last = *flag != 0;
         __syncthreads();  // (the staged epilogue reuses this LDS)
         if (!last) return;
-        for (int sp = 0; sp < ksplit; ++sp) {
-            if (sp == split) continue;
-            const int src = (id * ksplit + sp) * PART + tid * 16;
-            v4u_ v[8];
+        // the other S - 1 images, up to three at a time (24 x 16 B per lane in flight): image j of the sequence 0 .. S - 2 is split j + (j >= split)
+        auto add_images = [&](auto cnt_tag, int j0) {
+            constexpr int CNT = decltype(cnt_tag)::value;
+            v4u_ v[CNT][8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, src + i * 8192, 0, 16 /* sc1: past the TCP; an L2 hit on the local path */);
+            for (int u = 0; u < CNT; ++u) {
+                const int j = j0 + u, sp = j + (j >= split ? 1 : 0);
+                const int src = (id * ksplit + sp) * PART + tid * 16;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc16[i >> 2][i & 3] += __builtin_bit_cast(v4i, v[i]);
-        }
+                for (int i = 0; i < 8; ++i) v[u][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, src + i * 8192, 0, 16 /* sc1 */);
+            }
+#pragma unroll
+            for (int u = 0; u < CNT; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc16[i >> 2][i & 3] += __builtin_bit_cast(v4i, v[u][i]);
+        };
+        int j0 = 0;
+        for (; j0 + 3 <= ksplit - 1; j0 += 3) add_images(std::integral_constant<int, 3>{}, j0);
+        if (ksplit - 1 - j0 == 2) add_images(std::integral_constant<int, 2>{}, j0);
+        else if (ksplit - 1 - j0 == 1) add_images(std::integral_constant<int, 1>{}, j0);
     }
 
     // accumulator tile (in16 = 16-channel tile 0..3, im16 = 16-token tile 0..1) -> rows m0 + wm*32 + 16*im16, cols n0 + wn*64 + 16*in16

@@ -322,28 +322,4 @@ static __global__ void __launch_bounds__(256) ws_init_header(unsigned *hdr)
     for (int i = threadIdx.x; i < WS_HEADER_BYTES / 4; i += 256) hdr[i] = i == 0 ? (unsigned)(WS_MAGIC & 0xFFFFFFFFu) : i == 1 ? (unsigned)(WS_MAGIC >> 32) : 0u;
 }
 
-
-// Placement probe, run once per workspace by asq_workspace_init behind ws_init_header: block b records the hardware id of the XCD it runs on; ws_probe_eval
-// sets the flag when block b sat on the XCD of block b & 7 for all 64 blocks and blocks 0 .. 7 sat on eight different XCDs (MI355X in SPX mode deals the
-// workgroups of a launch to its XCDs round-robin).  gemm_i8_p8q2<Epi, true> relies on the flag to keep a tile's K splits in one L2 and re-checks its own
-// XCC_ID against the table in every block.
-static __global__ void __launch_bounds__(64) ws_probe_xcc(unsigned *hdr)
-{
-    unsigned v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    if (threadIdx.x == 0) hdr[WS_XCC_TABLE_OFF / 4 + 16 + blockIdx.x] = (v & 0xF) + 1;
-}
-static __global__ void __launch_bounds__(64) ws_probe_eval(unsigned *hdr)
-{
-    unsigned *const t = hdr + WS_XCC_TABLE_OFF / 4;
-    const int b = threadIdx.x;
-    const unsigned mine = t[16 + b], ref = t[16 + (b & 7)];
-    bool ok = mine != 0 && mine == ref;
-    if (b < 8)
-        for (int o = 0; o < 8; ++o) ok = ok && (o == b || t[16 + o] != mine);
-    const bool all = __ballot(ok) == ~0ull;
-    if (b < 8) t[b] = mine - 1;
-    if (b == 0) t[8] = all ? 1u : 0u;
-}
-
 }  // namespace asq

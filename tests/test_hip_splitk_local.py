@@ -1,7 +1,7 @@
-"""K splits of the 128 x 128 kernel reduced INSIDE the launch, XCD-affine (gemm_i8_p8q2<Epi, true>, asq_gemm_p8q2.h; round 5): every protocol
-(ASQ_SPLITK_FIX = 1: plain images in the XCD's L2 + an L2 ticket when the workspace's placement probe allows; 2: write-through images + agent-scope
-ticket, any placement; 0: slab launch + reduce launch, the former form) and every split count against the oracle's exact integer GEMM and its epilogues,
-repeated launches on one workspace, a hipGraph replay, tickets back at zero.  The env switches are read once per process, hence the child processes."""
+"""K splits of the 128 x 128 kernel reduced INSIDE the launch (gemm_i8_p8q2<Epi, true>, asq_gemm_p8q2.h; round 5: write-through register images, one
+ticket per tile, the last arriver adds the others and runs the caller's epilogue) and the former form (ASQ_SPLITK_FIX=0: int32 slab launch + reduce launch):
+every split count against the oracle's exact integer GEMM and its epilogues, ragged shapes, repeated launches on one workspace, a hipGraph replay, tickets
+back at zero.  The env switches are read once per process, hence the child processes."""
 import os
 import subprocess
 import sys
@@ -34,7 +34,7 @@ for (M, N, K) in %s:
         out = torch.full((M, N), -7, dtype=torch.int32, device=dev)
         L.check(lib.asq_gemm_i8_i32(xd.data_ptr(), wd.data_ptr(), out.data_ptr(), M, N, K, ws.data_ptr(), n, st), "i32")
         assert np.array_equal(out.cpu().numpy(), acc), ("i32", M, N, K, rep)
-    assert int(ws[16:hdr - 512].view(torch.int32).abs().max()) == 0, "tickets not back at zero"
+    assert int(ws[16:hdr].view(torch.int32).abs().max()) == 0, "tickets not back at zero"
     bias = detrng.normal(262, N, (N,)).astype(np.float32)
     s_row = (np.abs(detrng.normal(263, M, (M,))) * 0.01 + 1e-3).astype(np.float32)
     s_col = (np.abs(detrng.normal(264, N, (N,))) * 1e-3 + 1e-4).astype(np.float32)
@@ -44,11 +44,6 @@ for (M, N, K) in %s:
     assert np.array_equal(y.float().cpu().numpy(), O.dequant_epilogue(acc, np.float32(3e-3), None, None, "bf16")), ("bf16", M, N, K)
     y = ops.linear_w8a8(xd, wd, torch.float32, 1.0, None, torch.from_numpy(s_col).to(dev), torch.from_numpy(bias).to(dev))
     assert np.array_equal(y.cpu().numpy(), O.dequant_epilogue(acc, s_col, None, bias, "f32")), ("f32 per-channel", M, N, K)
-# the placement probe of asq_workspace_init: on MI355X (SPX) the flag is set and blocks 0..7 sat on eight different XCDs
-t = ws[hdr - 512:hdr].view(torch.int32).cpu().numpy()
-print("probe", t[:9].tolist())
-if %d:
-    assert t[8] == 1 and len(set(t[:8].tolist())) == 8, t[:24]
 # hipGraph: capture one split launch, replay it three times against the eager result
 M, N, K = %s
 xd = torch.from_numpy(detrng.int8_uniform(265, M, (M, K))).to(dev)
@@ -73,10 +68,10 @@ print("ok")
 SHAPES = "[(256, 512, 2048), (300, 520, 1536), (128, 1024, 4096), (513, 640, 1024), (64, 256, 2560)]"
 
 
-@pytest.mark.parametrize("mode", [1, 2, 0])
+@pytest.mark.parametrize("mode", [1, 0])
 @pytest.mark.parametrize("ksplit", [2, 3, 4, 8])
 def test_in_launch_split_k_every_protocol(mode, ksplit):
-    code = CODE % (ROOT, os.path.join(ROOT, "tests"), SHAPES, 1 if mode == 1 else 0, "(256, 1024, 4096)")
+    code = CODE % (ROOT, os.path.join(ROOT, "tests"), SHAPES, "(256, 1024, 4096)")
     env = dict(os.environ, ASQ_GEMM_KERNEL="p8q", ASQ_KSPLIT=str(ksplit), ASQ_SPLITK_FIX=str(mode))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
@@ -84,7 +79,7 @@ def test_in_launch_split_k_every_protocol(mode, ksplit):
 
 def test_dispatcher_chooses_the_split_by_itself():
     """No forcing: the shapes the cost model splits (few tiles, long K) against the oracle, through the module-level op (ops keeps the workspace)."""
-    code = CODE % (ROOT, os.path.join(ROOT, "tests"), "[(256, 4096, 4096), (384, 4096, 4096), (512, 4096, 4096), (256, 4096, 11008)]", 0, "(256, 4096, 4096)")
+    code = CODE % (ROOT, os.path.join(ROOT, "tests"), "[(256, 4096, 4096), (384, 4096, 4096), (512, 4096, 4096), (256, 4096, 11008)]", "(256, 4096, 4096)")
     code = code.replace('assert n > hdr, ("the forced split needs scratch", M, N, K, n)', 'n = max(n, hdr); print("ws", M, N, K, n, L.lib().asq_gemm_kernel_name(M, N, K).decode())')
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
