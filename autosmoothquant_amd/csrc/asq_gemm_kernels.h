@@ -1178,7 +1178,7 @@ static inline int pick_ksplit(int64_t tiles, int64_t K, int64_t M, int64_t N, si
     return s < 1 ? 1 : (int)s;
 }
 
-constexpr double P8Q_FIX_TAIL_US = 4.4, P8Q_FIX_PER_SPLIT_US = 0.5;   // in-launch tail of a tile split in two; per further split (fitted: profiles/r5_splitk_fix_sweep*.txt)
+constexpr double P8Q_FIX_TAIL_US = 4.4, P8Q_FIX_PER_SPLIT_US = 1.1;   // in-launch tail of a tile split in two; per further split (fitted: profiles/r5_splitk_fix_sweep.txt)
 // K splits for the 128 x 128 kernel, from a small cost model fitted to measurements (us): a block costs 3 + (K-tiles) x (0.40 + 0.20 x the
 // fraction of the 256 CUs that hold a block -- the L2->LDS path is shared), a split launch adds the reduce pass, 5 + S x M x N x 4 B at
 // 3 TB/s.  512x4096x4096: S = 1 (18.0 us measured; S = 2: 21.3); 512x4096x11008: S = 2 (37.3; S = 1: 40.1); 128x4096x11008: S = 7 (21.9).
