@@ -72,7 +72,9 @@ int asq_gemm_i8_i32(const int8_t *x, const int8_t *w, int32_t *out,
 
 /* Optional scratch for the GEMM entry points.  When the M x N tile grid cannot fill the 256 CUs
  * (e.g. OPT-13B fc2 at 256 rows: 20 tiles) the dispatcher splits K across CUs, writes exact int32
- * partial slabs into `workspace` and reduces them in a second launch that applies the epilogue.
+ * partial slabs into `workspace` and reduces them in a second launch that applies the epilogue.  The 128 x 128 kernel (M ~ 192 ... 512 against LLaMA-sized weights)
+ * reduces its K splits INSIDE the launch instead (round 5): write-through 64 KiB register images behind the header, one ticket per tile in the header, the last
+ * arriver adds the others and runs the epilogue -- the same tickets-return-to-zero contract as the weight-streaming kernel below (csrc/asq_gemm_p8q2.h).
  * Independently of the workspace, a grid a few tiles over a multiple of 256 (1536 x 11008: 258 tiles) runs its last tile columns as a launch of
  * 128 x 128 tiles instead of paying a second wave for two tiles (-3 ... -19 % of the call); with a workspace that remainder may split K too.
  * asq_gemm_workspace_bytes() returns the size that enables this for a shape (0 = never needed).
@@ -81,8 +83,8 @@ int asq_gemm_i8_i32(const int8_t *x, const int8_t *w, int32_t *out,
 size_t asq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
 
 /* Workspace contract.  A workspace is [ header: asq_workspace_header_bytes() = 8 KiB | scratch ].  The header holds a magic word and the
- * arrival tickets of the weight-streaming kernel's in-launch reduction (few rows against a large weight: decode, cfg1, OPT fc2 at 32 rows per GPU --
- * csrc/asq_gemm_wstream.h); split-K slabs of the tiled kernels live behind it.
+ * arrival tickets of the in-launch reductions (the weight-streaming kernel, few rows against a large weight: decode, cfg1, OPT fc2 at 32 rows per GPU --
+ * csrc/asq_gemm_wstream.h; the K splits of the 128 x 128 kernel, csrc/asq_gemm_p8q2.h); partial tiles / split-K slabs live behind it.
  *   - asq_workspace_init() must run ONCE on a buffer (on the stream it will be used on, or synchronised) before the first GEMM call that receives it;
  *     every launch leaves the tickets at zero, also under hipGraph replay, so there is nothing to reset between calls or shapes;
  *   - a buffer is used by one launch at a time (one stream): concurrent launches on one workspace corrupt each other's tickets;
@@ -339,7 +341,7 @@ int asq_linear_mxfp8(const uint8_t *xq, const uint8_t *x_scales, const uint8_t *
  * launches it does not carry -- 4-byte / int8 outputs, K splits -- run the same tile on gemm_i8_p8 in its 16x16x64 mode) or "generic";
  * "p16+tail" / "p8h+tail" when the call runs as a main launch + a column remainder of 128 x 128 tiles.
  * Development overrides (read once per process): ASQ_GEMM_KERNEL=generic|skinny|p8q|p8h|p16|p8|p4|p4x16 (p8 / p4: the 32x32x32-instruction kernels of
- * rounds 1-2, p4x16: four waves on the 16x16x64 instruction), ASQ_MMA=32 (p8h / p8q / grouped launches on the 32x32x32 instruction), ASQ_KSPLIT=n,
+ * rounds 1-2, p4x16: four waves on the 16x16x64 instruction), ASQ_MMA=32 (p8h / p8q / grouped launches on the 32x32x32 instruction), ASQ_KSPLIT=n, ASQ_SPLITK_FIX=0 (K splits of the 128 x 128 kernel as slab launch + reduce launch again),
  * ASQ_SK_NT=1|2, ASQ_NO_TAIL=1. */
 const char *asq_gemm_kernel_name(int64_t M, int64_t N, int64_t K);
 
