@@ -1589,7 +1589,11 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
     } else if (kern == KERN_P8Q) {
         bool fix = false;
         if constexpr (kInt && (Epi::kOutBytes == 2 || Epi::kOutBytes == 4)) fix = ws_ok && ws_hdr != nullptr && splitk_fix_mode() != 0 && p8q2_enabled() && !mma32_forced() && tm128 * tn128 <= WS_MAX_GROUPS;
-        const int ksplit = ws_ok ? pick_ksplit_p8q(tm128 * tn128, K, M, N, ws_bytes, fix) : 1;
+        int ksplit = ws_ok ? pick_ksplit_p8q(tm128 * tn128, K, M, N, ws_bytes, fix) : 1;
+        if (fix && (ksplit > 16 || p8q_fix_bytes(tm128 * tn128, ksplit) >= ((size_t)1 << 31))) {   // (32-bit image offsets; only a forced ASQ_KSPLIT gets here)
+            fix = false;
+            ksplit = pick_ksplit_p8q(tm128 * tn128, K, M, N, ws_bytes, false);   // (the slab form sizes its scratch differently)
+        }
         if (ksplit > 1 && fix) {
             if constexpr (kInt && (Epi::kOutBytes == 2 || Epi::kOutBytes == 4))
                 rc = launch_tiled(gemm_i8_p8q2<Epi, true>, P8Q_LDS_BYTES, P8Q_LDS_BYTES, 8 * ((tm128 * tn128 + 7) / 8) * ksplit, 512, (int)tm128, (int)tn128, ksplit, epi, (char *)ws_hdr);
