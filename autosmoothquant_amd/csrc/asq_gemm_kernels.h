@@ -1020,6 +1020,77 @@ struct OffsetArgs {
 };
 constexpr int64_t OFFSET_MAX_K = 65536;   // the start values are formed with 24-bit multiplies: |sum_k| <= 128 K < 2^23 + 1
 
+// ---- K splits reduced INSIDE the launch (round 5; gemm_i8_p8q2<Epi, true>, gemm_i8_p8h<Epi, false, true, true>; asq_gemm_p8q2.h has the story) -------------------
+// Work item of block b = 8 * slot + xcd: XCD xcd owns tiles [base, base + cnt) (xcd_remap's shares); its blocks take (tile, split) = (base + slot / S, slot % S).
+// false: an idle block of the rounded-up grid (8 x the largest share).
+__device__ __forceinline__ bool splitk_fix_item(int ntiles, int ksplit, int &id, int &split)
+{
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int cnt = q + (xcd < r ? 1 : 0), base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    if (slot >= cnt * ksplit) return false;
+    id = base + slot / ksplit;
+    split = slot - (slot / ksplit) * ksplit;
+    return true;
+}
+// The tail: every block stores its NV x 16 B accumulator registers per lane as a write-through register image behind the workspace header ((tile, split) -> image
+// tile * S + split; the layout is the registers' own order), takes the tile's ticket in the header (one agent-scope atomic; the last arriver puts it back to zero, so the
+// next launch and a captured graph's replay find it clean), and the last arriver adds the other images -- three images' loads in flight together where the registers
+// allow -- and returns true: it runs the caller's epilogue.  The others return false.  No block waits for another; any placement of the blocks is correct.
+// `lds`: 4 bytes of block-shared scratch (the operand ring is dead by now).  A header without the magic word or a ticket above S traps (asq_workspace_init contract).
+template <int NV, class AccAt>
+__device__ __forceinline__ bool splitk_fix_reduce(char *gws, unsigned long long ws_magic, int id, int split, int ksplit, int tid, char *lds, AccAt at)
+{
+    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(gws + WS_HEADER_BYTES, 0, 0x7FFFFFFF, 0x00020000);
+    constexpr int PART = NV * 8192;   // one register image: NV x (512 lanes x 16 B)
+    const int my = (id * ksplit + split) * PART + tid * 16;
+    // (offset in the VGPR, soffset 0 and a wait state after the stores: see the note on buffer stores in asq_gemm_wstream.h)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, at(i)), rsrc, my + i * 8192, 0, 16 /* sc1: write-through */);
+    asm volatile("s_nop 1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's image has been acknowledged before the block takes its ticket
+    unsigned *const flag = (unsigned *)lds;
+    if (tid == 0) {
+        unsigned *const tk = (unsigned *)gws + 4 + id;
+        if (ws_magic != WS_MAGIC) __builtin_trap();   // workspace never went through asq_workspace_init
+        const unsigned old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)ksplit - 1) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next launch / replay
+        if (old >= (unsigned)ksplit) __builtin_trap();  // poisoned tickets: header not initialised / workspace shared by concurrent launches
+        *flag = old == (unsigned)ksplit - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool last = *flag != 0;
+    __syncthreads();  // (the staged epilogue reuses this LDS)
+    if (!last) return false;
+    // the other S - 1 images, up to MAXB at a time (<= 24 x 16 B per lane in flight): image j of the sequence 0 .. S - 2 is split j + (j >= split)
+    constexpr int MAXB = NV <= 8 ? 3 : 1;
+    auto add_images = [&](auto cnt_tag, int j0) {
+        constexpr int CNT = decltype(cnt_tag)::value;
+        v4u_ v[CNT][NV];
+#pragma unroll
+        for (int u = 0; u < CNT; ++u) {
+            const int j = j0 + u, sp = j + (j >= split ? 1 : 0);
+            const int src = (id * ksplit + sp) * PART + tid * 16;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[u][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, src + i * 8192, 0, 16 /* sc1 */);
+        }
+#pragma unroll
+        for (int u = 0; u < CNT; ++u)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) at(i) += __builtin_bit_cast(v4i, v[u][i]);
+    };
+    int j0 = 0;
+    if constexpr (MAXB == 3) {
+        for (; j0 + 3 <= ksplit - 1; j0 += 3) add_images(std::integral_constant<int, 3>{}, j0);
+        if (ksplit - 1 - j0 == 2) add_images(std::integral_constant<int, 2>{}, j0);
+        else if (ksplit - 1 - j0 == 1) add_images(std::integral_constant<int, 1>{}, j0);
+    } else {
+        for (; j0 < ksplit - 1; ++j0) add_images(std::integral_constant<int, 1>{}, j0);
+    }
+    return true;
+}
+
 }  // namespace asq
 
 #include "asq_gemm_p8.h"
@@ -1228,7 +1299,10 @@ static inline int pick_ksplit_p8q(int64_t tiles, int64_t K, int64_t M, int64_t N
 // costs 3 + (K-tiles) x (0.45 + 0.33 x the fraction of the 256 CUs that hold a block), a split launch adds 5 + S x M x N x 4 B at 3 TB/s for the
 // reduce pass.  OPT-13B fc2 at 256 rows (40 tiles, 160 K-tiles): S = 6 (39.5 us warm / 46.0 cold; the former "fill ~192 CUs" rule gave S = 4:
 // 41.2 / 51.8); 384x4096x11008: S = 4 (31.4); 256x4096x11008: S = 6 (26.3); 2048x4096x4096 (128 tiles): S = 1.
-static inline int pick_ksplit_p8h(int64_t tiles, int64_t K, int64_t M, int64_t N, size_t ws_bytes)
+static inline size_t p8h_fix_bytes(int64_t tiles, int64_t s) { return (size_t)tiles * (size_t)s * 131072; }   // one 128 KiB register image per (tile, split)
+constexpr double P8H_FIX_TAIL_US = 5.0, P8H_FIX_PER_SPLIT_US = 1.5;   // in-launch tail of a 128 x 256 tile split in two; per further split (first fit: profiles/r5_p8h_splitk_fix.txt)
+// `fix`: the K splits are reduced inside the launch (gemm_i8_p8h<Epi, false, true, true>): the tail replaces the reduce launch and the slab round trip
+static inline int pick_ksplit_p8h(int64_t tiles, int64_t K, int64_t M, int64_t N, size_t ws_bytes, bool fix = false)
 {
     if (N % 4 != 0) return 1;
     const int64_t nt = K / 128;
@@ -1240,13 +1314,18 @@ static inline int pick_ksplit_p8h(int64_t tiles, int64_t K, int64_t M, int64_t N
         double best = 1e30;
         const int64_t smax = nt / 4 < 16 ? nt / 4 : 16;
         for (int64_t c = 1; c <= (smax < 1 ? 1 : smax); ++c) {
-            const double blocks = (double)tiles * (double)c, waves = (double)((tiles * c + 255) / 256), fill = blocks < 256.0 ? blocks / 256.0 : 1.0;
+            const int64_t nblk = fix ? 8 * ((tiles + 7) / 8) * c : tiles * c;   // (the in-launch grid rounds every XCD's share up)
+            const double blocks = (double)nblk, waves = (double)((nblk + 255) / 256), fill = blocks < 256.0 ? blocks / 256.0 : 1.0;
             double t = waves * (3.0 + (double)((nt + c - 1) / c) * (0.45 + 0.33 * fill));
-            if (c > 1) t += 5.0 + (double)c * (double)M * (double)N * 4.0 / 3.0e6;
+            if (c > 1) t += fix ? P8H_FIX_TAIL_US + P8H_FIX_PER_SPLIT_US * (double)(c - 2) : 5.0 + (double)c * (double)M * (double)N * 4.0 / 3.0e6;
             if (t < best) { best = t; s = c; }
         }
     }
-    while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ws_bytes) --s;
+    if (fix) {
+        while (s > 1 && p8h_fix_bytes(tiles, s) > ws_bytes) --s;
+    } else {
+        while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ws_bytes) --s;
+    }
     return s < 1 ? 1 : (int)s;
 }
 
@@ -1569,22 +1648,31 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
             if (!done) rc = launch_tiled(gemm_i8_p8<Epi>, P8_LDS_BYTES, P8_LDS_BYTES, tm256 * tn256, 512, (int)tm256, (int)tn256, 1, no_groups, 0, no_gws, epi, OffsetArgs{});
         }
     } else if (kern == KERN_P8H) {
-        const int ksplit = ws_ok ? pick_ksplit_p8h(tm128 * tn256, K, M, N, ws_bytes) : 1;
-        if (ksplit > 1) {
+        bool fix = false;
+        if constexpr (kInt && (Epi::kOutBytes == 2 || Epi::kOutBytes == 4)) fix = ws_ok && ws_hdr != nullptr && splitk_fix_mode() != 0 && !mma32_forced() && tm128 * tn256 <= WS_MAX_GROUPS;
+        int ksplit = ws_ok ? pick_ksplit_p8h(tm128 * tn256, K, M, N, ws_bytes, fix) : 1;
+        if (fix && (ksplit > 16 || p8h_fix_bytes(tm128 * tn256, ksplit) >= ((size_t)1 << 31))) {   // (32-bit image offsets)
+            fix = false;
+            ksplit = pick_ksplit_p8h(tm128 * tn256, K, M, N, ws_bytes, false);
+        }
+        if (ksplit > 1 && fix) {
+            if constexpr (kInt && (Epi::kOutBytes == 2 || Epi::kOutBytes == 4))
+                rc = launch_tiled(gemm_i8_p8h<Epi, false, true, true>, P8H_LDS_BYTES, P8H_LDS_BYTES, 8 * ((tm128 * tn256 + 7) / 8) * ksplit, 512, (int)tm128, (int)tn256, ksplit, epi, (char *)ws_hdr);
+        } else if (ksplit > 1) {
             if constexpr (kInt) {
-                rc = mma32_forced() ? launch_tiled(gemm_i8_p8h<EpiI32>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256 * ksplit, 512, (int)tm128, (int)tn256, ksplit, slab)
-                                    : launch_tiled(gemm_i8_p8h<EpiI32, false, true>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256 * ksplit, 512, (int)tm128, (int)tn256, ksplit, slab);
+                rc = mma32_forced() ? launch_tiled(gemm_i8_p8h<EpiI32>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256 * ksplit, 512, (int)tm128, (int)tn256, ksplit, slab, (char *)nullptr)
+                                    : launch_tiled(gemm_i8_p8h<EpiI32, false, true>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256 * ksplit, 512, (int)tm128, (int)tn256, ksplit, slab, (char *)nullptr);
                 if (rc == ASQ_OK) reduce_slabs(ksplit);
             }
         } else {
             bool done = false;
             if constexpr (kInt) {
                 if (!mma32_forced()) {
-                    rc = launch_tiled(gemm_i8_p8h<Epi, false, true>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256, 512, (int)tm128, (int)tn256, 1, epi);
+                    rc = launch_tiled(gemm_i8_p8h<Epi, false, true>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256, 512, (int)tm128, (int)tn256, 1, epi, (char *)nullptr);
                     done = true;
                 }
             }
-            if (!done) rc = launch_tiled(gemm_i8_p8h<Epi>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256, 512, (int)tm128, (int)tn256, 1, epi);
+            if (!done) rc = launch_tiled(gemm_i8_p8h<Epi>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256, 512, (int)tm128, (int)tn256, 1, epi, (char *)nullptr);
         }
     } else if (kern == KERN_P8Q) {
         bool fix = false;

@@ -54,13 +54,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8q2(const int8_t *__restrict_
     int split, id;
     [[maybe_unused]] unsigned long long ws_magic = 0;
     if constexpr (FIX) {
-        // XCD xcd owns tiles [base, base + cnt) (xcd_remap's shares); its blocks take (tile, split) = (base + slot / ksplit, slot % ksplit)
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        const int cnt = q + (xcd < r ? 1 : 0), base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        if (slot >= cnt * ksplit) return;   // (block-uniform; the grid is 8 x the largest share)
-        id = base + slot / ksplit;
-        split = slot - (slot / ksplit) * ksplit;
+        if (!splitk_fix_item(nwg, ksplit, id, split)) return;   // (block-uniform; the grid is 8 x the largest share)
         ws_magic = *(const volatile unsigned long long *)gws;   // checked at the ticket
     } else {
         const int lid = xcd_remap(blockIdx.x, nwg * ksplit);
@@ -180,50 +174,8 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8q2(const int8_t *__restrict_
     P8_WAIT_LGKM0();  // ... and the fragment reads past the last tile, before LDS becomes staging space
     if (grp == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier
 
-    if constexpr (FIX) if (ksplit > 1) {   // block-uniform: in-launch reduction of the tile's K splits (see the top of the kernel)
-        typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(gws + WS_HEADER_BYTES, 0, 0x7FFFFFFF, 0x00020000);
-        constexpr int PART = 128 * 128 * 4;   // one register image: 8 x (512 lanes x 16 B)
-        const int my = (id * ksplit + split) * PART + tid * 16;
-        // (offset in the VGPR, soffset 0 and a wait state after the stores: see the note on buffer stores in asq_gemm_wstream.h)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_, acc16[i >> 2][i & 3]), rsrc, my + i * 8192, 0, 16 /* sc1: write-through */);
-        asm volatile("s_nop 1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // every wave's image has been acknowledged before the block takes its ticket
-        unsigned *const flag = (unsigned *)lds;  // (the ring is dead)
-        if (tid == 0) {
-            unsigned *const tk = (unsigned *)gws + 4 + id;
-            if (ws_magic != WS_MAGIC) __builtin_trap();   // workspace never went through asq_workspace_init
-            const unsigned old = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == (unsigned)ksplit - 1) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next launch / replay
-            if (old >= (unsigned)ksplit) __builtin_trap();  // poisoned tickets: header not initialised / workspace shared by concurrent launches
-            *flag = old == (unsigned)ksplit - 1 ? 1u : 0u;
-        }
-        __syncthreads();
-        const bool last = *flag != 0;
-        __syncthreads();  // (the staged epilogue reuses this LDS)
-        if (!last) return;
-        // the other S - 1 images, up to three at a time (24 x 16 B per lane in flight): image j of the sequence 0 .. S - 2 is split j + (j >= split)
-        auto add_images = [&](auto cnt_tag, int j0) {
-            constexpr int CNT = decltype(cnt_tag)::value;
-            v4u_ v[CNT][8];
-#pragma unroll
-            for (int u = 0; u < CNT; ++u) {
-                const int j = j0 + u, sp = j + (j >= split ? 1 : 0);
-                const int src = (id * ksplit + sp) * PART + tid * 16;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[u][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, src + i * 8192, 0, 16 /* sc1 */);
-            }
-#pragma unroll
-            for (int u = 0; u < CNT; ++u)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc16[i >> 2][i & 3] += __builtin_bit_cast(v4i, v[u][i]);
-        };
-        int j0 = 0;
-        for (; j0 + 3 <= ksplit - 1; j0 += 3) add_images(std::integral_constant<int, 3>{}, j0);
-        if (ksplit - 1 - j0 == 2) add_images(std::integral_constant<int, 2>{}, j0);
-        else if (ksplit - 1 - j0 == 1) add_images(std::integral_constant<int, 1>{}, j0);
-    }
+    if constexpr (FIX)
+        if (ksplit > 1 && !splitk_fix_reduce<8>(gws, ws_magic, id, split, ksplit, tid, lds, [&](int i) -> v4i & { return acc16[i >> 2][i & 3]; })) return;   // not the last arriver
 
     // accumulator tile (in16 = 16-channel tile 0..3, im16 = 16-token tile 0..1) -> rows m0 + wm*32 + 16*im16, cols n0 + wn*64 + 16*in16
     auto get16 = [&](int in16, int im16) -> const v4i & { return acc16[im16][in16]; };

@@ -1,4 +1,4 @@
-"""K splits of the 128 x 128 kernel reduced INSIDE the launch (gemm_i8_p8q2<Epi, true>, asq_gemm_p8q2.h; round 5: write-through register images, one
+"""K splits of the 128-row kernels reduced INSIDE the launch (gemm_i8_p8q2<Epi, true>, gemm_i8_p8h<Epi, false, true, true>; asq_gemm_p8q2.h, round 5: write-through register images, one
 ticket per tile, the last arriver adds the others and runs the caller's epilogue) and the former form (ASQ_SPLITK_FIX=0: int32 slab launch + reduce launch):
 every split count against the oracle's exact integer GEMM and its epilogues, ragged shapes, repeated launches on one workspace, a hipGraph replay, tickets
 back at zero.  The env switches are read once per process, hence the child processes."""
@@ -70,16 +70,18 @@ SHAPES = "[(256, 512, 2048), (300, 520, 1536), (128, 1024, 4096), (513, 640, 102
 
 @pytest.mark.parametrize("mode", [1, 0])
 @pytest.mark.parametrize("ksplit", [2, 3, 4, 8])
-def test_in_launch_split_k_every_protocol(mode, ksplit):
+@pytest.mark.parametrize("kern", ["p8q", "p8h"])
+def test_in_launch_split_k_every_protocol(kern, mode, ksplit):
+    """kern: the 128 x 128 kernel (gemm_i8_p8q2<Epi, true>, 64 KiB images) and the 128 x 256 one (gemm_i8_p8h<Epi, false, true, true>, 128 KiB images)."""
     code = CODE % (ROOT, os.path.join(ROOT, "tests"), SHAPES, "(256, 1024, 4096)")
-    env = dict(os.environ, ASQ_GEMM_KERNEL="p8q", ASQ_KSPLIT=str(ksplit), ASQ_SPLITK_FIX=str(mode))
+    env = dict(os.environ, ASQ_GEMM_KERNEL=kern, ASQ_KSPLIT=str(ksplit), ASQ_SPLITK_FIX=str(mode))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_dispatcher_chooses_the_split_by_itself():
     """No forcing: the shapes the cost model splits (few tiles, long K) against the oracle, through the module-level op (ops keeps the workspace)."""
-    code = CODE % (ROOT, os.path.join(ROOT, "tests"), "[(256, 4096, 4096), (384, 4096, 4096), (512, 4096, 4096), (256, 4096, 11008)]", "(256, 4096, 4096)")
+    code = CODE % (ROOT, os.path.join(ROOT, "tests"), "[(256, 4096, 4096), (384, 4096, 4096), (512, 4096, 4096), (256, 4096, 11008), (256, 5120, 20480), (384, 4096, 14336)]", "(256, 4096, 4096)")
     code = code.replace('assert n > hdr, ("the forced split needs scratch", M, N, K, n)', 'n = max(n, hdr); print("ws", M, N, K, n, L.lib().asq_gemm_kernel_name(M, N, K).decode())')
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
