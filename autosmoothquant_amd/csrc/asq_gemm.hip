@@ -69,12 +69,6 @@ extern "C" size_t asq_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K)
                       : kern == KERN_P8H ? pick_ksplit_p8h(((M + 127) / 128) * ((N + 255) / 256), K, M, N, (size_t)-1)
                                          : pick_ksplit_p8q(((M + 127) / 128) * ((N + 127) / 128), K, M, N, (size_t)-1);
         scratch = s > 1 ? (size_t)s * (size_t)M * (size_t)N * 4 : 0;
-        if (kern == KERN_P8H) {   // (as below, with 128 KiB images of 128 x 256 tiles)
-            const int64_t tiles = ((M + 127) / 128) * ((N + 255) / 256);
-            const int sf = tiles <= WS_MAX_GROUPS ? pick_ksplit_p8h(tiles, K, M, N, (size_t)-1, true) : 1;
-            const size_t fb = sf > 1 ? p8h_fix_bytes(tiles, sf) : 0;
-            scratch = fb > scratch ? fb : scratch;
-        }
         if (kern == KERN_P8Q) {   // the in-launch reduction of gemm_i8_p8q2<Epi, true> keeps one 64 KiB register image per (tile, split): whole tiles, and its own split count
             const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
             const int sf = tiles <= WS_MAX_GROUPS ? pick_ksplit_p8q(tiles, K, M, N, (size_t)-1, true) : 1;

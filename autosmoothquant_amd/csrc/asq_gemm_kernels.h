@@ -1020,7 +1020,7 @@ struct OffsetArgs {
 };
 constexpr int64_t OFFSET_MAX_K = 65536;   // the start values are formed with 24-bit multiplies: |sum_k| <= 128 K < 2^23 + 1
 
-// ---- K splits reduced INSIDE the launch (round 5; gemm_i8_p8q2<Epi, true>, gemm_i8_p8h<Epi, false, true, true>; asq_gemm_p8q2.h has the story) -------------------
+// ---- K splits reduced INSIDE the launch (round 5; gemm_i8_p8q2<Epi, true>; asq_gemm_p8q2.h has the story) -------------------
 // Work item of block b = 8 * slot + xcd: XCD xcd owns tiles [base, base + cnt) (xcd_remap's shares); its blocks take (tile, split) = (base + slot / S, slot % S).
 // false: an idle block of the rounded-up grid (8 x the largest share).
 __device__ __forceinline__ bool splitk_fix_item(int ntiles, int ksplit, int &id, int &split)
@@ -1299,10 +1299,7 @@ static inline int pick_ksplit_p8q(int64_t tiles, int64_t K, int64_t M, int64_t N
 // costs 3 + (K-tiles) x (0.45 + 0.33 x the fraction of the 256 CUs that hold a block), a split launch adds 5 + S x M x N x 4 B at 3 TB/s for the
 // reduce pass.  OPT-13B fc2 at 256 rows (40 tiles, 160 K-tiles): S = 6 (39.5 us warm / 46.0 cold; the former "fill ~192 CUs" rule gave S = 4:
 // 41.2 / 51.8); 384x4096x11008: S = 4 (31.4); 256x4096x11008: S = 6 (26.3); 2048x4096x4096 (128 tiles): S = 1.
-static inline size_t p8h_fix_bytes(int64_t tiles, int64_t s) { return (size_t)tiles * (size_t)s * 131072; }   // one 128 KiB register image per (tile, split)
-constexpr double P8H_FIX_TAIL_US = 5.0, P8H_FIX_PER_SPLIT_US = 1.5;   // in-launch tail of a 128 x 256 tile split in two; per further split (first fit: profiles/r5_p8h_splitk_fix.txt)
-// `fix`: the K splits are reduced inside the launch (gemm_i8_p8h<Epi, false, true, true>): the tail replaces the reduce launch and the slab round trip
-static inline int pick_ksplit_p8h(int64_t tiles, int64_t K, int64_t M, int64_t N, size_t ws_bytes, bool fix = false)
+static inline int pick_ksplit_p8h(int64_t tiles, int64_t K, int64_t M, int64_t N, size_t ws_bytes)
 {
     if (N % 4 != 0) return 1;
     const int64_t nt = K / 128;
@@ -1314,20 +1311,17 @@ static inline int pick_ksplit_p8h(int64_t tiles, int64_t K, int64_t M, int64_t N
         double best = 1e30;
         const int64_t smax = nt / 4 < 16 ? nt / 4 : 16;
         for (int64_t c = 1; c <= (smax < 1 ? 1 : smax); ++c) {
-            const int64_t nblk = fix ? 8 * ((tiles + 7) / 8) * c : tiles * c;   // (the in-launch grid rounds every XCD's share up)
-            const double blocks = (double)nblk, waves = (double)((nblk + 255) / 256), fill = blocks < 256.0 ? blocks / 256.0 : 1.0;
+            const double blocks = (double)tiles * (double)c, waves = (double)((tiles * c + 255) / 256), fill = blocks < 256.0 ? blocks / 256.0 : 1.0;
             double t = waves * (3.0 + (double)((nt + c - 1) / c) * (0.45 + 0.33 * fill));
-            if (c > 1) t += fix ? P8H_FIX_TAIL_US + P8H_FIX_PER_SPLIT_US * (double)(c - 2) : 5.0 + (double)c * (double)M * (double)N * 4.0 / 3.0e6;
+            if (c > 1) t += 5.0 + (double)c * (double)M * (double)N * 4.0 / 3.0e6;
             if (t < best) { best = t; s = c; }
         }
     }
-    if (fix) {
-        while (s > 1 && p8h_fix_bytes(tiles, s) > ws_bytes) --s;
-    } else {
-        while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ws_bytes) --s;
-    }
+    while (s > 1 && (size_t)s * (size_t)M * (size_t)N * 4 > ws_bytes) --s;
     return s < 1 ? 1 : (int)s;
 }
+// (K splits of this kernel reduced inside the launch were built on splitk_fix_reduce and measured: no gain at two splits, 3-7 us slower from three on -- 128 KiB images,
+// 40-80 tiles, 4-6 splits: profiles/r5_p8h_splitk_in_launch_dropped.txt)
 
 template <class Epi, int MT, int NT> int launch_skinny_mt(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int64_t K, int mblocks, const Epi &epi, hipStream_t s)
 {
@@ -1481,6 +1475,12 @@ static inline TailPeel plan_tail_peel(GemmKernel kern, int64_t M, int64_t N, int
     const int ks = p.rem_p8h ? pick_ksplit_p8h(((M + 127) / 128) * ((n_rem + 255) / 256), K, M, n_rem, (size_t)-1)
                              : pick_ksplit_p8q(((M + 127) / 128) * ((n_rem + 127) / 128), K, M, n_rem, (size_t)-1);
     p.ws_bytes = ks > 1 ? (size_t)ks * (size_t)M * (size_t)n_rem * 4 : 0;
+    if (!p.rem_p8h) {   // a 128 x 128 remainder reduces its K splits inside its launch when the caller's workspace has a header (register images of whole tiles, their own split count)
+        const int64_t tiles = ((M + 127) / 128) * ((n_rem + 127) / 128);
+        const int kf = tiles > WS_MAX_GROUPS ? 1 : pick_ksplit_p8q(tiles, K, M, n_rem, (size_t)-1, true);
+        const size_t fb = kf > 1 ? p8q_fix_bytes(tiles, kf) : 0;
+        p.ws_bytes = fb > p.ws_bytes ? fb : p.ws_bytes;
+    }
     return p;
 }
 
@@ -1564,7 +1564,7 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
             if (tp.n_main > 0) {
                 const int rc = launch_gemm_impl(x, w, M, tp.n_main, K, epi, s, what, nullptr, nullptr, 0, nullptr, 0, 1);
                 if (rc) return rc;
-                return launch_gemm_impl(x, w + tp.n_main * K, M, N - tp.n_main, K, epi.col_view(tp.n_main), s, what, nullptr, ws, ws_bytes, nullptr, 0, tp.rem_p8h ? 3 : 2);
+                return launch_gemm_impl(x, w + tp.n_main * K, M, N - tp.n_main, K, epi.col_view(tp.n_main), s, what, ws_hdr, ws, ws_bytes, nullptr, 0, tp.rem_p8h ? 3 : 2);
             }
         }
     }
@@ -1648,31 +1648,22 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
             if (!done) rc = launch_tiled(gemm_i8_p8<Epi>, P8_LDS_BYTES, P8_LDS_BYTES, tm256 * tn256, 512, (int)tm256, (int)tn256, 1, no_groups, 0, no_gws, epi, OffsetArgs{});
         }
     } else if (kern == KERN_P8H) {
-        bool fix = false;
-        if constexpr (kInt && (Epi::kOutBytes == 2 || Epi::kOutBytes == 4)) fix = ws_ok && ws_hdr != nullptr && splitk_fix_mode() != 0 && !mma32_forced() && tm128 * tn256 <= WS_MAX_GROUPS;
-        int ksplit = ws_ok ? pick_ksplit_p8h(tm128 * tn256, K, M, N, ws_bytes, fix) : 1;
-        if (fix && (ksplit > 16 || p8h_fix_bytes(tm128 * tn256, ksplit) >= ((size_t)1 << 31))) {   // (32-bit image offsets)
-            fix = false;
-            ksplit = pick_ksplit_p8h(tm128 * tn256, K, M, N, ws_bytes, false);
-        }
-        if (ksplit > 1 && fix) {
-            if constexpr (kInt && (Epi::kOutBytes == 2 || Epi::kOutBytes == 4))
-                rc = launch_tiled(gemm_i8_p8h<Epi, false, true, true>, P8H_LDS_BYTES, P8H_LDS_BYTES, 8 * ((tm128 * tn256 + 7) / 8) * ksplit, 512, (int)tm128, (int)tn256, ksplit, epi, (char *)ws_hdr);
-        } else if (ksplit > 1) {
+        const int ksplit = ws_ok ? pick_ksplit_p8h(tm128 * tn256, K, M, N, ws_bytes) : 1;
+        if (ksplit > 1) {
             if constexpr (kInt) {
-                rc = mma32_forced() ? launch_tiled(gemm_i8_p8h<EpiI32>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256 * ksplit, 512, (int)tm128, (int)tn256, ksplit, slab, (char *)nullptr)
-                                    : launch_tiled(gemm_i8_p8h<EpiI32, false, true>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256 * ksplit, 512, (int)tm128, (int)tn256, ksplit, slab, (char *)nullptr);
+                rc = mma32_forced() ? launch_tiled(gemm_i8_p8h<EpiI32>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256 * ksplit, 512, (int)tm128, (int)tn256, ksplit, slab)
+                                    : launch_tiled(gemm_i8_p8h<EpiI32, false, true>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256 * ksplit, 512, (int)tm128, (int)tn256, ksplit, slab);
                 if (rc == ASQ_OK) reduce_slabs(ksplit);
             }
         } else {
             bool done = false;
             if constexpr (kInt) {
                 if (!mma32_forced()) {
-                    rc = launch_tiled(gemm_i8_p8h<Epi, false, true>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256, 512, (int)tm128, (int)tn256, 1, epi, (char *)nullptr);
+                    rc = launch_tiled(gemm_i8_p8h<Epi, false, true>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256, 512, (int)tm128, (int)tn256, 1, epi);
                     done = true;
                 }
             }
-            if (!done) rc = launch_tiled(gemm_i8_p8h<Epi>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256, 512, (int)tm128, (int)tn256, 1, epi, (char *)nullptr);
+            if (!done) rc = launch_tiled(gemm_i8_p8h<Epi>, P8H_LDS_BYTES, P8H_LDS_BYTES, tm128 * tn256, 512, (int)tm128, (int)tn256, 1, epi);
         }
     } else if (kern == KERN_P8Q) {
         bool fix = false;

@@ -35,13 +35,10 @@ constexpr int P8H_LDS_BYTES = 3 * P8H_STAGE;  // 144 KiB
 
 // L16 (int8 only): the matrix work on v_mfma_i32_16x16x64_i8 (asq_gemm_p16.h for why): a phase is 2 k-steps x {4 token tiles x 2 channel tiles} = 16
 // instructions of 16 cycles on acc16[n-half][token tile][channel tile]; fragments 16 rows x 64 k-bytes from the same unit images.
-// FIX (L16 only, round 5): the K splits of a tile are reduced inside the launch -- 128 KiB write-through register images behind the workspace header, one ticket
-// per tile, the last arriver adds the others and runs the caller's epilogue (splitk_fix_reduce, asq_gemm_kernels.h; asq_gemm_p8q2.h has the story and the numbers).
-template <class Epi, bool PROBE = false, bool L16 = false, bool FIX = false>  // PROBE: per-block s_memtime stamps for tools/ubench/p8_probe (production: false)
+template <class Epi, bool PROBE = false, bool L16 = false>  // PROBE: per-block s_memtime stamps for tools/ubench/p8_probe (production: false)
 __global__ void __launch_bounds__(512, 2) gemm_i8_p8h(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
-                                                      int tiles_m, int tiles_n, int ksplit, Epi epi_in, char *__restrict__ gws = nullptr)
+                                                      int tiles_m, int tiles_n, int ksplit, Epi epi_in)
 {
-    static_assert(!FIX || L16, "the in-launch reduction is built for the 16 x 16 x 64 form");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -51,17 +48,9 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p8h(const int8_t *__restrict__
     // logical id = split * ntiles + tile (see p8); groups of GM tile rows share their X panels in L2
     constexpr int GM = 8;
     const int nwg = tiles_m * tiles_n;
-    int split, id;
-    [[maybe_unused]] unsigned long long ws_magic = 0;
-    if constexpr (FIX) {
-        if (!splitk_fix_item(nwg, ksplit, id, split)) return;   // (block-uniform; the grid is 8 x the largest share)
-        ws_magic = *(const volatile unsigned long long *)gws;   // checked at the ticket
-    } else {
-        const int lid = xcd_remap(blockIdx.x, nwg * ksplit);
-        split = lid / nwg;
-        id = lid - split * nwg;
-    }
-    const Epi epi = epi_in.rebased(0, FIX ? 0 : split, M, N);   // (FIX: the last arriver writes the caller's output itself; slabs otherwise)
+    const int lid = xcd_remap(blockIdx.x, nwg * ksplit);
+    const int split = lid / nwg, id = lid - split * nwg;
+    const Epi epi = epi_in.rebased(0, split, M, N);
     const int per_group = GM * tiles_n;
     const int group = id / per_group, in_group = id - group * per_group;
     const int first_m = group * GM;
@@ -260,9 +249,6 @@ if constexpr (L16) {
     P8H_BLK(2);
     P8_WAIT_VM(0);                                // drain the dead prefetches before LDS is released
     if (wm == 0) __builtin_amdgcn_s_barrier();    // balance the stagger barrier
-
-    if constexpr (FIX)
-        if (ksplit > 1 && !splitk_fix_reduce<16>(gws, ws_magic, id, split, ksplit, tid, lds, [&](int i) -> v4i & { return acc16[i >> 3][(i >> 1) & 3][i & 1]; })) return;   // not the last arriver
 
     if constexpr (L16) {
         // accumulator tile (in16 = 16-channel tile 0..3, im16 = 16-token tile 0..3) -> rows m0 + wm*64 + 16*im16, cols n0 + wn*64 + 16*in16

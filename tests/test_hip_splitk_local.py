@@ -1,4 +1,4 @@
-"""K splits of the 128-row kernels reduced INSIDE the launch (gemm_i8_p8q2<Epi, true>, gemm_i8_p8h<Epi, false, true, true>; asq_gemm_p8q2.h, round 5: write-through register images, one
+"""K splits of the 128 x 128 kernel reduced INSIDE the launch (gemm_i8_p8q2<Epi, true>, asq_gemm_p8q2.h; round 5: write-through register images, one
 ticket per tile, the last arriver adds the others and runs the caller's epilogue) and the former form (ASQ_SPLITK_FIX=0: int32 slab launch + reduce launch):
 every split count against the oracle's exact integer GEMM and its epilogues, ragged shapes, repeated launches on one workspace, a hipGraph replay, tickets
 back at zero.  The env switches are read once per process, hence the child processes."""
@@ -72,7 +72,8 @@ SHAPES = "[(256, 512, 2048), (300, 520, 1536), (128, 1024, 4096), (513, 640, 102
 @pytest.mark.parametrize("ksplit", [2, 3, 4, 8])
 @pytest.mark.parametrize("kern", ["p8q", "p8h"])
 def test_in_launch_split_k_every_protocol(kern, mode, ksplit):
-    """kern: the 128 x 128 kernel (gemm_i8_p8q2<Epi, true>, 64 KiB images) and the 128 x 256 one (gemm_i8_p8h<Epi, false, true, true>, 128 KiB images)."""
+    """kern: the 128 x 128 kernel (gemm_i8_p8q2<Epi, true>: in-launch for mode 1) and the 128 x 256 one (slab launch + reduce launch in both modes: its in-launch form
+    was measured and dropped, profiles/r5_p8h_splitk_in_launch_dropped.txt)."""
     code = CODE % (ROOT, os.path.join(ROOT, "tests"), SHAPES, "(256, 1024, 4096)")
     env = dict(os.environ, ASQ_GEMM_KERNEL=kern, ASQ_KSPLIT=str(ksplit), ASQ_SPLITK_FIX=str(mode))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)

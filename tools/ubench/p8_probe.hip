@@ -66,7 +66,7 @@ template <class Epi> void blk_timeline_p8h(const int8_t* x, const int8_t* w, Epi
     auto kfn = gemm_i8_p8h<Epi, true>;
     CK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8H_LDS_BYTES));
     int tm = (M + 127) / 128, tn = (N + 255) / 256;
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8H_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, epi, (char *)nullptr);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8H_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, epi);
     CK(hipDeviceSynchronize());
     static unsigned long long h[4096][8];
     CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(p8_blk), sizeof(h)));

@@ -44,7 +44,7 @@ int main(int argc, char **argv)
         auto kfn = gemm_i8_p8h<decltype(e)>;
         CK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, P8H_LDS_BYTES));
         const int tm = (int)((M + 127) / 128), tn = (int)((N + 255) / 256);
-        time([&] { hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8H_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, e, (char *)nullptr); }, "p8h", tm * tn);
+        time([&] { hipLaunchKernelGGL(kfn, dim3(tm * tn), dim3(512), P8H_LDS_BYTES, 0, x, w, M, N, K, tm, tn, 1, e); }, "p8h", tm * tn);
     }
     return 0;
 }
