@@ -275,6 +275,17 @@ __global__ void __launch_bounds__(512) gemm_i8_wstream(const int8_t *__restrict_
         const int g = g_first + ord;
         const unsigned lo = (unsigned)g * (unsigned)KU;
         const int bf = ws_block_of(lo, T, G), bl = ws_block_of(lo + KU - 1, T, G);
+        // the epilogue's own operands first (round 5): per-token scales, channel scales and bias used to be fetched behind the slab sums -- a second dependent
+        // round trip (~1 us of the ~3 us between "ticket known" and "group done", profiles/r3_wstream_timelines.txt); issued here they travel with the slab loads
+        float srv[MT];
+        v4f scv = {0.f, 0.f, 0.f, 0.f}, bbv = {0.f, 0.f, 0.f, 0.f};
+        const int64_t ncol = (int64_t)g * WS_CB + 16 * wave + 4 * fg;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = mt * 16 + fr;
+            srv[mt] = Epi::kHasRow ? epi.row(m < M ? m : M - 1) : 1.0f;
+        }
+        if (ncol < N) epi.cols(ncol, N, scv, bbv);
         acc4_t sum[MT];
         if (bf == bl && ord == nseg - 1) {  // the whole group ran in this block and ended with it: still in registers
 #pragma unroll
@@ -303,13 +314,8 @@ __global__ void __launch_bounds__(512) gemm_i8_wstream(const int8_t *__restrict_
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int64_t m = mt * 16 + fr, n = (int64_t)g * WS_CB + 16 * wave + 4 * fg;
-            if (m < M && n < N) {
-                const float sr = Epi::kHasRow ? epi.row(m) : 1.0f;
-                v4f sc = {0.f, 0.f, 0.f, 0.f}, bb = {0.f, 0.f, 0.f, 0.f};
-                epi.cols(n, N, sc, bb);
-                epi.store4(m, n, sum[mt], sr, sc, bb, N);
-            }
+            const int64_t m = mt * 16 + fr;
+            if (m < M && ncol < N) epi.store4(m, ncol, sum[mt], srv[mt], scv, bbv, N);
         }
         WS_STAMP(5);
     }

@@ -66,7 +66,9 @@ for sh in args.shapes.split(","):
     wss = {}
     if args.ws:
         for k in libs:
-            wss[k] = torch.zeros(8192 + 65536, dtype=torch.uint8, device=dev)
+            libs[k].asq_gemm_workspace_bytes.restype = sz
+            libs[k].asq_gemm_workspace_bytes.argtypes = [i64, i64, i64]
+            wss[k] = torch.zeros(max(8192 + 65536, int(libs[k].asq_gemm_workspace_bytes(M, N, K))), dtype=torch.uint8, device=dev)   # (what the shape's own kernel asks for: stream-K slabs, split-K images)
             assert libs[k].asq_workspace_init(wss[k].data_ptr(), wss[k].numel(), stream) == 0
 
     def call(k):
