@@ -504,6 +504,100 @@ def cfg1_block(device):
     return out
 
 
+def _time_calls(fn, n, warm):
+    """(host period per call, device period per call) in us: n eager calls after `warm` of them."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    host = (time.perf_counter() - t0) / n * 1e6
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    b.synchronize()
+    return host, a.elapsed_time(b) / n * 1e3
+
+
+def _time_graph(fn, n=50):
+    """One call of fn captured as a hipGraph on a side stream (warm-up on that stream first: per-stream workspace), us per replay."""
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(cap)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=cap):
+        fn()
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        g.replay()
+    b.record()
+    b.synchronize()
+    us = a.elapsed_time(b) / n * 1e3
+    del g
+    return us
+
+
+def other_configs_block(device, tdt):
+    """The BASELINE configs the main value is not quoted on, each as a short measurement inside the default line (rank 0, one GPU's share), so that the driver's own
+    record carries a number for every config: configs[1] (LLaMA-2-7B decoder layer at batch 1, S = 2048 / 128 / 1: eager and as a hipGraph, N1-fused composition),
+    configs[3] (OPT-13B fc2 per-token + bias at 32 rows -- the 8-GPU shard of batch 256 -- and at 256 rows: module call and device period) and configs[4] (Mixtral
+    experts, 8192 routed rows: grouped launches with torch SiLU*up and with the fused SiLU*up -> int8 kernel).  Synthetic weights and inputs as everywhere in this file."""
+    out = {}
+    lin_ops_tok = 2.0 * (4 * 4096 * 4096 + 3 * 4096 * 11008)
+    cfg2 = {"workload": "BASELINE configs[1]: LLaMA-2-7B decoder layer (W8A8 linears; RMSNorm->int8, one QKV GEMM, SiLU*up->int8 fused; RoPE / causal SDPA in torch), batch 1"}
+    for S in (2048, 128, 1):
+        layers, x = make_layer_workload(f"layer:1:{S}:1", device, seed=777 + S, dtype=tdt, fuse_norm=True, fuse_qkv=True)
+        for l in layers:
+            l.defer_residual = True
+        fn = lambda: run_layers(layers, x)
+        host, dev = _time_calls(fn, 30 if S > 128 else 100, 10)
+        rec = {"eager_us": round(max(host, dev), 1), "linear_TOPS_eager": round(lin_ops_tok * S / max(host, dev) / 1e6, 1)}
+        try:
+            gus = _time_graph(fn)
+            rec.update({"hipgraph_us": round(gus, 1), "tokens_per_s_hipgraph": round(S / gus * 1e6, 1)})
+        except Exception as e:   # a capture failure must not cost the line
+            rec["hipgraph_us"] = None
+            rec["hipgraph_error"] = str(e)[:120]
+            torch.cuda.synchronize()
+        cfg2[f"S{S}"] = rec
+        del layers, x
+    out["cfg2"] = cfg2
+    cfg4 = {"workload": "BASELINE configs[3]: OPT-13B fc2 W8A8BFP32OFP32LinearWithQuantScale 20480->5120 + bias, per-token (one GPU's rows; weights warm)"}
+    for M in (32, 256):
+        spec = WORKLOADS["opt13b_fc2"][2]
+        mods, xs = make_workload(spec, M, device, seed=555 + M, dtype=tdt)
+        host, dev = _time_calls(lambda: run_step(mods, spec, xs), 200, 20)
+        byts = 20480 * 5120 + M * 20480 * 2 + M * 5120 * 2
+        cfg4[f"rows{M}"] = {"module_call_us": round(host, 2), "device_period_us": round(dev, 2), "rows_per_s": round(M / max(host, dev) * 1e6, 1),
+                            "GBps": round(byts / max(host, dev) / 1e3, 1), "TOPS": round(2.0 * M * 20480 * 5120 / max(host, dev) / 1e6, 1)}
+        del mods, xs
+    out["cfg4"] = cfg4
+    st, grouped, _seq = make_moe_workload(device, 1234, tdt)
+    ops_ = 2.0 * 8192 * 3 * 4096 * 14336
+    cfg5 = {"workload": "BASELINE configs[4]: Mixtral-8x7B expert MLPs, 4096 tokens x top-2 = 8192 routed rows, one grouped launch per projection", "operands": st.get("operands", "plain")}
+    for tag, fn in (("grouped_torch_silu", grouped), ("grouped_fused_silu", st.get("grouped_fused_fast") or st.get("grouped_fused"))):
+        if fn is None:
+            continue
+        host, dev = _time_calls(fn, 20, 5)
+        cfg5[tag] = {"ms": round(max(host, dev) / 1e3, 4), "TOPS": round(ops_ / max(host, dev) / 1e6, 1), "tokens_per_s": round(4096 / max(host, dev) * 1e6, 1)}
+    out["cfg5"] = cfg5
+    del st, grouped, _seq
+    torch.cuda.empty_cache()
+    return out
+
+
 def pmc_traffic(kernel_key, M, N, K):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r*_pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc
@@ -755,6 +849,7 @@ def main():
                          "(arena broadcast, fingerprints, barriers, max-over-ranks timing) can be rehearsed on a box with fewer GPUs than ranks: ranks then share "
                          "device LOCAL_RANK %% device_count and the line is marked rehearsal=true (not a scaling measurement)")
     ap.add_argument("--no-plain-compare", action="store_true", help="skip the plain-operand timing of the dominant kernel (rocprofv3 passes: the comparison launches carry the same kernel name as the offset-image launches and would mix into its average)")
+    ap.add_argument("--no-other-configs", action="store_true", help="default workload only: skip the short cfg2 / cfg4 / cfg5 measurements (block 'configs')")
     ap.add_argument("--no-cfg3", action="store_true", help="default workload only: skip the LLaMA-2-7B 32-layer decoder forward (BASELINE configs[2]) that is timed after the main step")
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)   # internal: one pinned leg of cpu_baseline() in its own process
     args = ap.parse_args()
@@ -994,6 +1089,13 @@ def main():
             if M >= 2304 and not args.no_plain_compare and not args.graph:
                 operand_table = by_operands(mods, xs, tdt, args.settle_ms)
     cfg1 = cfg1_block(device) if (rank == 0 and args.workload == "llama7b_attn_linears" and not args.graph) else None
+    other = None
+    if rank == 0 and args.workload == "llama7b_attn_linears" and not args.graph and not args.no_other_configs:
+        try:
+            other = other_configs_block(device, tdt)
+        except Exception as e:   # (the extra blocks must never cost the headline line)
+            other = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.synchronize()
     cfg3 = time_cfg3(cfg3_layers, cfg3_x, world, sync_all) if cfg3_layers is not None else None
     del cfg3_layers, cfg3_x
 
@@ -1047,6 +1149,8 @@ def main():
             out["config"]["workload"] += f"  +  {cfg3['workload']} (block 'cfg3': tokens_per_s = its whole-forward rate in the reference's module composition)"
         if cfg1:
             out["cfg1"] = cfg1
+        if other:
+            out["configs"] = other   # BASELINE configs[1], [3], [4]: short measurements of the same build in the same process (other_configs_block)
         if fused_qkv:
             out["step_fused_qkv"] = fused_qkv
         if bcast:

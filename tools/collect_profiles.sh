@@ -13,9 +13,9 @@ cd /tmp && export TMPDIR=/tmp
 python "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 # the traced passes run WITHOUT the cfg3 block: the same kernel templates also serve its M = 65536 launches, which would pollute the
 # per-kernel averages of the 4096^3 launches the roofline block is about; cfg3 gets its own --stats pass below
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --no-cfg3 --no-plain-compare > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --no-cfg3 --no-other-configs --no-plain-compare > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
 for C in FETCH_SIZE WRITE_SIZE MfmaUtil SQ_INSTS_VALU_MFMA_I8 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- python "$ROOT/bench.py" --no-cpu-baseline --no-cfg3 --no-plain-compare --steps 5 --warmup 2 > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err"
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- python "$ROOT/bench.py" --no-cpu-baseline --no-cfg3 --no-other-configs --no-plain-compare --steps 5 --warmup 2 > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err"
 done
 for F in "" "--fuse-norm --fuse-qkv"; do
   T=cfg3$( [ -n "$F" ] && echo _fused )
