@@ -43,4 +43,8 @@ for nk in args.nks.split(","):
         us = ts[len(ts) // 2]
         ops_, byts = 2.0 * M * N * K, N * K + M * K + 2 * M * N
         floor = max(ops_ / (0.6 * 5033e6), byts / 5.5e6) + 2.5
-        print(f"{M:5d} x {N:5d} x {K:5d}  {ops.gemm_kernel_name(M, N, K):8s} {us:7.1f} us  {ops_ / us / 1e6:6.0f} TOPS {ops_ / us / 50.33e6:5.1f} %  {byts / us / 1e3:6.0f} GB/s   floor ~{floor:6.1f} us  x{us / floor:.2f}", flush=True)
+        kn = ops.gemm_kernel_name(M, N, K)
+        tile = {"p8q": (128, 128), "p8h": (128, 256), "p16": (256, 256), "p8": (256, 256)}.get(kn.split("+")[0])
+        # bytes the launch moves L2 -> LDS (every tile streams its X and W panels): the path tops out near 38 B/clk per CU and 17-18 TB/s chip-wide
+        lds_tbs = f"{-(-M // tile[0]) * -(-N // tile[1]) * K * (tile[0] + tile[1]) / max(us - 3.0, 0.1) / 1e6:5.1f} TB/s L2->LDS" if tile else ""
+        print(f"{M:5d} x {N:5d} x {K:5d}  {kn:8s} {us:7.1f} us  {ops_ / us / 1e6:6.0f} TOPS {ops_ / us / 50.33e6:5.1f} %  {byts / us / 1e3:6.0f} GB/s   floor ~{floor:6.1f} us  x{us / floor:.2f}  {lds_tbs}", flush=True)
