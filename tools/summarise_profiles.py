@@ -35,7 +35,10 @@ shutil.copy(stats, os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
 trace = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)
 if trace:
     rows = sorted(csv.DictReader(open(trace[0])), key=lambda r: int(r["Start_Timestamp"]))
-    names = collections.Counter(r["Kernel_Name"] for r in rows if "asq::gemm_i8" in r["Kernel_Name"])
+    names = collections.Counter()   # the dominant kernel = the GEMM with the largest total time (not the most launches: the cfg1 block launches its small kernel 5000 times)
+    for r in rows:
+        if "asq::gemm_i8" in r["Kernel_Name"]:
+            names[r["Kernel_Name"]] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     dom = names.most_common(1)[0][0]
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if r["Kernel_Name"] == dom]
     live = last_json_line(os.path.join(src, "bench_under_rocprof.json"))["roofline"]
