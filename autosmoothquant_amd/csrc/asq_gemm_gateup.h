@@ -24,7 +24,17 @@ template <int DT, bool HAS_ROW> struct EpiGateUp {
     const float *s_row;  // [M]  (HAS_ROW: per-token activation scales)
     float s_gate, s_up, s_scalar;   // dequant scales of the two projections (s_scalar: unused, keeps the functor interface)
     int fast;
-    __device__ __forceinline__ EpiGateUp rebased(int, int, int64_t, int64_t) const { return *this; }
+    const float *sg_group = nullptr, *su_group = nullptr;   // grouped launch (asq_linear_w8a8_grouped_gate_up): per-group dequant scales [ngroups]
+    static constexpr bool kGroupable = true;
+    __device__ __forceinline__ EpiGateUp rebased(int grp, int, int64_t, int64_t) const
+    {
+        EpiGateUp e = *this;
+        if (sg_group) {
+            e.s_gate = sg_group[grp];
+            e.s_up = su_group[grp];
+        }
+        return e;
+    }
     // 4 outputs (channels c .. c + 3 of one token) from the lane's 4 gate and 4 up accumulators
     __device__ __forceinline__ v2u pack_gate_up(const v4i &g, const v4i &u, float sr) const
     {
@@ -59,8 +69,7 @@ template <int DT, bool HAS_ROW> struct EpiGateUp {
     }
 };
 
-template <class Epi, class = void> struct IsGateUp : std::false_type {};
-template <class Epi> struct IsGateUp<Epi, std::enable_if_t<Epi::kGateUp>> : std::true_type {};
+// (IsGateUp<Epi>: asq_gemm_kernels.h, in front of the kernels)
 
 // Epilogue of one wave tile (128 tokens x 64 interleaved channels = 32 output channels) of gemm_i8_p16p: interior tiles only, per-token scales from the tile's
 // LDS operand area (EL = EpiTileLds<EpiGateUp>), direct 8-byte stores (a store instruction covers 16 rows x 32 bytes; the output is half a plain tile's bytes).
@@ -85,6 +94,23 @@ template <class EL, class Get> __device__ __forceinline__ void epilogue_gate_up(
             const v2u o = (im16 == 0 && p == 0) ? first : e.pack_gate_up(get(2 * p, im16), get(2 * p + 1, im16), sr[im16]);
             *(glb_v2u)(uintptr_t)(tile + (uint64_t)((unsigned)(im16 * 16) * ldb + (unsigned)(p * 32)) + voff) = o;
         }
+}
+
+// The same epilogue for a wave tile of the GROUPED 256 x 256 kernel (gemm_i8_p8<Epi, 0, true, true>; Mixtral's w1 || w3): rows are bounded by the group's end / the
+// half tile (Mw), per-token scales come from memory (the grouped launches of the models run per-tensor activations: HAS_ROW = false costs nothing), no operand area.
+template <class Epi, class Get> __device__ __forceinline__ void epilogue_gate_up_rows(const Epi &e, Get get, int64_t mw0, int64_t nw0, int lane, int64_t Mw)
+{
+    const int t = lane & 15, q = lane >> 4;
+    typedef __attribute__((address_space(1))) v2u *glb_v2u;
+#pragma unroll
+    for (int im16 = 0; im16 < 8; ++im16) {
+        const int64_t m = mw0 + im16 * 16 + t;
+        if (m >= Mw) continue;
+        const float sr = Epi::kHasRow ? e.s_row[m] : 1.0f;
+        char *const row = (char *)e.out + (m * e.N + (nw0 >> 1)) * 2 + q * 8;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) *(glb_v2u)(uintptr_t)(row + p * 32) = e.pack_gate_up(get(2 * p, im16), get(2 * p + 1, im16), sr);
+    }
 }
 
 }  // namespace asq

@@ -1020,6 +1020,10 @@ struct OffsetArgs {
 };
 constexpr int64_t OFFSET_MAX_K = 65536;   // the start values are formed with 24-bit multiplies: |sum_k| <= 128 K < 2^23 + 1
 
+// epilogues of the gate || up GEMMs (asq_gemm_gateup.h) mark themselves with kGateUp; the kernels that carry them select their epilogue on this trait
+template <class Epi, class = void> struct IsGateUp : std::false_type {};
+template <class Epi> struct IsGateUp<Epi, std::enable_if_t<Epi::kGateUp>> : std::true_type {};
+
 // ---- K splits reduced INSIDE the launch (round 5; gemm_i8_p8q2<Epi, true>; asq_gemm_p8q2.h has the story) -------------------
 // Work item of block b = 8 * slot + xcd: XCD xcd owns tiles [base, base + cnt) (xcd_remap's shares); its blocks take (tile, split) = (base + slot / S, slot % S).
 // false: an idle block of the rounded-up grid (8 x the largest share).

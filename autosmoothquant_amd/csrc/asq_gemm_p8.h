@@ -668,7 +668,9 @@ if constexpr (L16) {
         const int64_t mw0 = m0 + (half ? wm * 64 : wm * 128), nw0 = n0 + wn * 64;   // (half tile: see below)
         const int64_t Mw = half && mw0 + 64 < M ? mw0 + 64 : M;
         auto run = [&](auto getter) {
-            if (staged16) {
+            if constexpr (IsGateUp<Epi>::value) {   // gate || up groups: SiLU(gate) * up of the lane's own accumulator pairs, half the output bytes (asq_gemm_gateup.h)
+                epilogue_gate_up_rows(epi, getter, mw0, nw0, lane, Mw);
+            } else if (staged16) {
                 if constexpr (Epi::kOutBytes >= 2) {
                     P8_BAR();
                     bool rows_path = false;
@@ -719,6 +721,8 @@ if constexpr (L16) {
         run(get16);
         return;
     }
+    if constexpr (IsGateUp<Epi>::value) return;   // (the gate || up epilogue exists for the 16 x 16 x 64 form only)
+    else {
     // accumulator tile (in = n-half, im = 2*m-half + j) -> rows m0 + wm*128 + 32*im, cols n0 + wn*64 + 32*in
     auto get = [&](int in, int im) -> const acc_t & { return acc[im >> 1][in][im & 1]; };
     bool staged = false;
@@ -741,6 +745,7 @@ if constexpr (L16) {
         epilogue_wave<2, 4>(epi, get, [](int im) { return im * 32; }, mw0, n0 + wn * 64, lane, Mw, N);
     }
     P8_PROBE_END_WHERE(tile_m, tile_n);
+    }
 }
 
 }  // namespace asq

@@ -282,6 +282,53 @@ def linear_w8a8_gate_up(xq, w_gu, out_dtype, s_gate, s_up, s_row=None, fast=None
     return out
 
 
+def grouped_gate_up_supported(M, F_, K, out_dtype):
+    return out_dtype in (torch.float16, torch.bfloat16) and bool(L.lib().asq_grouped_gate_up_supported(M, F_, K, _DT[out_dtype]))
+
+
+def interleave_gate_up_stack(w1, w3):
+    """[G, 2F, K] int8: every group's gate (w1[g]) and up (w3[g]) rows interleaved in blocks of 16 channels (interleave_gate_up per group)."""
+    if w1.shape != w3.shape or w1.dim() != 3:
+        raise ValueError("w1 / w3 must be [G, F, K] stacks of one shape")
+    G, F_, K = w1.shape
+    out = torch.empty((G, 2 * F_, K), dtype=torch.int8, device=w1.device)
+    for g in range(G):
+        interleave_gate_up(w1[g], w3[g], out=out[g])
+    return out
+
+
+def linear_w8a8_grouped_gate_up(xq, w_gu, group_offsets, s_gate, s_up, out_dtype, fast=None, row_off=None, col_off=None):
+    """SiLU(w1 x) * (w3 x) of ALL groups in ONE grouped launch over the interleaved stacks w_gu [G, 2F, K] (asq_linear_w8a8_grouped_gate_up; reference
+    models/mixtral.py:99-101,142-145): out [M, F], bit-identical to linear_w8a8_grouped (w1), (w3) and the SiLU * up of silu_mul_quantize(fast=...).  Per-tensor
+    activations.  row_off / col_off: offset operand images of xq and of the stack viewed as [G * 2F, K]."""
+    _dev(xq, "xq"), _dev(w_gu, "w_gu"), _dev(group_offsets, "group_offsets"), _dev(s_gate, "s_gate"), _dev(s_up, "s_up")
+    if xq.dtype != torch.int8 or w_gu.dtype != torch.int8 or xq.dim() != 2 or w_gu.dim() != 3 or xq.shape[1] != w_gu.shape[2] or w_gu.shape[1] % 2:
+        raise ValueError("xq [M,K] int8 and w_gu [G,2F,K] int8 with equal K expected")
+    if not (xq.is_contiguous() and w_gu.is_contiguous()):
+        raise ValueError("xq / w_gu must be contiguous")
+    M, K = xq.shape
+    G, F_ = w_gu.shape[0], w_gu.shape[1] // 2
+    if group_offsets.dtype != torch.int32 or group_offsets.numel() != G + 1:
+        raise ValueError("group_offsets must be int32 [G+1]")
+    for name, t in (("s_gate", s_gate), ("s_up", s_up)):
+        if t.dtype != torch.float32 or t.numel() != G:
+            raise ValueError(f"{name} must be float32 [G]")
+    if (row_off is None) != (col_off is None):
+        raise ValueError("row_off and col_off come together")
+    if row_off is not None and (row_off.dtype != torch.int32 or row_off.numel() != 2 * M or col_off.dtype != torch.int32 or col_off.numel() != 4 * G * F_):
+        raise ValueError("row_off must be int32 [M,2] and col_off int32 [G,2F,2]")
+    if fast is None:
+        fast = not SILU_EXACT_DEFAULT
+    out = torch.empty((M, F_), dtype=out_dtype, device=xq.device)
+    dev = _same_device(xq, w_gu, group_offsets, s_gate, s_up, row_off, col_off)
+    with _on(dev):
+        lib, st = L.lib(), _stream(xq)
+        ws, n = _grouped_ws(lib, M, 2 * F_, K, G, dev, st)
+        L.check(lib.asq_linear_w8a8_grouped_gate_up(xq.data_ptr(), w_gu.data_ptr(), out.data_ptr(), _DT[out_dtype], group_offsets.data_ptr(), G, M, F_, K, s_gate.data_ptr(),
+                                                    s_up.data_ptr(), L.ASQ_SILU_FAST if fast else 0, _ptr(row_off), _ptr(col_off), _ptr(ws), n, st), "asq_linear_w8a8_grouped_gate_up")
+    return out
+
+
 def _check_image(image, N, K, device):
     """an offset operand image handed to a C-ABI call: int8 [N,K] + int32 [N,2], contiguous, on `device` (the kernels read both through raw pointers)"""
     w_off, col_off = image

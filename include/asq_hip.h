@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ASQ_VERSION 120 /* 0.1.2: + asq_forward_fused_supported, asq_linear_w8a8_forward_fused (the one-launch forward for decode-sized inputs; asq_linear_w8a8_forward takes it
+#define ASQ_VERSION 121 /* 0.1.3: + asq_grouped_gate_up_supported, asq_linear_w8a8_grouped_gate_up (Mixtral's w1 || w3 as one grouped launch with the SiLU * up epilogue); 0.1.2: + asq_forward_fused_supported, asq_linear_w8a8_forward_fused (the one-launch forward for decode-sized inputs; asq_linear_w8a8_forward takes it
                            * by itself where it wins); ASQ_ROCTX=1 ranges.  0.1.1: + offset operand images (asq_*_off); workspace sizes include the 8 KiB header
                            * (asq_workspace_init is mandatory for a workspace handed to a GEMM entry point); asq_silu_mul_quantize's `per_token` is a bit field (bit 0
                            * per-token, ASQ_SILU_FAST) */
@@ -275,6 +275,16 @@ int asq_add_norm_quantize_off(const void *x, const void *residual, void *h_out, 
 int asq_gate_up_supported(int64_t M, int64_t F, int64_t K, int out_dtype);
 int asq_linear_w8a8_gate_up(const int8_t *xq, const int8_t *w_gu, void *out, int out_dtype, int64_t M, int64_t F, int64_t K,
                             float s_gate, float s_up, const float *s_row, int flags, const int32_t *row_off, const int32_t *col_off, void *stream);
+/* The grouped form (round 5, last session): Mixtral's experts (reference models/mixtral.py:99-101,142-145: w2(act(w1 x) * w3 x) per expert) -- w1 || w3 of ALL experts as ONE
+ * grouped launch whose epilogue writes SiLU(w1 x) * (w3 x): asq_linear_w8a8_grouped[_off]'s launch (rows sorted by group, group_offsets[0 .. ngroups], device-side tile
+ * scheduler, half tiles, in-launch K split of the tail round with a workspace) over w_gu int8 [ngroups, 2 F, K], each group's rows interleaved as above; s_gate / s_up
+ * [ngroups] are the per-group dequant scales of the two projections; out [M, F].  Per-tensor activations (no row scales).  row_off / col_off: both NULL or the activation's
+ * row vector and the column vector of asq_weight_offset_image over the [ngroups * 2 F, K] stack.  Bit-identical to asq_linear_w8a8_grouped (w1), (w3) and the SiLU * up of
+ * asq_silu_mul_quantize with the same ASQ_SILU_FAST flag.  asq_grouped_gate_up_supported: F % 128 == 0, K % 128 == 0, K <= 65536, 2-byte out_dtype. */
+int asq_grouped_gate_up_supported(int64_t M, int64_t F, int64_t K, int out_dtype);
+int asq_linear_w8a8_grouped_gate_up(const int8_t *xq, const int8_t *w_gu, void *out, int out_dtype, const int32_t *group_offsets, int ngroups,
+                                    int64_t M, int64_t F, int64_t K, const float *s_gate, const float *s_up, int flags,
+                                    const int32_t *row_off, const int32_t *col_off, void *workspace, size_t workspace_bytes, void *stream);
 int asq_silu_mul_quantize_off(const void *gate, const void *up, int x_dtype, int per_token, float quant_scale,
                               int8_t *xq_off, float *s_row, int32_t *row_off, int64_t M, int64_t K, void *stream);
 int asq_linear_w8a8_forward_off(const void *x, int x_dtype, const int8_t *w, const int8_t *w_off, const int32_t *col_off, void *out,

@@ -1,0 +1,69 @@
+"""GPU (-m gpu): Mixtral's w1 || w3 of all experts as ONE grouped launch with the SiLU(w1 x) * (w3 x) epilogue (asq_linear_w8a8_grouped_gate_up on the grouped
+256 x 256 kernel; reference models/mixtral.py:99-101,142-145) against the composition it replaces -- linear_w8a8_grouped (w1), linear_w8a8_grouped (w3), the SiLU * up
+of asq_silu_mul_quantize -- through the consumer's quantiser (per-token as Mixtral's w2, and per-tensor), both SiLU forms, plain operands and offset images, ragged
+groups (empty, < 128 rows, not a multiple of 256), repeated launches on one workspace, and at Mixtral size with the bench's routing (the tail round's in-launch K
+split runs there).  Bit for bit."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+TDT = {"f16": torch.float16, "bf16": torch.bfloat16}
+
+
+def _check(counts, F_, K, dt, seed):
+    from autosmoothquant_amd import ops
+    G, M = len(counts), sum(counts)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    w1 = torch.randint(-128, 128, (G, F_, K), generator=g, device=DEV, dtype=torch.int8)
+    w3 = torch.randint(-128, 128, (G, F_, K), generator=g, device=DEV, dtype=torch.int8)
+    x = (torch.randn(M, K, generator=g, device=DEV) * 3.0)
+    x[:, torch.rand(K, generator=g, device=DEV) < 0.01] *= 20.0
+    x = x.to(TDT[dt])
+    offs = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32, device=DEV)
+    s1 = (torch.rand(G, generator=g, device=DEV) * 2e-4 + 1e-4)
+    s3 = (torch.rand(G, generator=g, device=DEV) * 2e-4 + 1e-4)
+    assert ops.grouped_gate_up_supported(M, F_, K, TDT[dt])
+    w_gu = ops.interleave_gate_up_stack(w1, w3)
+    w_img, col = ops.weight_offset_image(w_gu.view(G * 2 * F_, K))
+    xq, _ = ops.quantize_act(x, "per-tensor-round")
+    xo, _, row_off = ops.quantize_act_off(x, "per-tensor-round")
+    gate = ops.linear_w8a8_grouped(xq, w1, offs, s1, TDT[dt])
+    up = ops.linear_w8a8_grouped(xq, w3, offs, s3, TDT[dt])
+    for fast in (False, True):
+        a = ops.linear_w8a8_grouped_gate_up(xq, w_gu, offs, s1, s3, TDT[dt], fast)
+        for rep in range(2):   # (the tail split's tickets must be back at zero)
+            a_img = ops.linear_w8a8_grouped_gate_up(xo, w_img.view(G, 2 * F_, K), offs, s1, s3, TDT[dt], fast, row_off, col)
+            assert torch.equal(a.view(torch.int16), a_img.view(torch.int16)), (counts, dt, fast, "images", rep)
+        for per_token, qs in ((True, 1.0), (False, 0.013)):
+            want = ops.silu_mul_quantize(gate, up, per_token, qs, fast=fast)
+            got = ops.quantize_act(a, "per-token" if per_token else "per-tensor-div", qs)
+            assert torch.equal(got[0], want[0]), (counts, dt, fast, per_token)
+            if per_token:
+                assert torch.equal(got[1], want[1])
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("counts", [[300, 0, 70, 513, 129], [256, 256], [1, 127, 128, 255, 257, 640]])
+def test_grouped_gate_up_equals_the_composition(dt, counts):
+    _check(counts, 384, 512, dt, 7 + len(counts))
+
+
+def test_grouped_gate_up_at_mixtral_size_with_the_bench_routing():
+    p = torch.ones(8)
+    counts = torch.bincount(torch.multinomial(p / p.sum(), 8192, replacement=True, generator=torch.Generator().manual_seed(1234)), minlength=8).tolist()
+    _check(counts, 14336, 4096, "f16", 99)
+    _check([4096, 2048, 1024, 512, 256, 256, 0, 0], 14336, 4096, "f16", 100)
+
+
+def test_refusals():
+    from autosmoothquant_amd import ops
+    assert not ops.grouped_gate_up_supported(512, 200, 512, torch.float16)     # F % 128
+    assert not ops.grouped_gate_up_supported(512, 256, 500, torch.float16)     # K % 128
+    assert not ops.grouped_gate_up_supported(512, 256, 512, torch.float32)
+    xq = torch.zeros(8, 512, dtype=torch.int8, device=DEV)
+    w = torch.zeros(2, 400, 512, dtype=torch.int8, device=DEV)
+    offs = torch.tensor([0, 4, 8], dtype=torch.int32, device=DEV)
+    s = torch.ones(2, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.linear_w8a8_grouped_gate_up(xq, w, offs, s, s, torch.float16)
