@@ -166,6 +166,23 @@ def make_moe_workload(device, seed, dtype, skew=False):
         r = ops.silu_mul_quantize(h1, h3, per_token=True, fast=fast, offsets=images)
         return glin(r[0], r[2] if images else None, "w2", r[1])
 
+    if ops.grouped_gate_up_supported(R, F_, H, dtype):
+        # round 5: w1 || w3 of all experts as ONE grouped launch whose epilogue writes SiLU(w1 x) * (w3 x) (asq_linear_w8a8_grouped_gate_up); the per-token quantiser for w2 follows
+        st["w13"] = ops.interleave_gate_up_stack(st["w1"], st["w3"])
+        if images:
+            img, col = ops.weight_offset_image(st["w13"].view(-1, H))
+            st["w13_img"], st["w13_col"] = img.view(st["w13"].shape), col
+
+        def gate_up(fast=True):
+            xq, _, ro = quant(st["x"], "per-tensor-round")
+            if ro is not None:
+                a = ops.linear_w8a8_grouped_gate_up(xq, st["w13_img"], st["offs"], st["s1"], st["s3"], dtype, fast, ro, st["w13_col"])
+            else:
+                a = ops.linear_w8a8_grouped_gate_up(xq, st["w13"], st["offs"], st["s1"], st["s3"], dtype, fast)
+            aq, srow, ao = quant(a, "per-token")
+            return glin(aq, ao, "w2", srow)
+        st["grouped_gate_up"] = gate_up
+
     st["grouped_fused"] = lambda: fused(False)        # N1: SiLU(w1 x) * (w3 x) -> int8 in one pass instead of silu, mul and the per-token quantiser
     st["grouped_fused_fast"] = lambda: fused(True)    # ... with the opt-in hardware exp2/rcp SiLU (ASQ_SILU_FAST: +-1 int8 of the exact kernel, asserted in tests/test_hip_n1.py)
 
@@ -587,7 +604,9 @@ def other_configs_block(device, tdt):
     st, grouped, _seq = make_moe_workload(device, 1234, tdt)
     ops_ = 2.0 * 8192 * 3 * 4096 * 14336
     cfg5 = {"workload": "BASELINE configs[4]: Mixtral-8x7B expert MLPs, 4096 tokens x top-2 = 8192 routed rows, one grouped launch per projection", "operands": st.get("operands", "plain")}
-    for tag, fn in (("grouped_torch_silu", grouped), ("grouped_fused_silu", st.get("grouped_fused_fast") or st.get("grouped_fused"))):
+    if "grouped_gate_up" in st:   # same int8 into w2 as the fused SiLU kernel's path, bit for bit
+        assert torch.equal(st["grouped_gate_up"](), st["grouped_fused_fast"]()), "grouped gate || up launch != w1, w3 launches + fused SiLU"
+    for tag, fn in (("grouped_torch_silu", grouped), ("grouped_fused_silu", st.get("grouped_fused_fast") or st.get("grouped_fused")), ("grouped_gate_up_gemm", st.get("grouped_gate_up"))):
         if fn is None:
             continue
         host, dev = _time_calls(fn, 20, 5)
@@ -929,6 +948,16 @@ def main():
                 st["grouped_fused"]()
             torch.cuda.synchronize()
             moe_extra["grouped_fused_silu_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
+        if "grouped_gate_up" in st:
+            assert torch.equal(st["grouped_gate_up"](), st["grouped_fused_fast"]()), "grouped gate || up launch != w1, w3 launches + fused SiLU"
+            for _ in range(5):
+                st["grouped_gate_up"]()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                st["grouped_gate_up"]()
+            torch.cuda.synchronize()
+            moe_extra["grouped_gate_up_gemm_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
         if "grouped_fused_fast" in st:
             for _ in range(5):
                 st["grouped_fused_fast"]()

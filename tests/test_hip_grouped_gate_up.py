@@ -65,5 +65,5 @@ def test_refusals():
     w = torch.zeros(2, 400, 512, dtype=torch.int8, device=DEV)
     offs = torch.tensor([0, 4, 8], dtype=torch.int32, device=DEV)
     s = torch.ones(2, device=DEV)
-    with pytest.raises(RuntimeError):
+    with pytest.raises(ValueError):                                            # F = 200: ASQ_ERR_DIM
         ops.linear_w8a8_grouped_gate_up(xq, w, offs, s, s, torch.float16)
