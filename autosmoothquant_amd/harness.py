@@ -618,6 +618,29 @@ class MixtralLayer(LlamaLayer):
             self.__dict__[f"_{name}_image"] = hit
         return hit[1]
 
+    def _w13_operand(self, want_image):
+        """w1 || w3 of every expert interleaved in blocks of 16 channels, [E, 2F, K] (ops.interleave_gate_up_stack), and its offset image when asked for: the operand
+        of the grouped gate || up launch (opt-in `fuse_gate_up`: one more int8 copy of the two stacks, plus the image).  Follows the stacks (storage + version)."""
+        from . import ops
+        s1, s3 = self._w1_stack, self._w3_stack
+        try:
+            key = (s1.data_ptr(), s1._version, s3.data_ptr(), s3._version, s1.device)
+        except RuntimeError:
+            return None, None
+        hit = self.__dict__.get("_w13_cache")
+        if hit is None or hit[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                return None, None
+            hit = [key, ops.interleave_gate_up_stack(s1, s3), None]
+            self.__dict__["_w13_cache"] = hit
+        if want_image and hit[2] is None:
+            if torch.cuda.is_current_stream_capturing():
+                return hit[1], None
+            E, N2, K = hit[1].shape
+            img, col = ops.weight_offset_image(hit[1].view(E * N2, K))
+            hit[2] = (img.view(E, N2, K), col)
+        return hit[1], hit[2]
+
     def refresh_offset_images(self):
         """Rebuild the three stacks' images from the current stacks into their existing buffers (after a weight update, before replaying a hipGraph captured
         on them; see _W8A8Base.refresh_offset_image)."""
@@ -662,7 +685,25 @@ class MixtralLayer(LlamaLayer):
                 i1, i3, i2 = (self._stack_image(n) for n in ("w1", "w3", "w2"))
             else:
                 i1 = None
-            if i1 is not None and i3 is not None and i2 is not None:
+            F2 = self._w1_stack.shape[1]
+            gate_up = (getattr(self, "fuse_gate_up", False) and mode != "per-token" and ops.grouped_gate_up_supported(R, F2, H, x.dtype))
+            if gate_up:
+                # opt-in (round 5): w1 || w3 of all experts as ONE grouped launch whose epilogue writes SiLU(w1 x) * (w3 x) -- the fused-SiLU arithmetic (+-1 int8 of torch's
+                # silu at rounding boundaries, like ops.silu_mul_quantize), which is why the reference composition below stays the default
+                w13, img13 = self._w13_operand(i1 is not None and i2 is not None)
+                gate_up = w13 is not None
+            if gate_up:
+                if img13 is not None and i2 is not None:
+                    xq, _, ro = ops.quantize_act_off(xs.contiguous(), mode, qs)
+                    a = ops.linear_w8a8_grouped_gate_up(xq, img13[0], offs, self._w1_scale, self._w3_scale, x.dtype, getattr(self, "fast_silu", None), ro, img13[1])
+                    aq, arow, ao = ops.quantize_act_off(a, "per-token")
+                    y = ops.linear_w8a8_grouped_off(aq, i2[0], ao, i2[1], offs, self._w2_scale, x.dtype, arow)
+                else:
+                    xq, _ = ops.quantize_act(xs.contiguous(), mode, qs)
+                    a = ops.linear_w8a8_grouped_gate_up(xq, w13, offs, self._w1_scale, self._w3_scale, x.dtype, getattr(self, "fast_silu", None))
+                    aq, arow = ops.quantize_act(a, "per-token")
+                    y = ops.linear_w8a8_grouped(aq, self._w2_stack, offs, self._w2_scale, x.dtype, arow)
+            elif i1 is not None and i3 is not None and i2 is not None:
                 xq, srow, ro = ops.quantize_act_off(xs.contiguous(), mode, qs)
                 h1 = ops.linear_w8a8_grouped_off(xq, i1[0], ro, i1[1], offs, self._w1_scale, x.dtype, srow)
                 h3 = ops.linear_w8a8_grouped_off(xq, i3[0], ro, i3[1], offs, self._w3_scale, x.dtype, srow)

@@ -67,3 +67,41 @@ def test_refusals():
     s = torch.ones(2, device=DEV)
     with pytest.raises(ValueError):                                            # F = 200: ASQ_ERR_DIM
         ops.linear_w8a8_grouped_gate_up(xq, w, offs, s, s, torch.float16)
+
+
+def test_mixtral_layer_opt_in_equals_the_fused_silu_composition():
+    """harness.MixtralLayer.moe with fuse_gate_up: the grouped gate || up launch gives the expert outputs of grouped w1, grouped w3 + ops.silu_mul_quantize (same SiLU
+    form) bit for bit, on offset images and on plain operands; against the default (torch SiLU) composition it moves a few activations across int8 rounding boundaries."""
+    from autosmoothquant_amd import harness, ops
+    torch.manual_seed(5)
+    fl = harness.MixtralLayer(256, 384, 4, 2, experts=4, top_k=2)
+    with torch.no_grad():
+        for p in fl.parameters():
+            if p.dim() == 2:
+                p.copy_(torch.randn(p.shape) * 0.05)
+    lay = harness.to_w8a8_mixtral(fl, {"attn_in": 0.05, "o_in": 0.05, "mlp_in": 0.05, "down_in": [0.05, 0.06, 0.07, 0.08]}).to(DEV).half()
+    lay.stack_experts()
+    x = (torch.randn(2, 320, 256, device=DEV) * 2).half()
+    with torch.no_grad():
+        for offsets in (True, False):
+            lay.offsets = offsets
+            lay.fuse_gate_up = False
+            base = lay.moe(x)
+            for fast in (False, True):
+                lay.fuse_gate_up, lay.fast_silu = True, fast
+                got = lay.moe(x)
+                # the composition with the fused SiLU kernel, spelled out
+                x2 = x.reshape(-1, 256)
+                tok, wts, counts = lay.route(x2)
+                xs = x2[tok].contiguous()
+                offs = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int32)
+                mode, qs = lay.experts[0].w1._input_mode()
+                xq, _ = ops.quantize_act(xs, mode, qs)
+                h1 = ops.linear_w8a8_grouped(xq, lay._w1_stack, offs, lay._w1_scale, torch.float16)
+                h3 = ops.linear_w8a8_grouped(xq, lay._w3_stack, offs, lay._w3_scale, torch.float16)
+                aq, arow = ops.silu_mul_quantize(h1, h3, True, 1.0, fast=fast)
+                y = ops.linear_w8a8_grouped(aq, lay._w2_stack, offs, lay._w2_scale, torch.float16, arow)
+                want = torch.zeros_like(x2)
+                want.index_add_(0, tok, y * wts[:, None])
+                assert torch.equal(got.reshape(-1, 256), want), (offsets, fast)
+                assert float((got - base).abs().max()) <= 0.05 * float(base.abs().max()) + 1e-3
