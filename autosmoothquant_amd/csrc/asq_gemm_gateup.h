@@ -11,12 +11,16 @@
 // Runs on the persistent 256 x 256 kernel (gemm_i8_p16p) only: multi-round prefill launches, M % 256 == 0, F % 128 == 0, K % 256 == 0.
 #pragma once
 #include "asq_silu_core.h"
+#include "asq_quant_core.h"
 
 namespace asq {
 
-template <int DT, bool HAS_ROW> struct EpiGateUp {
+// Q8 (round 5, last session): the consumer is a per-tensor linear (reference models/llama.py:228-235 with fc2 per-tensor: x.div(input_scale).round().clamp -- linear.py:289-292),
+// so the epilogue goes one step further and stores int8(clamp(round(dt(a / quant_scale)))) -- the per-tensor-div quantiser's arithmetic (asq_quant_core.h) on the same dt(a):
+// out int8 [M, F], a QUARTER of the two fp tensors' bytes, and the consumer's quantiser launch disappears.
+template <int DT, bool HAS_ROW, bool Q8 = false> struct EpiGateUp {
     using Mma = MmaI8;
-    static constexpr bool kHasRow = HAS_ROW, kHasCol = false, kHasBias = false, kGateUp = true;
+    static constexpr bool kHasRow = HAS_ROW, kHasCol = false, kHasBias = false, kGateUp = true, kQ8 = Q8;
     static constexpr int kOutBytes = 2;
     static_assert(DT == ASQ_F16 || DT == ASQ_BF16, "2-byte activations");
     void *out;           // [M, F]
@@ -24,6 +28,7 @@ template <int DT, bool HAS_ROW> struct EpiGateUp {
     const float *s_row;  // [M]  (HAS_ROW: per-token activation scales)
     float s_gate, s_up, s_scalar;   // dequant scales of the two projections (s_scalar: unused, keeps the functor interface)
     int fast;
+    float qs = 1.0f, qy = 0.0f;   // Q8: the consumer's quant_scale and RN(1 / quant_scale) (0: outside the fast division's range, divide)
     const float *sg_group = nullptr, *su_group = nullptr;   // grouped launch (asq_linear_w8a8_grouped_gate_up): per-group dequant scales [ngroups]
     static constexpr bool kGroupable = true;
     __device__ __forceinline__ EpiGateUp rebased(int grp, int, int64_t, int64_t) const
@@ -67,6 +72,17 @@ template <int DT, bool HAS_ROW> struct EpiGateUp {
         }
         return (v2u){o[0], o[1]};
     }
+    // Q8: the four dt values of pack_gate_up quantised like asq_quantize_act(.., ASQ_ACT_DIV, quant_scale) would quantise them
+    __device__ __forceinline__ uint32_t quantise4(const v2u &a) const
+    {
+        int r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = ElemT<DT>::load((uint16_t)(a[i >> 1] >> (16 * (i & 1))));
+            r[i] = qy != 0.0f ? QDivFast<DT>{qs, qy}(v) : QDiv<DT>{qs}(v);
+        }
+        return pack4(r[0], r[1], r[2], r[3]);
+    }
 };
 
 // (IsGateUp<Epi>: asq_gemm_kernels.h, in front of the kernels)
@@ -78,10 +94,12 @@ template <class EL, class Get> __device__ __forceinline__ void epilogue_gate_up(
 {
     const auto &e = el.e;
     const int t = lane & 15, q = lane >> 4;
-    const unsigned ldb = __builtin_amdgcn_readfirstlane((unsigned)(e.N * 2));   // output row pitch in bytes (128 * ldb < 2^31: the launcher checks)
-    const uint64_t tile = (uint64_t)(uintptr_t)uniform_ptr((const int8_t *)e.out + (mw0 * e.N + (nw0 >> 1)) * 2);
-    const unsigned voff = (unsigned)t * ldb + (unsigned)q * 8;
+    constexpr int OB = std::remove_reference_t<decltype(e)>::kQ8 ? 1 : 2;   // bytes per output element
+    const unsigned ldb = __builtin_amdgcn_readfirstlane((unsigned)(e.N * OB));   // output row pitch in bytes (128 * ldb < 2^31: the launcher checks)
+    const uint64_t tile = (uint64_t)(uintptr_t)uniform_ptr((const int8_t *)e.out + (mw0 * e.N + (nw0 >> 1)) * OB);
+    const unsigned voff = (unsigned)t * ldb + (unsigned)q * (4 * OB);
     typedef __attribute__((address_space(1))) v2u *glb_v2u;
+    typedef __attribute__((address_space(1))) uint32_t *glb_u32;
     float sr[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) sr[i] = el.row(mw0 + i * 16 + t);
@@ -92,7 +110,8 @@ template <class EL, class Get> __device__ __forceinline__ void epilogue_gate_up(
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const v2u o = (im16 == 0 && p == 0) ? first : e.pack_gate_up(get(2 * p, im16), get(2 * p + 1, im16), sr[im16]);
-            *(glb_v2u)(uintptr_t)(tile + (uint64_t)((unsigned)(im16 * 16) * ldb + (unsigned)(p * 32)) + voff) = o;
+            if constexpr (OB == 2) *(glb_v2u)(uintptr_t)(tile + (uint64_t)((unsigned)(im16 * 16) * ldb + (unsigned)(p * 32)) + voff) = o;
+            else *(glb_u32)(uintptr_t)(tile + (uint64_t)((unsigned)(im16 * 16) * ldb + (unsigned)(p * 16)) + voff) = e.quantise4(o);
         }
 }
 

@@ -31,6 +31,48 @@ static int launch_gate_up(const int8_t *xq, const int8_t *w_gu, void *out, int64
     return asq_after_launch(s, "asq_linear_w8a8_gate_up");
 }
 
+template <int DT, bool ROW>
+static int launch_gate_up_q8(const int8_t *xq, const int8_t *w_gu, int8_t *out, int64_t M, int64_t F, int64_t K, float s_gate, float s_up, const float *s_row, int fast, float qs,
+                             OffsetArgs off, hipStream_t s)
+{
+    using Epi = EpiGateUp<DT, ROW, true>;
+    auto kfn = gemm_i8_p16p<Epi>;
+    const hipError_t e = ensure_dynamic_lds((const void *)kfn, P16P_LDS_BYTES);
+    if (e != hipSuccess) {
+        asq_set_error("asq_linear_w8a8_gate_up_q8: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    const int64_t N = 2 * F, tm = M / 256, tn = N / 256, T = tm * tn;
+    const int64_t grid = T < 8 * P8_CUS_PER_XCD ? T : 8 * P8_CUS_PER_XCD;
+    Epi epi{out, F, s_row, s_gate, s_up, 1.0f, fast};
+    epi.qs = qs;
+    epi.qy = (qs > 0x1p-60f && qs < 0x1p60f) ? 1.0f / qs : 0.0f;   // (asq_quantize_act's own choice between the two divisions: the same int8 either way)
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), P16P_LDS_BYTES, s, xq, w_gu, M, N, K, (int)tm, (int)tn, epi, off);
+    return asq_after_launch(s, "asq_linear_w8a8_gate_up_q8");
+}
+
+extern "C" int asq_linear_w8a8_gate_up_q8(const int8_t *xq, const int8_t *w_gu, int8_t *out_q, int act_dtype, int64_t M, int64_t F, int64_t K, float s_gate, float s_up,
+                                          const float *s_row, int flags, float quant_scale, const int32_t *row_off, const int32_t *col_off, void *stream)
+{
+    const AsqRange range_("asq_linear_w8a8_gate_up_q8");
+    ASQ_REQUIRE(M >= 0 && F >= 0 && K >= 0, ASQ_ERR_DIM, "asq_linear_w8a8_gate_up_q8: bad dims");
+    if (M == 0 || F == 0) return ASQ_OK;
+    ASQ_REQUIRE(xq != nullptr && w_gu != nullptr && out_q != nullptr, ASQ_ERR_NULL, "asq_linear_w8a8_gate_up_q8: NULL xq / w_gu / out_q");
+    ASQ_REQUIRE(act_dtype == ASQ_F16 || act_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_linear_w8a8_gate_up_q8: act_dtype must be ASQ_F16 or ASQ_BF16 (got %d)", act_dtype);
+    ASQ_REQUIRE((flags & ~ASQ_SILU_FAST) == 0, ASQ_ERR_DTYPE, "asq_linear_w8a8_gate_up_q8: flags is a bit field (ASQ_SILU_FAST), got %d", flags);
+    ASQ_REQUIRE(quant_scale > 0.0f && quant_scale == quant_scale, ASQ_ERR_DIM, "asq_linear_w8a8_gate_up_q8: quant_scale must be positive");
+    ASQ_REQUIRE(gate_up_shape(M, F, K, act_dtype), ASQ_ERR_DIM,
+                "asq_linear_w8a8_gate_up_q8: needs M %% 256 == 0, F %% 128 == 0, K %% 256 == 0, K <= 65536 and more than 256 tiles of 256 x 256 over [M, 2 F] (asq_gate_up_supported)");
+    ASQ_REQUIRE((((uintptr_t)xq | (uintptr_t)w_gu | (uintptr_t)out_q) & 15) == 0 && (((uintptr_t)s_row) & 3) == 0, ASQ_ERR_ALIGN, "asq_linear_w8a8_gate_up_q8: xq / w_gu / out_q must be 16-byte aligned");
+    ASQ_REQUIRE((row_off == nullptr) == (col_off == nullptr) && ((((uintptr_t)row_off | (uintptr_t)col_off) & 7) == 0), ASQ_ERR_ALIGN,
+                "asq_linear_w8a8_gate_up_q8: row_off and col_off come together (offset operand images), 8-byte aligned");
+    const OffsetArgs off{row_off, col_off};
+    const int fast = (flags & ASQ_SILU_FAST) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (act_dtype == ASQ_F16) return s_row ? launch_gate_up_q8<ASQ_F16, true>(xq, w_gu, out_q, M, F, K, s_gate, s_up, s_row, fast, quant_scale, off, s) : launch_gate_up_q8<ASQ_F16, false>(xq, w_gu, out_q, M, F, K, s_gate, s_up, s_row, fast, quant_scale, off, s);
+    return s_row ? launch_gate_up_q8<ASQ_BF16, true>(xq, w_gu, out_q, M, F, K, s_gate, s_up, s_row, fast, quant_scale, off, s) : launch_gate_up_q8<ASQ_BF16, false>(xq, w_gu, out_q, M, F, K, s_gate, s_up, s_row, fast, quant_scale, off, s);
+}
+
 extern "C" int asq_linear_w8a8_gate_up(const int8_t *xq, const int8_t *w_gu, void *out, int out_dtype, int64_t M, int64_t F, int64_t K, float s_gate, float s_up,
                                        const float *s_row, int flags, const int32_t *row_off, const int32_t *col_off, void *stream)
 {

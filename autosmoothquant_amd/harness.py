@@ -191,7 +191,7 @@ class LlamaLayer(torch.nn.Module):
         if gu is not None:
             from .layers.nn.fused import QuantizedActivation
             qa = x if isinstance(x, QuantizedActivation) else self.gate_proj.quantize_input(x, consumers=(gu,))
-            a = gu(qa, fast=getattr(self, "fast_silu", None))
+            a = gu(qa, fast=getattr(self, "fast_silu", None), consumer=self.down_proj)   # (a per-tensor down_proj gets int8 straight from the epilogue)
             if a is not None:
                 d = self.down_proj(a)
                 return DeferredResidual(h, d) if getattr(self, "defer_residual", False) else h + d

@@ -194,7 +194,9 @@ class GateUpSiLU(torch.nn.Module):
         return self.__dict__["_wgu_image"]
 
     @torch.no_grad()
-    def forward(self, qa, fast=None):
+    def forward(self, qa, fast=None, consumer=None):
+        """consumer (optional): the linear that reads the result.  A per-tensor consumer (a W8A8BFP32OFP32LinearWithQuantScale with act_quant "per-tensor") gets its
+        int8 input straight from the GEMM's epilogue (ops.linear_w8a8_gate_up_q8) as a QuantizedActivation; otherwise the [.., F] tensor in the activation dtype."""
         if not isinstance(qa, QuantizedActivation):
             raise TypeError("GateUpSiLU takes the QuantizedActivation its projections share (mod.quantize_input / a fused norm)")
         M = qa.xq.shape[0]
@@ -204,13 +206,19 @@ class GateUpSiLU(torch.nn.Module):
         if w is None:
             return None
         sg, su = self.gate._scalar("dequant_scale"), self.up._scalar("dequant_scale")
+        q8 = consumer is not None and getattr(consumer, "act_quant", None) == "per-tensor" and hasattr(consumer, "quant_scale") and consumer.in_features == self.out_features
+        qs = float(consumer.quant_scale) if q8 else None
+        ro = col = None
         if qa.row_off is not None:
             image = self.offset_image(M, qa.out_dtype)
             if image is not None:
-                out = ops.linear_w8a8_gate_up(qa.xq, image[0], qa.out_dtype, sg, su, qa.s_row, fast, qa.row_off, image[1])
-                return out.view(*qa.lead, self.out_features)
-            xq = qa.plain_xq()
+                xq, w, ro, col = qa.xq, image[0], qa.row_off, image[1]
+            else:
+                xq = qa.plain_xq()
         else:
             xq = qa.xq
-        out = ops.linear_w8a8_gate_up(xq, w, qa.out_dtype, sg, su, qa.s_row, fast)
+        if q8:
+            out = ops.linear_w8a8_gate_up_q8(xq, w, qa.out_dtype, sg, su, qs, qa.s_row, fast, ro, col)
+            return QuantizedActivation(out, None, qa.out_dtype, qa.lead)
+        out = ops.linear_w8a8_gate_up(xq, w, qa.out_dtype, sg, su, qa.s_row, fast, ro, col)
         return out.view(*qa.lead, self.out_features)

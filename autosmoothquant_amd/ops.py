@@ -282,6 +282,34 @@ def linear_w8a8_gate_up(xq, w_gu, out_dtype, s_gate, s_up, s_row=None, fast=None
     return out
 
 
+def linear_w8a8_gate_up_q8(xq, w_gu, act_dtype, s_gate, s_up, quant_scale, s_row=None, fast=None, row_off=None, col_off=None):
+    """linear_w8a8_gate_up with the consumer's per-tensor quantiser as part of the epilogue (asq_linear_w8a8_gate_up_q8): int8 [M, F] =
+    quantize_act(linear_w8a8_gate_up(..., act_dtype), "per-tensor-div", quant_scale)[0], bit for bit; the fp tensor never exists."""
+    _dev(xq, "xq"), _dev(w_gu, "w_gu")
+    if xq.dtype != torch.int8 or w_gu.dtype != torch.int8 or xq.dim() != 2 or w_gu.dim() != 2 or xq.shape[1] != w_gu.shape[1] or w_gu.shape[0] % 2:
+        raise ValueError("xq [M,K] and w_gu [2F,K] must be int8 with equal K")
+    if not (xq.is_contiguous() and w_gu.is_contiguous()):
+        raise ValueError("xq / w_gu must be contiguous")
+    M, K = xq.shape
+    F_ = w_gu.shape[0] // 2
+    if s_row is not None:
+        _dev(s_row, "s_row")
+        if s_row.dtype != torch.float32 or s_row.numel() != M:
+            raise ValueError(f"s_row must be float32 with {M} elements")
+    if (row_off is None) != (col_off is None):
+        raise ValueError("row_off and col_off come together")
+    if row_off is not None and (row_off.dtype != torch.int32 or row_off.numel() != 2 * M or col_off.dtype != torch.int32 or col_off.numel() != 4 * F_):
+        raise ValueError("row_off must be int32 [M,2] and col_off int32 [2F,2]")
+    if fast is None:
+        fast = not SILU_EXACT_DEFAULT
+    out = torch.empty((M, F_), dtype=torch.int8, device=xq.device)
+    dev = _same_device(xq, w_gu, out, s_row, row_off, col_off)
+    with _on(dev):
+        L.check(L.lib().asq_linear_w8a8_gate_up_q8(xq.data_ptr(), w_gu.data_ptr(), out.data_ptr(), _DT[act_dtype], M, F_, K, float(s_gate), float(s_up), _ptr(s_row),
+                                                   L.ASQ_SILU_FAST if fast else 0, float(quant_scale), _ptr(row_off), _ptr(col_off), _stream(xq)), "asq_linear_w8a8_gate_up_q8")
+    return out
+
+
 def grouped_gate_up_supported(M, F_, K, out_dtype):
     return out_dtype in (torch.float16, torch.bfloat16) and bool(L.lib().asq_grouped_gate_up_supported(M, F_, K, _DT[out_dtype]))
 

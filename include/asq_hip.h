@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ASQ_VERSION 121 /* 0.1.3: + asq_grouped_gate_up_supported, asq_linear_w8a8_grouped_gate_up (Mixtral's w1 || w3 as one grouped launch with the SiLU * up epilogue); 0.1.2: + asq_forward_fused_supported, asq_linear_w8a8_forward_fused (the one-launch forward for decode-sized inputs; asq_linear_w8a8_forward takes it
+#define ASQ_VERSION 122 /* 0.1.4: + asq_linear_w8a8_gate_up_q8 (gate || up with an int8-out epilogue for per-tensor consumers); 0.1.3: + asq_grouped_gate_up_supported, asq_linear_w8a8_grouped_gate_up (Mixtral's w1 || w3 as one grouped launch with the SiLU * up epilogue); 0.1.2: + asq_forward_fused_supported, asq_linear_w8a8_forward_fused (the one-launch forward for decode-sized inputs; asq_linear_w8a8_forward takes it
                            * by itself where it wins); ASQ_ROCTX=1 ranges.  0.1.1: + offset operand images (asq_*_off); workspace sizes include the 8 KiB header
                            * (asq_workspace_init is mandatory for a workspace handed to a GEMM entry point); asq_silu_mul_quantize's `per_token` is a bit field (bit 0
                            * per-token, ASQ_SILU_FAST) */
@@ -275,6 +275,12 @@ int asq_add_norm_quantize_off(const void *x, const void *residual, void *h_out, 
 int asq_gate_up_supported(int64_t M, int64_t F, int64_t K, int out_dtype);
 int asq_linear_w8a8_gate_up(const int8_t *xq, const int8_t *w_gu, void *out, int out_dtype, int64_t M, int64_t F, int64_t K,
                             float s_gate, float s_up, const float *s_row, int flags, const int32_t *row_off, const int32_t *col_off, void *stream);
+/* The int8-out form for a per-tensor consumer (round 5, last session: reference models/llama.py:228-235 with fc2 per-tensor; its prologue linear.py:289-292): out_q int8 [M, F] =
+ * asq_quantize_act(ASQ_ACT_DIV, quant_scale) of the [M, F] tensor asq_linear_w8a8_gate_up would have written in act_dtype (ASQ_F16 / ASQ_BF16: the dtype every intermediate is
+ * rounded in) -- bit-identical to that composition and to asq_silu_mul_quantize(per-tensor) behind the two linears; the consumer's quantiser launch and the fp tensor disappear.
+ * Same shapes as asq_linear_w8a8_gate_up (asq_gate_up_supported); quant_scale > 0. */
+int asq_linear_w8a8_gate_up_q8(const int8_t *xq, const int8_t *w_gu, int8_t *out_q, int act_dtype, int64_t M, int64_t F, int64_t K, float s_gate, float s_up,
+                               const float *s_row, int flags, float quant_scale, const int32_t *row_off, const int32_t *col_off, void *stream);
 /* The grouped form (round 5, last session): Mixtral's experts (reference models/mixtral.py:99-101,142-145: w2(act(w1 x) * w3 x) per expert) -- w1 || w3 of ALL experts as ONE
  * grouped launch whose epilogue writes SiLU(w1 x) * (w3 x): asq_linear_w8a8_grouped[_off]'s launch (rows sorted by group, group_offsets[0 .. ngroups], device-side tile
  * scheduler, half tiles, in-launch K split of the tail round with a workspace) over w_gu int8 [ngroups, 2 F, K], each group's rows interleaved as above; s_gate / s_up

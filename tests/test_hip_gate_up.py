@@ -70,7 +70,37 @@ def test_unsupported_shapes_are_refused_and_the_module_falls_back():
         ops.linear_w8a8_gate_up(xq, w, f16, 1.0, 1.0)
 
 
-@pytest.mark.parametrize("cfg", [None, {"qkv": "per-token", "fc1": "per-token"}])
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_int8_out_epilogue_equals_the_per_tensor_quantiser_behind_it(dt):
+    """asq_linear_w8a8_gate_up_q8 (a per-tensor consumer's int8 input straight from the epilogue) == quantize_act(gate || up GEMM's tensor, per-tensor-div, quant_scale) ==
+    silu_mul_quantize(per-tensor) behind the two linears: both SiLU forms, per-tensor and per-token activations, plain and images, quant scales inside and outside the fast
+    division's range (the huge quotients saturate alike)."""
+    from autosmoothquant_amd import ops
+    M, F, K = 4096, 2304, 512
+    wg, wu, x = _case(M, F, K, 77)
+    xh = x.to(TDT[dt])
+    w_gu = ops.interleave_gate_up(wg, wu)
+    image = ops.weight_offset_image(w_gu)
+    sg, su = 2.1e-4, 1.7e-4
+    for mode in ("per-tensor-round", "per-token"):
+        xq, s_row = ops.quantize_act(xh, mode)
+        xo, s_row_o, row_off = ops.quantize_act_off(xh, mode)
+        gate = ops.linear_w8a8(xq, wg, TDT[dt], sg, s_row)
+        up = ops.linear_w8a8(xq, wu, TDT[dt], su, s_row)
+        for fast in (False, True):
+            a = ops.linear_w8a8_gate_up(xq, w_gu, TDT[dt], sg, su, s_row, fast)
+            for qs in (0.013, 0.37, 3e-5, 1e-19):
+                want = ops.quantize_act(a, "per-tensor-div", qs)[0]
+                got = ops.linear_w8a8_gate_up_q8(xq, w_gu, TDT[dt], sg, su, qs, s_row, fast)
+                got_img = ops.linear_w8a8_gate_up_q8(xo, image[0], TDT[dt], sg, su, qs, s_row_o, fast, row_off, image[1])
+                assert torch.equal(got, want), (dt, mode, fast, qs)
+                assert torch.equal(got_img, want), (dt, mode, fast, qs, "images")
+                if qs > 1e-10:
+                    assert torch.equal(got, ops.silu_mul_quantize(gate, up, False, qs, fast=fast)[0]), (dt, mode, fast, qs, "composition")
+            assert int((ops.linear_w8a8_gate_up_q8(xq, w_gu, TDT[dt], sg, su, 0.013, s_row, fast).to(torch.int16).abs() > 0).sum()) > M * F // 10   # (not a table of zeros)
+
+
+@pytest.mark.parametrize("cfg", [None, {"qkv": "per-token", "fc1": "per-token"}, {"out": "per-tensor", "fc2": "per-tensor"}])
 def test_llama_layer_fused_path_with_and_without_the_gate_up_gemm(cfg):
     """harness.LlamaLayer (hidden 512, inter 1536): the N1-fused path with the gate || up GEMM == the same path with two linears + silu_mul_q, bit for bit"""
     from autosmoothquant_amd import harness
