@@ -32,6 +32,38 @@ for M in map(int, args.ms.split(",")):
         ops.linear_w8a8_gate_up(xo, img_gu[0], torch.float16, 2e-4, 2e-4, None, None, ro, img_gu[1], out=bufs["a"])
         return ops.quantize_act_off(bufs["a"], "per-token" if per_token else "per-tensor-div", 0.02)
 
+    # round 5, last session: a per-tensor consumer's int8 straight from the epilogue (asq_linear_w8a8_gate_up_q8), and what the consumer's GEMM pays for running on plain
+    # activations behind it (down_proj: [M, F] x [K, F]^T on images after the quantiser vs on the plain int8 of the epilogue)
+    wd = (torch.randn(K, F, device=dev, generator=g) * 22).round().clamp(-128, 127).to(torch.int8)
+    img_d = ops.weight_offset_image(wd)
+    dbuf = torch.empty((M, K), dtype=torch.float16, device=dev)
+
+    def mlp_fused_quantiser():
+        aq, _, aro = fused(False)
+        return ops.linear_w8a8_off(aq, img_d[0], aro, img_d[1], torch.float16, 2e-4, out=dbuf)
+
+    def mlp_q8():
+        aq = ops.linear_w8a8_gate_up_q8(xo, img_gu[0], torch.float16, 2e-4, 2e-4, 0.02, None, None, ro, img_gu[1])
+        return ops.linear_w8a8(aq, wd, torch.float16, 2e-4, out=dbuf)
+
+    y0 = mlp_fused_quantiser().clone()
+    same_q8 = torch.equal(y0, mlp_q8())
+    tq = {"quantiser": [], "q8": []}
+    for fn in (mlp_fused_quantiser, mlp_q8):
+        for _ in range(4):
+            fn()
+    torch.cuda.synchronize()
+    for r in range(8):
+        for name, fn in ((("quantiser", mlp_fused_quantiser), ("q8", mlp_q8)) if r % 2 == 0 else (("q8", mlp_q8), ("quantiser", mlp_fused_quantiser))):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            e1.synchronize()
+            tq[name].append(e0.elapsed_time(e1) / 5 * 1e3)
+    m0, m1 = (sorted(tq[k])[len(tq[k]) // 2] for k in ("quantiser", "q8"))
+    print(f"M={M} F={F} K={K} whole MLP, per-tensor down_proj: gate||up + quantiser + down on images {m0:.1f} us | gate||up with int8-out epilogue + down on plain activations {m1:.1f} us  ratio {m1 / m0:.4f}  outputs equal {same_q8}", flush=True)
     for per_token in (True, False):
         a, b = composed(per_token), fused(per_token)
         same = torch.equal(a[0], b[0]) and (a[1] is None or torch.equal(a[1], b[1]))
