@@ -400,13 +400,15 @@ __global__ void __launch_bounds__(256) quant_rows_wave(const void *__restrict__ 
     finish(a, row);
 }
 
-// true when a launch was made (rows of up to 64 * VEC * 24 elements)
+// true when a launch was made (rows of up to 64 * VEC * 28 elements)
 template <int DT, class Q, bool PT, bool OFF>
 bool launch_rows_wave(const void *x, int8_t *xq, float *s_row, int32_t *row_off, int64_t M, int64_t K, Q q, int C, hipStream_t s)
 {
     constexpr int VEC = ElemT<DT>::VEC;
     const int64_t nvec = K / VEC;
-    if (nvec > 64 * 24 || M >= (1ll << 31)) return false;
+    // (28 vectors per lane for per-token rows only: Mixtral's F = 14336 in fp16, the quantiser in front of w2 -- 64.1 instead of 74.5 us at 8192 rows, round 5; the per-tensor
+    // forms of that length run out of registers -- 262 VGPRs, 3.5 TB/s measured -- and stay on the block-per-row kernels)
+    if (nvec > 64 * (PT ? 28 : 24) || M >= (1ll << 31)) return false;
     const int nv = (int)((nvec + 63) / 64);
     dim3 grid((unsigned)((M + 3) / 4)), block(256);
 #define ASQ_RW(NV) hipLaunchKernelGGL((quant_rows_wave<DT, NV, Q, PT, OFF>), grid, block, 0, s, x, xq, s_row, row_off, (int)M, (int)K, q, C)
@@ -419,7 +421,10 @@ bool launch_rows_wave(const void *x, int8_t *xq, float *s_row, int32_t *row_off,
     else if (nv <= 12) ASQ_RW(12);
     else if (nv <= 16) ASQ_RW(16);
     else if (nv <= 22) ASQ_RW(22);
-    else ASQ_RW(24);
+    else if (nv <= 24) ASQ_RW(24);
+    else {
+        if constexpr (PT) ASQ_RW(28);
+    }
 #undef ASQ_RW
     return true;
 }

@@ -43,7 +43,7 @@ def test_weight_image_equals_oracle():
 def test_quantize_act_off_is_quantize_act_plus_row_offsets(dt, mode):
     from autosmoothquant_amd import ops
     rng = np.random.default_rng(7)
-    for (M, K) in ((1, 128), (9, 1024), (67, 4096), (5, 11008), (3, 20480), (2, 40960)):
+    for (M, K) in ((1, 128), (9, 1024), (67, 4096), (5, 11008), (7, 14336), (6, 13312), (3, 20480), (2, 40960)):   # (14336 / 13312: 28 vectors per lane in the 2-byte per-token form)
         if dt == "f32" and K > 20480:
             continue
         x = rng.standard_normal((M, K)).astype(np.float32) * (1.4 if mode != "per-tensor-div" else 0.05)

@@ -219,7 +219,7 @@ def test_gemm_unaligned_operands_take_generic_path(dev):
 
 @pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
 @pytest.mark.parametrize("shape", [(5, 64), (33, 320), (7, 4096), (3, 11008), (2, 20480), (4, 24584), (9, 77),
-                                   (1030, 512), (1500, 4096), (1025, 1000)])  # >= 1024 rows: wave-per-row kernel
+                                   (1030, 512), (1500, 4096), (1025, 1000), (1026, 14336), (1100, 13312)])  # >= 1024 rows: wave-per-row kernel (the last two: 28 vectors per lane in fp16 / bf16)
 def test_quantize_act_vs_oracle(dt, shape, dev):
     from autosmoothquant_amd import ops
     M, K = shape
