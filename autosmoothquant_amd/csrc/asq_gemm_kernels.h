@@ -755,9 +755,11 @@ template <class Epi> __device__ __forceinline__ bool rows_write_through(int64_t 
 // other LDS stage already holds the next tile's operands; a wave's LDS operations execute in order, so rewriting an image behind its own reads is safe).
 // DRAIN: `s_waitcnt vmcnt(0)` between the first tile's conversions and the first store (gemm_i8_p16p: retires the next tile's in-flight operand DMAs at a point
 // where only they are outstanding -- behind ~500 cycles of VALU work, before any store joins the counter).
-template <int NTM, int NTN, bool L16 = false, int IMGS = NTM, bool DRAIN = false, class Epi, class Get>
+// IM0, IM1: only the token tiles [IM0, IM1) of the wave tile (gemm_i8_p16's tail: the wave tile's upper 64 rows leave while the lower 64 still accumulate).
+template <int NTM, int NTN, bool L16 = false, int IMGS = NTM, bool DRAIN = false, int IM0 = 0, int IM1 = NTM, class Epi, class Get>
 __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int64_t mw0, int64_t nw0, int lane, unsigned stage, bool wt = false)
 {
+    static_assert(0 <= IM0 && IM0 < IM1 && IM1 <= NTM, "token-tile range");
     static_assert(Epi::kOutBytes == 2, "2-byte outputs");
     static_assert(NTN == 2 || NTN == 4, "wave tile of 64 or 128 channels");
     typedef __attribute__((address_space(3))) v2u *lds_u2;
@@ -773,7 +775,7 @@ __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int6
 
     float sr[NSR];
 #pragma unroll
-    for (int i = 0; i < NSR; ++i) sr[i] = Epi::kHasRow ? epi.row(mw0 + i * (L16 ? 16 : 32) + ml) : 1.0f;
+    for (int i = 0; i < NSR; ++i) sr[i] = (Epi::kHasRow && i >= IM0 * (NSR / NTM) && i < IM1 * (NSR / NTM)) ? epi.row(mw0 + i * (L16 ? 16 : 32) + ml) : 1.0f;
     v4f sc[L16 ? 2 * NTN : NTN][NSC], bb[L16 ? 2 * NTN : NTN][NSC];
     if constexpr (L16) {
 #pragma unroll
@@ -836,10 +838,10 @@ __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int6
             }
         }
     };
-    pack_tile(0);
+    pack_tile(IM0);
     if constexpr (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int im = 0; im < NTM; ++im) {
+    for (int im = IM0; im < IM1; ++im) {
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
         v2u lo[NRD], up[NRD];
@@ -849,7 +851,7 @@ __device__ __forceinline__ void epilogue_wave_rows(const Epi &epi, Get get, int6
             up[i] = *(lds_u2)(uintptr_t)(ra1[i] + (im % IMGS) * IMG);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (im + 1 < NTM) pack_tile(im + 1);
+        if (im + 1 < IM1) pack_tile(im + 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NRD; ++i) {
@@ -1629,6 +1631,16 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
                 epi.N * 2 < (int64_t(1) << 24)) {
                 const int64_t grid = T < 8 * P8_CUS_PER_XCD ? T : 8 * P8_CUS_PER_XCD;
                 rc = launch_tiled(gemm_i8_p16p<Epi>, P16P_LDS_BYTES, P16P_LDS_BYTES, grid, 512, (int)tm256, (int)tn256, epi, off);
+                done = true;
+            }
+        }
+        if constexpr (kP16 && Epi::kOutBytes == 2 && ASQ_P16_TAIL != 0) {
+            // (builds with -DASQ_P16_TAIL=1 only; measured and NOT shipped, profiles/r6_tail_overlap_ab.txt)  launches of interior tiles only, with an even number >= 4
+            // of K-tiles and aligned output rows: the kernel whose last two K-tiles run m-half first, so that half of every block's epilogue leaves under its last
+            // 64 MFMAs per wave (asq_gemm_p16.h, "THE TAIL").  ASQ_P16_TAIL=0 in the environment keeps the plain end (A/B inside one build).
+            static const int tail = [] { const char *e = getenv("ASQ_P16_TAIL"); return e ? atoi(e) : 1; }();
+            if (!done && tail && M % 256 == 0 && N % 256 == 0 && K % 256 == 0 && K >= 512 && ((((uintptr_t)epi.out) & 15) == 0) && (epi.N * 2) % 16 == 0 && epi.N * 2 < (int64_t(1) << 24)) {
+                rc = launch_tiled(gemm_i8_p16<Epi, 0, true>, P16_LDS_BYTES, off.row ? P16_LDS_BYTES : P8_LDS_BYTES, tm256 * tn256, 512, (int)tm256, (int)tn256, epi, off);
                 done = true;
             }
         }

@@ -20,6 +20,7 @@ ap.add_argument("--plain", action="store_true", help="third arm: library B's asq
 ap.add_argument("--env-a", default="", help="KEY=VALUE[,KEY=VALUE] put into the environment before library A's FIRST GEMM launch (switches the library reads once, e.g. ASQ_P16_PERSIST=0)")
 ap.add_argument("--env-b", default="", help="the same for library B: with --a and --b the same file this is an A/B of one build's switch")
 ap.add_argument("--no-images", action="store_true", help="both arms on the plain operands (asq_linear_w8a8)")
+ap.add_argument("--zeros", action="store_true", help="all-zero weights and activations: the matrix cores draw almost no data-dependent power, so the launch is cycle-bound, not energy-bound")
 args = ap.parse_args()
 vp, i64, f32, sz, cint = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t, ctypes.c_int
 
@@ -66,9 +67,12 @@ for sh in args.shapes.split(","):
     idx = torch.randperm(K, device=dev, generator=g)[: max(1, K // 100)]
     x[:, idx] *= 20
     x = x.to(torch.float16)
+    if args.zeros:
+        w.zero_()
+        x.zero_()
     A = libs["A"]
     mode = 2 if args.per_token else 0   # ASQ_ACT_PER_TOKEN / ASQ_ACT_ROUND
-    qs = 1.0 if args.per_token else float(x.abs().max()) / 127
+    qs = 1.0 if (args.per_token or args.zeros) else float(x.abs().max()) / 127
     xs = x if args.per_token else (x.float() / qs).to(torch.float16)   # per-tensor: the caller's x / scale, as the reference's quantize does before the round
     w_off, col_off = torch.empty_like(w), torch.empty((N, 2), dtype=torch.int32, device=dev)
     ck(A, A.asq_weight_offset_image(w.data_ptr(), N, K, w_off.data_ptr(), col_off.data_ptr(), st), "image")
