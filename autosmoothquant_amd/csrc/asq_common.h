@@ -156,6 +156,22 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)
 __device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t absbits(float x) { return __float_as_uint(x) & 0x7FFFFFFFu; }
 
+// one 16-byte vector of DT elements as floats (4 x fp32 or 8 x fp16 / bf16)
+template <int DT> __device__ __forceinline__ void vec_unpack(const v4i &v, float (&f)[ElemT<DT>::VEC])
+{
+    if constexpr (DT == ASQ_F32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = __int_as_float(v[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t w = (uint32_t)v[i];
+            f[2 * i] = ElemT<DT>::load((uint16_t)(w & 0xFFFF));
+            f[2 * i + 1] = ElemT<DT>::load((uint16_t)(w >> 16));
+        }
+    }
+}
+
 template <int DT> struct AbsMax {  // running |x| maximum of raw DT vectors
     uint32_t acc = 0;              // fp32: |bits|;  16-bit types: two packed 15-bit patterns
     __device__ __forceinline__ void add(const v4i &v)

@@ -1102,6 +1102,12 @@ __device__ __forceinline__ bool splitk_fix_reduce(char *gws, unsigned long long 
 #include "asq_gemm_p8.h"
 #include "asq_gemm_p4.h"
 #include "asq_gemm_p16.h"
+#ifndef ASQ_P16_TAIL
+#define ASQ_P16_TAIL 0   // 1: also build gemm_i8_p16t (asq_gemm_p16t.h: round 6, bit-identical to gemm_i8_p16 and no faster -- not shipped) and dispatch it
+#endif
+#if ASQ_P16_TAIL
+#include "asq_gemm_p16t.h"
+#endif
 #include "asq_gemm_gateup.h"
 #include "asq_gemm_p16p.h"
 #include "asq_gemm_p4x16.h"
@@ -1634,16 +1640,15 @@ int launch_gemm_impl(const int8_t *x, const int8_t *w, int64_t M, int64_t N, int
                 done = true;
             }
         }
-        if constexpr (kP16 && Epi::kOutBytes == 2 && ASQ_P16_TAIL != 0) {
-            // (builds with -DASQ_P16_TAIL=1 only; measured and NOT shipped, profiles/r6_tail_overlap_ab.txt)  launches of interior tiles only, with an even number >= 4
-            // of K-tiles and aligned output rows: the kernel whose last two K-tiles run m-half first, so that half of every block's epilogue leaves under its last
-            // 64 MFMAs per wave (asq_gemm_p16.h, "THE TAIL").  ASQ_P16_TAIL=0 in the environment keeps the plain end (A/B inside one build).
+#if ASQ_P16_TAIL
+        if constexpr (kP16 && Epi::kOutBytes == 2) {   // (builds with -DASQ_P16_TAIL=1 only: asq_gemm_p16t.h, measured and NOT shipped, profiles/r6_tail_overlap_ab.txt)
             static const int tail = [] { const char *e = getenv("ASQ_P16_TAIL"); return e ? atoi(e) : 1; }();
             if (!done && tail && M % 256 == 0 && N % 256 == 0 && K % 256 == 0 && K >= 512 && ((((uintptr_t)epi.out) & 15) == 0) && (epi.N * 2) % 16 == 0 && epi.N * 2 < (int64_t(1) << 24)) {
-                rc = launch_tiled(gemm_i8_p16<Epi, 0, true>, P16_LDS_BYTES, off.row ? P16_LDS_BYTES : P8_LDS_BYTES, tm256 * tn256, 512, (int)tm256, (int)tn256, epi, off);
+                rc = launch_tiled(gemm_i8_p16t<Epi>, P16_LDS_BYTES, off.row ? P16_LDS_BYTES : P8_LDS_BYTES, tm256 * tn256, 512, (int)tm256, (int)tn256, epi, off);
                 done = true;
             }
         }
+#endif
         if constexpr (kP16) if (!done) rc = launch_tiled(gemm_i8_p16<Epi>, P16_LDS_BYTES, off.row ? P16_LDS_BYTES : P8_LDS_BYTES, tm256 * tn256, 512, (int)tm256, (int)tn256, epi, off);
     } else if (kern == KERN_P8) {
         const int ksplit = ws_ok ? pick_ksplit(tm256 * tn256, K, M, N, ws_bytes) : 1;

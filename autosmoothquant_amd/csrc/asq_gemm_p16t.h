@@ -1,35 +1,15 @@
-// "p16": the 256(m) x 256(n) x 128(k) INT8 GEMM of asq_gemm_p8.h on the OTHER int8 matrix instruction,
-// v_mfma_i32_16x16x64_i8.  Included by asq_gemm_kernels.h after asq_gemm_p8.h (shares its LDS-DMA helper, unit images, ring,
-// phase / barrier cadence and XCD tile map; plain launches only: no groups, no K split, int8 operands).
-//
-// Why.  At 4096^3 on real operands the MI355X runs this GEMM against its 1.4 kW socket limit, so its time is its energy
-// (profiles/r2_clock_power_evidence.md): ~30 of the 46.5 mJ are the matrix cores' own.  tools/ubench/mfma_shape_power (operands in
-// registers, ~1 s per arm, profiles/r3_mfma_shape_power.txt) sustains
-//                                   v_mfma_i32_32x32x32_i8      v_mfma_i32_16x16x64_i8
-//     zeros                              4955 TOPS                   4889        (not power-limited: the issue rates)
-//     bench-like operands                3386                        3911  +15.5 %
-//     uniform int8                       3146                        3743  +19 %
-// the 16 x 16 x 64 form moves a quarter of the accumulator registers per instruction (4 instead of 16 for half the MACs: half the
-// accumulator traffic per MAC) for the same operand bytes.  The fragment bytes read from LDS per MAC are set by the wave tile
-// (128 x 64, unchanged), not by the instruction shape.
-//
-// What changes against p8 (everything else is its schedule, line for line):
-//   * a phase (quadrant of 64 tokens x 32 channels x 128 k) is 2 k-steps of 64 x {2 channel tiles x 4 token tiles} = 16 MFMAs of 16 cycles
-//     (p8: 4 k-steps x 2 tiles = 8 of 32 cycles); the W fragment stays for 4 consecutive instructions;
-//   * a fragment is 16 rows x 64 k-bytes: lane l reads row (l & 15), 16-byte chunk (kstep * 4 + (l >> 4)) of the unit image
-//     [128 rows][8 chunks], chunk ^= (row >> 1) & 7.  With ds_read_b128's four 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32)
-//     every group touches 16 different 16-byte slots of the 256-byte bank row: conflict-free on the image p8 already builds;
-//   * accumulators: acc[m-half][n-half][token tile 0..3][channel tile 0..1], 4 registers each (128 in all, as p8); in the matrix-core
-//     layout lane l owns token (l & 15) and channels 4 * (l >> 4) .. + 3 of a 16 x 16 tile -- again 4 consecutive channels of one
-//     token, so the staged row epilogue only needs other write addresses (epilogue_wave_rows<.., L16 = true>).
-// Edge tiles and unaligned outputs leave through direct stores (epilogue_wave16).  Round 4: 4-byte outputs (int32 accumulators -- the reference's native boundary
-// linear_a8_w8_o32_ -- and fp32) have their own pipelined row epilogue (epilogue_wave_rows4); int8 outputs stay on gemm_i8_p8.
+// "p16t": gemm_i8_p16 with THE TAIL -- the single-round 256 x 256 x 128 kernel whose last two K-tiles run m-half first, so that half of every block's epilogue is
+// issued under the partner wave's last 64 MFMAs instead of behind the K loop.  EXPERIMENTAL, NOT BUILT BY DEFAULT: bit-identical to gemm_i8_p16
+// (tests/test_hip_tail.py on a -DASQ_P16_TAIL=1 build) and no faster -- on the bench operands the launch is energy-bound, on zeros (cycle-bound) the E0 wave does not
+// advance beside its SIMD partner's prio-1 MFMA stream: profiles/r6_tail_overlap_ab.txt.  Kept as the record of what was built; `make FLAGS+=-DASQ_P16_TAIL=1`
+// builds it and launch_gemm_impl dispatches it for launches of interior tiles only (M % 256 == 0, N % 256 == 0, K % 256 == 0, K >= 512, aligned 2-byte output rows);
+// ASQ_P16_TAIL=0/1 in the environment then switches inside that build.  Everything up to the last three K-tiles is gemm_i8_p16's code.
 #pragma once
 
 namespace asq {
 
-template <class Epi, int ABL = 0>
-__global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
+template <class Epi, int ABL = 0>   // launches of interior block tiles only, aligned 2-byte output rows, an even number >= 4 of K-tiles (launch_gemm_impl checks)
+__global__ void __launch_bounds__(512, 2) gemm_i8_p16t(const int8_t *__restrict__ x, const int8_t *__restrict__ w, int64_t M, int64_t N, int64_t K,
                                                       int tiles_m, int tiles_n, Epi epi_in, OffsetArgs off)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -71,8 +51,8 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
 
     // ---- DMA sources (as p8): this wave fills row-groups 2*wave, 2*wave+1 (8 rows each) of every unit
     const int nt = (int)(K / 128);
-    const int8_t *const xbase = uniform_ptr(x + m0 * K);
-    const int8_t *const wbase = uniform_ptr(w + n0 * K);
+    const int8_t *xbase = uniform_ptr(x + m0 * K);
+    const int8_t *wbase = uniform_ptr(w + n0 * K);
     const int64_t mrem = M - m0 - 1, nrem = N - n0 - 1;  // last valid local row
     unsigned voff[4][2];  // [kind][i]: X-even, W-even, W-odd, X-odd
 #pragma unroll
@@ -91,7 +71,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
         voff[3][i] = (unsigned)(rxo * K) + cb;
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)lds;
-    const unsigned dma_dst = lds0 + wave * 2048;  // + stage*P8_STAGE + kind*P8_UNIT + i*1024
+    unsigned dma_dst = lds0 + wave * 2048;  // + stage*P8_STAGE + kind*P8_UNIT + i*1024
 
     // ---- fragment read addresses: one VGPR per (stage, operand, k-step of 64); + 2048 * tile (16 rows) + the unit as immediates
     const int t16 = lane & 15, q16 = lane >> 4, sw = (t16 >> 1) & 7;
@@ -155,8 +135,11 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
     };
 
     // one K-tile at LDS stage S (compile-time), prefetching K-tile (t+1) into stage S^1: p8's four phases
-    auto ktile = [&](auto stage_tag, int t) {
+    // PRE (the tail below): this is K-tile nt - 3; besides K-tile nt - 2 (into NS) it also fetches the X-even and W-even units of K-tile nt - 1 into its OWN stage,
+    // whose two units were last read in P1 (>= 2 phases before: WAR as in the steady state), and P4 waits with two more units in flight.
+    auto ktile = [&](auto stage_tag, auto pre_tag, int t) {
         constexpr int S = decltype(stage_tag)::value, NS = S ^ 1;
+        constexpr bool PRE = decltype(pre_tag)::value;
         int kn = (t + 1) * 128;
         kn = kn < klast ? kn : klast;
 
@@ -198,6 +181,7 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
 
         // ---------------- P3: (m-half 1, n-half 1): reads X-odd (8)
         issue(2, NS, kn);
+        if constexpr (PRE) issue(0, S, klast);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -213,7 +197,12 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
 
         // ---------------- P4: (m-half 1, n-half 0): W-even fragments are still in wa[]
         issue(3, NS, kn);
-        P8_WAIT_VM(4);
+        if constexpr (PRE) {
+            issue(1, S, klast);
+            P8_WAIT_VM(8);   // in flight: W-odd, X-odd of K-tile nt - 2; X-even, W-even of K-tile nt - 1
+        } else {
+            P8_WAIT_VM(4);
+        }
         P8_BAR();
         __builtin_amdgcn_sched_barrier(0);
         P8_PRIO(1);
@@ -223,69 +212,169 @@ __global__ void __launch_bounds__(512, 2) gemm_i8_p16(const int8_t *__restrict__
         P8_BAR();
     };
 
-    int t = 0;
-    for (; t + 1 < nt; t += 2) {
-        ktile(std::integral_constant<int, 0>{}, t);
-        ktile(std::integral_constant<int, 1>{}, t + 1);
-    }
-    if (t < nt) ktile(std::integral_constant<int, 0>{}, t);
-
-    P8_BLK(2);
-    P8_WAIT_VM(0);          // drain the dead prefetches before LDS is released
-    if (wm == 0) P8_BAR();  // balance the stagger barrier
-
+    using std::integral_constant;
+    using std::false_type;
+    using std::true_type;
+    const int64_t mw0 = m0 + wm * 128, nw0 = n0 + wn * 64;
+    const bool wt = M * epi.N * Epi::kOutBytes <= (int64_t)ASQ_WT_BYTES && ASQ_WT_BYTES > 0;   // small outputs leave as write-through stores (rows_write_through)
     // accumulator tile (in16 = 16-channel tile 0..3, im16 = 16-token tile 0..7) -> rows mw0 + 16*im16, cols nw0 + 16*in16
     auto get = [&](int in16, int im16) -> const v4i & { return acc[im16 >> 2][in16 >> 1][im16 & 3][in16 & 1]; };
-    const int64_t mw0 = m0 + wm * 128, nw0 = n0 + wn * 64;
-    // interior wave tiles leave through the pipelined row epilogues (2-byte: epilogue_wave_rows, 4-byte: epilogue_wave_rows4), edge tiles and unaligned outputs through direct stores
-    bool rows_path = ((((uintptr_t)epi.out) & 15) == 0) && ((epi.N * Epi::kOutBytes) % 16 == 0) && mw0 + 128 <= M && nw0 + 64 <= N && epi.N * Epi::kOutBytes < (int64_t(1) << 24);
-    P8_BAR();  // (block-uniform) every wave's ring reads are done and every wave's (dead) DMAs have landed: the ring becomes staging space; the staged pairs are visible
-    const bool wt = M * epi.N * Epi::kOutBytes <= (int64_t)ASQ_WT_BYTES && ASQ_WT_BYTES > 0;   // small outputs leave as write-through stores (rows_write_through)
-    auto run = [&](auto getter) {
-        if (rows_path) {
-            if constexpr (Epi::kOutBytes == 2) epilogue_wave_rows<4, 2, true>(epi, getter, mw0, nw0, lane, lds0 + wave * 16384, wt);
-            else epilogue_wave_rows4(epi, getter, mw0, nw0, lane, lds0 + wave * 16384, wt);
-        } else {
-            epilogue_wave16(epi, getter, mw0, nw0, lane, M, N);
-        }
-    };
-    if (offs) {
-        // this lane's 16 channels {cw, wsum} (32 registers) and its 8 tokens' packed words (8): two v_mad_i32_i24 per element (v_mul_i32_i24 semantics: the low 24 bits
-        // of either factor, sign-extended -- the packed word IS -xsum' there) + one shift per accumulator tile for -cx
+    // offset images: this lane's 16 channels {cw, wsum} (32 registers) and its 8 tokens' packed words (8): two v_mad_i32_i24 per element (v_mul_i32_i24 semantics:
+    // the low 24 bits of either factor, sign-extended -- the packed word IS -xsum' there) + one shift per accumulator tile for -cx
+    // (pairs packed as cw << 24 | wsum: tried for the fp32 column-scale + bias epilogue, the compiler hoists the unpacking and spills more)
+    int cw[4][4], ws[4][4], rw[8];
+    auto load_pairs = [&]() {
         const int t16i = lane & 15, q16i = lane >> 4;
-        constexpr bool kPack = false;   // (pairs packed as cw << 24 | wsum: tried for the fp32 column-scale + bias epilogue, the compiler hoists the unpacking and spills more)
-        int cw[kPack ? 1 : 4][4], ws[4][4], rw[8];
 #pragma unroll
         for (int in16 = 0; in16 < 4; ++in16) {
             const unsigned ca = obase + 1024 + (wn * 64 + in16 * 16 + 4 * q16i) * 8;
             const v4i p0 = *(lds_v4i_)(uintptr_t)ca, p1 = *(lds_v4i_)(uintptr_t)(ca + 16);   // channels n, n+1 | n+2, n+3
             const int c4[4] = {p0[0], p0[2], p1[0], p1[2]}, s4[4] = {p0[1], p0[3], p1[1], p1[3]};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if constexpr (kPack) ws[in16][e] = (int)(((unsigned)c4[e] << 24) | ((unsigned)s4[e] & 0xFFFFFFu));
-                else cw[in16][e] = c4[e], ws[in16][e] = s4[e];
-            }
+            for (int e = 0; e < 4; ++e) cw[in16][e] = c4[e], ws[in16][e] = s4[e];
         }
 #pragma unroll
         for (int im16 = 0; im16 < 8; ++im16) rw[im16] = *(lds_i32)(uintptr_t)(obase + (wm * 128 + im16 * 16 + t16i) * 4);
-        auto getc = [&](int in16, int im16) -> v4i {
-            const v4i &a = acc[im16 >> 2][in16 >> 1][im16 & 3][in16 & 1];
-            const int ncx = rw[im16] >> 24;
-            v4i o;
+    };
+    auto getc = [&](int in16, int im16) -> v4i {
+        const v4i &a = acc[im16 >> 2][in16 >> 1][im16 & 3][in16 & 1];
+        const int ncx = rw[im16] >> 24;
+        v4i o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                int c;
-                if constexpr (kPack) c = ws[in16][e] >> 24;
-                else c = cw[in16][e];
-                // two v_mad_i32_i24, spelled out: from the C expression hipcc builds v_mul_i32_i24 x 2 (the >> 24 folded into an SDWA byte select) + v_add3_u32,
-                // three VALU operations per element where two do (128 elements per lane, two waves per SIMD: ~1 k cycles of a 85 k-cycle block)
-                o[e] = mad24(c, rw[im16], mad24(ncx, ws[in16][e], a[e]));
+        // two v_mad_i32_i24, spelled out: from the C expression hipcc builds v_mul_i32_i24 x 2 (the >> 24 folded into an SDWA byte select) + v_add3_u32,
+        // three VALU operations per element where two do (128 elements per lane, two waves per SIMD: ~1 k cycles of a 85 k-cycle block)
+        for (int e = 0; e < 4; ++e) o[e] = mad24(cw[in16][e], rw[im16], mad24(ncx, ws[in16][e], a[e]));
+        return o;
+    };
+
+    // ---- THE TAIL (round 6, TAIL launches: 2-byte outputs, interior block tiles only, an even number >= 4 of K-tiles -- the host checks, p16_tail_ok): the block's last two K-tiles, n2 = nt - 2 (stage 0) and
+    // n1 = nt - 1 (stage 1), are BOTH resident when the last eight phases start, and these run m-half first instead of K-tile first:
+    //     s0 Q(0,0) n2 | s1 Q(0,1) n2 | s2 Q(0,0) n1 | s3 Q(0,1) n1 || free-running:  M1 = Q(1,1) n2, Q(1,0) n2, Q(1,1) n1, Q(1,0) n1
+    // After s3 the wave tile's upper 64 rows are final, every DMA has landed and the X-even units of both stages are dead: no wave needs another barrier.  Each
+    // wave stages its epilogue in a PRIVATE 4 KiB image inside them (epilogue_wave_rows<.., IMGS = 1, IM0, IM1>), and the two waves of a SIMD take the remaining
+    // work in opposite orders -- the wm = 0 wave writes its upper half (E0) while the wm = 1 wave runs its last 64 MFMAs (M1), then they swap -- so half of the
+    // tile's conversions, LDS round trips and output bytes leave under matrix work instead of behind it, and the chip's 256 simultaneous output bursts start
+    // ~2 k cycles earlier.  The unit fetches move with it (vmcnt counts = DMAs that may stay in flight, two per unit):
+    //     K-tile nt - 3 (PRE):  P3 + X-even n1, P4 + W-even n1, wait 8  |  s0: W-odd n1, wait 8  |  s1: X-odd n1, wait 4  |  s2: wait 2  |  s3: wait 0
+    // Results are bit-identical (the same integer sums; the same epilogue arithmetic per element).
+    static_assert(Epi::kOutBytes == 2, "the tail stages 2-byte outputs");
+    int t = 0;
+    const int nplain = nt - 4;
+    for (; t + 1 < nplain; t += 2) {
+        ktile(integral_constant<int, 0>{}, false_type{}, t);
+        ktile(integral_constant<int, 1>{}, false_type{}, t + 1);
+    }
+    {
+        // The DMA bases again, through v_readfirstlane: hipcc hoists the loop's `dma_dst + constant` sums, merges them with the copies of the code below in PHIs of
+        // the (possibly skipped) loop's exit and has been seen to keep those in VGPRs -- which the DMAs' "s" operands then receive unrepaired.
+        dma_dst = __builtin_amdgcn_readfirstlane(dma_dst);
+        xbase = uniform_ptr(xbase);
+        wbase = uniform_ptr(wbase);
+        ktile(integral_constant<int, 0>{}, false_type{}, nt - 4);
+        ktile(integral_constant<int, 1>{}, true_type{}, nt - 3);
+        // ---------------- s0: Q(0,0) of n2
+        issue(2, 1, klast);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) wa[it][kk] = ld(wbp[0][kk] + 1 * P8_UNIT + it * 2048);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) xf[jt][kk] = ld(xb[0][kk] + 0 * P8_UNIT + jt * 2048);
+        P8_WAIT_VM(8);
+        P8_BAR();
+        P8_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        P8_PRIO(1);
+        quadrant(acc[0][0], wa);
+        P8_PRIO(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_BAR();
+        // ---------------- s1: Q(0,1) of n2
+        issue(3, 1, klast);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) wb[it][kk] = ld(wbp[0][kk] + 2 * P8_UNIT + it * 2048);
+        P8_WAIT_VM(4);
+        P8_BAR();
+        P8_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        P8_PRIO(1);
+        quadrant(acc[0][1], wb);
+        P8_PRIO(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_BAR();
+        // ---------------- s2: Q(0,0) of n1
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) wa[it][kk] = ld(wbp[1][kk] + 1 * P8_UNIT + it * 2048);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) xf[jt][kk] = ld(xb[1][kk] + 0 * P8_UNIT + jt * 2048);
+        P8_WAIT_VM(2);
+        P8_BAR();
+        P8_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        P8_PRIO(1);
+        quadrant(acc[0][0], wa);
+        P8_PRIO(0);
+        __builtin_amdgcn_sched_barrier(0);
+        P8_BAR();
+        // ---------------- s3: Q(0,1) of n1; the last wait: everything has landed
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) wb[it][kk] = ld(wbp[1][kk] + 2 * P8_UNIT + it * 2048);
+        P8_WAIT_VM(0);
+        P8_BAR();
+        P8_WAIT_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        P8_PRIO(1);
+        quadrant(acc[0][1], wb);
+        P8_PRIO(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (wm == 0) P8_BAR();   // the wm = 0 group's closing barrier pairs with the wm = 1 group's barrier above: the stagger is balanced, nobody waits again
+        P8_BLK(2);
+
+        // ---------------- free-running: M1 (the lower 64 rows' last two K-tiles), E0 / E1 (the upper / lower 64 rows' epilogue)
+        auto m1 = [&]() {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) xf[jt][kk] = ld(xb[s][kk] + 3 * P8_UNIT + jt * 2048);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        wb[it][kk] = ld(wbp[s][kk] + 2 * P8_UNIT + it * 2048);
+                        wa[it][kk] = ld(wbp[s][kk] + 1 * P8_UNIT + it * 2048);
+                    }
+                P8_WAIT_LGKM0();
+                __builtin_amdgcn_sched_barrier(0);
+                P8_PRIO(1);
+                quadrant(acc[1][1], wb);
+                quadrant(acc[1][0], wa);
+                P8_PRIO(0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            return o;
         };
-        run(getc);
-    } else {
-        run(get);
+        const unsigned img = lds0 + (wave >> 2) * P8_STAGE + (wave & 3) * 4096;   // this wave's image: a quarter of the (dead) X-even unit of stage wave / 4
+        if (wm == 1) m1();
+        if (offs) {
+            load_pairs();
+            epilogue_wave_rows<4, 2, true, 1, false, 0, 2>(epi, getc, mw0, nw0, lane, img, wt);
+        } else {
+            epilogue_wave_rows<4, 2, true, 1, false, 0, 2>(epi, get, mw0, nw0, lane, img, wt);
+        }
+        if (wm == 0) m1();
+        if (offs) epilogue_wave_rows<4, 2, true, 1, false, 2, 4>(epi, getc, mw0, nw0, lane, img, wt);
+        else epilogue_wave_rows<4, 2, true, 1, false, 2, 4>(epi, get, mw0, nw0, lane, img, wt);
     }
     P8_PROBE_END();
 }

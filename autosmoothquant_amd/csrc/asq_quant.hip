@@ -545,21 +545,6 @@ __device__ __forceinline__ float block_sum_256(float v, float *red)
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <int DT> __device__ __forceinline__ void vec_unpack(const v4i &v, float (&f)[ElemT<DT>::VEC])
-{
-    if constexpr (DT == ASQ_F32) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) f[i] = __int_as_float(v[i]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t w = (uint32_t)v[i];
-            f[2 * i] = ElemT<DT>::load((uint16_t)(w & 0xFFFF));
-            f[2 * i + 1] = ElemT<DT>::load((uint16_t)(w >> 16));
-        }
-    }
-}
-
 template <int DT> __device__ __forceinline__ v4i vec_pack(const float (&f)[ElemT<DT>::VEC])
 {
     if constexpr (DT == ASQ_F32) {

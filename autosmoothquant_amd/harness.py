@@ -230,6 +230,26 @@ def calibrate(layer, h):
 
 
 @torch.no_grad()
+def refresh_derived_operands(root):
+    """After ANY in-place weight update, before replaying a hipGraph captured on `root` (a layer, a stack of layers, a model): rebuild every operand DERIVED from
+    a weight INTO its existing buffers -- the linears' offset images (_W8A8Base.refresh_offset_image), GateUpSiLU's interleaved gate || up operand and its image
+    (GateUpSiLU.refresh), MixtralLayer's stack images and grouped gate || up operand (MixtralLayer.refresh_offset_images).  A graph bakes those buffers in; an eager
+    forward notices a changed weight by itself (storage + version key), a replay cannot.  Returns the number of operands rebuilt."""
+    from .layers.nn.fused import GateUpSiLU
+    from .layers.nn.linear import _W8A8Base
+    n = 0
+    for m in root.modules():
+        if isinstance(m, _W8A8Base):
+            n += bool(m.refresh_offset_image())
+        elif isinstance(m, GateUpSiLU):
+            n += bool(m.refresh())
+        if isinstance(m, MixtralLayer) and hasattr(m, "_w1_stack"):
+            m.refresh_offset_images()
+            n += 1
+    return n
+
+
+@torch.no_grad()
 def qkv_from_parts(q_proj, k_proj, v_proj):
     """One W8A8BFP32OFP32QKVLinear over three already-quantised projections: the int8 rows are concatenated as they are
     and each segment keeps its own dequant scale -- exactly what QKVLinear.from_float produces from the concatenated
@@ -598,7 +618,16 @@ class MixtralLayer(LlamaLayer):
         try:
             ver = st._version
         except RuntimeError:
-            return None   # a stack without a version counter (built under inference_mode): writes into it cannot be seen -> plain operands
+            # a stack without a version counter (built under inference_mode): writes into it cannot be seen.  build_offset_images() is the opt-in -- the caller
+            # then owns the refresh (refresh_offset_images), as with _W8A8Base.build_offset_image; otherwise plain operands (logged once)
+            if not self.__dict__.get("_images_pinned", False):
+                if not self.__dict__.get("_images_off_logged", False):
+                    self.__dict__["_images_off_logged"] = True
+                    import logging
+                    logging.getLogger("autosmoothquant_amd").info("MixtralLayer: expert stacks have no version counter (inference tensors): offset images and the grouped "
+                                                                  "gate || up launch are off; call build_offset_images() to opt in (then refresh_offset_images() after weight writes)")
+                return None
+            ver = -1
         key = (st.data_ptr(), ver, st.device)
         hit = self.__dict__.get(f"_{name}_image")
         if hit is None or hit[0] != key:
@@ -626,20 +655,45 @@ class MixtralLayer(LlamaLayer):
         try:
             key = (s1.data_ptr(), s1._version, s3.data_ptr(), s3._version, s1.device)
         except RuntimeError:
-            return None, None
-        hit = self.__dict__.get("_w13_cache")
+            if not self.__dict__.get("_images_pinned", False):
+                return None, None
+            key = (s1.data_ptr(), -1, s3.data_ptr(), -1, s1.device)
+        hit = self.__dict__.get("_w13_cache")   # [key, operand, image or None, image is current]
         if hit is None or hit[0] != key:
             if torch.cuda.is_current_stream_capturing():
                 return None, None
-            hit = [key, ops.interleave_gate_up_stack(s1, s3), None]
+            # rebuild INTO the cached buffers when they still fit: a hipGraph captured on them then replays the new weights instead of freed memory
+            E, F_, K = s1.shape
+            fits = hit is not None and hit[1].device == s1.device and tuple(hit[1].shape) == (E, 2 * F_, K)
+            try:
+                w13 = ops.interleave_gate_up_stack(s1, s3, out=hit[1] if fits else None)
+            except torch.cuda.OutOfMemoryError:
+                self.fuse_gate_up = False
+                self.__dict__.pop("_w13_cache", None)
+                return None, None
+            hit = [key, w13, hit[2] if fits else None, False]
             self.__dict__["_w13_cache"] = hit
-        if want_image and hit[2] is None:
+        if want_image and not hit[3]:
             if torch.cuda.is_current_stream_capturing():
                 return hit[1], None
             E, N2, K = hit[1].shape
-            img, col = ops.weight_offset_image(hit[1].view(E * N2, K))
-            hit[2] = (img.view(E, N2, K), col)
-        return hit[1], hit[2]
+            out = None if hit[2] is None else (hit[2][0].view(E * N2, K), hit[2][1])
+            try:
+                img, col = ops.weight_offset_image(hit[1].view(E * N2, K), out=out)
+            except torch.cuda.OutOfMemoryError:
+                return hit[1], None
+            hit[2], hit[3] = (img.view(E, N2, K), col), True
+        return hit[1], (hit[2] if hit[3] else None)
+
+    def build_offset_images(self):
+        """Build the three stacks' images (and, with fuse_gate_up, the w1 || w3 operand and its image) now -- load time -- instead of inside the first grouped forward,
+        and opt in for stacks without a version counter (a model built under torch.inference_mode()): the caller then calls refresh_offset_images() after writing
+        weights.  Mirrors _W8A8Base.build_offset_image.  Returns True when every image exists."""
+        self.__dict__["_images_pinned"] = True
+        ok = all(self._stack_image(n) is not None for n in ("w1", "w3", "w2"))
+        if getattr(self, "fuse_gate_up", False):
+            ok = self._w13_operand(True)[1] is not None and ok
+        return ok
 
     def refresh_offset_images(self):
         """Rebuild the three stacks' images from the current stacks into their existing buffers (after a weight update, before replaying a hipGraph captured
@@ -649,6 +703,11 @@ class MixtralLayer(LlamaLayer):
             if hit is not None:
                 self.__dict__[f"_{name}_image"] = (None, hit[1])   # (key None never matches: the next _stack_image call rebuilds in place)
                 self._stack_image(name)
+        hit = self.__dict__.get("_w13_cache")   # the grouped gate || up operand and its image follow (same buffers: graphs captured on them stay valid)
+        if hit is not None:
+            had_image = hit[2] is not None
+            hit[0] = None
+            self._w13_operand(had_image)
 
     def _stacks_current(self):
         """The per-expert modules stay the source of truth (state_dict, load_state_dict, .to(), replica.broadcast_quantized all act on THEIR buffers): the

@@ -136,6 +136,34 @@ def silu_mul_q(gate, up, consumer, fast=None):
     return QuantizedActivation(r[0], r[1], gate.dtype, lead, r[2] if len(r) > 2 else None)
 
 
+class QuantizedActivationFp8:
+    """e4m3 activation [.., K] + per-token scales f32 [M,1] produced by a fused kernel for an FP8LinearDynamic(act_quant="per-token"); `out_dtype` is the floating
+    dtype the consuming linear emits.  The fp8 counterpart of QuantizedActivation."""
+    __slots__ = ("xq", "scale", "out_dtype", "lead")
+
+    def __init__(self, xq, scale, out_dtype, lead):
+        self.xq, self.scale, self.out_dtype, self.lead = xq, scale, out_dtype, lead
+
+    @property
+    def shape(self):
+        return (*self.lead, self.xq.shape[-1])
+
+
+@torch.no_grad()
+def silu_mul_q_fp8(gate, up, consumer=None, fast=None):
+    """silu(gate) * up quantised per token to e4m3 for an FP8LinearDynamic (Mixtral's w2 / LLaMA's down_proj in an fp8 checkpoint; reference models/mixtral.py:99-101 on
+    FP8LinearDynamic modules, linear.py:413-427): ONE pass (ops.silu_mul_quantize_fp8) instead of silu, mul and per_token_quantize_fp8.  Returns a
+    QuantizedActivationFp8 the consumer's forward accepts."""
+    if consumer is not None and getattr(consumer, "act_quant", None) != "per-token":
+        raise ValueError("silu_mul_q_fp8 needs a per-token FP8LinearDynamic consumer (a per-tensor scale depends on the whole tensor)")
+    lead = gate.shape[:-1]
+    g2, u2 = gate.reshape(-1, gate.shape[-1]), up.reshape(-1, up.shape[-1])
+    g2 = g2 if g2.is_contiguous() else g2.contiguous()
+    u2 = u2 if u2.is_contiguous() else u2.contiguous()
+    q, sc = ops.silu_mul_quantize_fp8(g2, u2, fast)
+    return QuantizedActivationFp8(q, sc, gate.dtype, lead)
+
+
 class GateUpSiLU(torch.nn.Module):
     """SiLU(gate_proj(x)) * up_proj(x) as ONE GEMM over the two projections' interleaved int8 rows (ops.linear_w8a8_gate_up; reference models/llama.py:206-211 /
     HF LlamaMLP).  A VIEW of two existing W8A8BFP32OFP32Linear modules: they stay the source of truth (state_dict, load_state_dict, the arena broadcast act on THEIR
@@ -166,17 +194,55 @@ class GateUpSiLU(torch.nn.Module):
 
     def _operand(self):
         key = self._key()
-        if any(k[1] is None for k in key):
-            return None   # a weight without a version counter: writes into it cannot be seen -> the unfused composition
+        if any(k[1] is None for k in key) and not self.__dict__.get("_pinned", False):
+            return None   # a weight without a version counter: writes into it cannot be seen -> the unfused composition (build() is the opt-in: the caller then owns refresh())
+        if self.__dict__.get("_disabled", False):
+            return None
         hit = self.__dict__.get("_wgu")
         if hit is None or hit[0] != key:
             if torch.cuda.is_current_stream_capturing():
                 return None
             out = hit[1] if hit is not None and hit[1].device == self.gate.weight.device else None
-            hit = (key, ops.interleave_gate_up(self.gate._buffers["weight"], self.up._buffers["weight"], out=out))
+            try:
+                hit = (key, ops.interleave_gate_up(self.gate._buffers["weight"], self.up._buffers["weight"], out=out))
+            except torch.cuda.OutOfMemoryError:
+                # one more int8 copy of gate + up did not fit: this module answers None from now on and the caller runs the two linears + silu_mul_q
+                self.__dict__["_disabled"] = True
+                self.__dict__.pop("_wgu", None)
+                self.__dict__.pop("_wgu_image", None)
+                return None
             self.__dict__["_wgu"] = hit
             self.__dict__["_wgu_image_key"] = None
         return hit[1]
+
+    def build(self, M=None, dtype=None):
+        """Build the interleaved operand now (load time) instead of inside the first forward that can use it, and -- given the (M, dtype) of the forwards to come -- its
+        offset image too.  Also the opt-in for weights without a version counter (inference tensors): the caller then calls refresh() after writing them.
+        Returns True when the module holds the operand."""
+        self.__dict__["_pinned"] = True
+        ok = self._operand() is not None
+        if ok and M is not None and dtype is not None:
+            self.offset_image(M, dtype)
+        return ok
+
+    def refresh(self):
+        """Rebuild the interleaved operand -- and its offset image, if one exists -- from the CURRENT gate / up weights INTO the existing buffers.  Call after any
+        weight update before replaying a hipGraph that was captured on the fused path (the graph bakes these derived buffers in; an eager forward would notice the
+        change by itself, a replay cannot), next to gate.refresh_offset_image() / up.refresh_offset_image().  No-op (False) when the
+        module holds no operand."""
+        hit = self.__dict__.get("_wgu")
+        if hit is None or torch.cuda.is_current_stream_capturing():
+            return False
+        self.__dict__["_wgu"] = (None, hit[1])          # (key None never matches: _operand rebuilds into hit[1])
+        had_image = self.__dict__.get("_wgu_image") is not None
+        w = self._operand()
+        if w is None:
+            return False
+        if had_image:
+            old = self.__dict__["_wgu_image"]
+            self.__dict__["_wgu_image"] = ops.weight_offset_image(w, out=old if old[0].device == w.device else None)
+            self.__dict__["_wgu_image_key"] = self._key()
+        return True
 
     def offset_image(self, M, dtype):
         """the interleaved operand's offset image when a forward of M rows runs on images, else None (so a fused norm in front emits the activation's image for it)"""
@@ -189,7 +255,12 @@ class GateUpSiLU(torch.nn.Module):
             if torch.cuda.is_current_stream_capturing():
                 return None
             old = self.__dict__.get("_wgu_image")
-            self.__dict__["_wgu_image"] = ops.weight_offset_image(w, out=old if old is not None and old[0].device == w.device else None)
+            try:
+                self.__dict__["_wgu_image"] = ops.weight_offset_image(w, out=old if old is not None and old[0].device == w.device else None)
+            except torch.cuda.OutOfMemoryError:
+                self.offsets = False   # (a third int8 copy did not fit: the fused GEMM runs on the plain interleaved operand from now on)
+                self.__dict__.pop("_wgu_image", None)
+                return None
             self.__dict__["_wgu_image_key"] = self._key()
         return self.__dict__["_wgu_image"]
 

@@ -21,9 +21,10 @@ from .. import functional as _F  # noqa: F401  (package marker)
 from ..functional.quantization import quantize_per_tensor_absmax
 from ... import ops
 from ..._CUDA import I8CUGEMM
-from .fused import QuantizedActivation
+from .fused import QuantizedActivation, QuantizedActivationFp8
 
 _ACT_CODE = dict(ops._ACT)   # quantiser mode name -> C-ABI code
+_cur_dev = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device   # (the raw getter: ~0.1 us instead of ~0.4)
 
 _ACT_QUANT = ("per-token", "per-tensor")
 
@@ -57,6 +58,7 @@ class Int8GEMM(object):
 class _W8A8Base(torch.nn.Module):
     """Shared plumbing: buffers, host-pinned scalar scales, shape handling."""
     _host_scalars = ("dequant_scale",)
+    _fast_ok = False   # classes whose forward is exactly _module_forward(mode, qs, dequant_scale, no column vector) switch the cached decode call on
 
     def __init__(self, in_features, out_features, use_bias=False, act_quant="per-tensor"):
         super().__init__()
@@ -98,6 +100,31 @@ class _W8A8Base(torch.nn.Module):
             self._pin_scalars()
             t = self._buffers[name]
         return float(t)
+
+    def _fast(self, x):
+        """The cached call of a decode-sized forward (round 6): _module_forward records, per module, the last (shape, dtype, device) it ran WITHOUT an
+        offset image together with everything that was derived from the module's state -- C-ABI entry, quantiser code, the host scalars as Python floats, output
+        shape.  A later forward with the same input geometry whose state tensors are still the same OBJECTS at the same versions (weight, bias, every host scalar)
+        skips the re-derivation and the re-validation: empty + one C-ABI call.  Anything else returns None and takes the full path, which refreshes the record.
+        Not used for shapes that run on offset images (their image follows the weight's version; those forwards are GPU-bound anyway)."""
+        fc = self.__dict__.get("_fast_state")
+        if fc is None or x.shape != fc[0] or x.dtype is not fc[1] or not x.is_cuda or x.get_device() != fc[2] or not x.is_contiguous():
+            return None
+        b = self._buffers
+        if b["weight"] is not fc[3] or b.get("bias") is not fc[4] or _cur_dev() != fc[2]:
+            return None
+        for name, t, ver in fc[5]:
+            u = b[name]
+            if u is not t or u._version != ver:
+                return None
+        out = torch.empty(fc[6], dtype=fc[1], device=fc[7])
+        stream = ops._stream(x)
+        ws, nbytes = ops._forward_ws(fc[8], fc[9], fc[10], fc[11], fc[7], stream)
+        rc = fc[12](x.data_ptr(), fc[13], fc[3].data_ptr(), out.data_ptr(), fc[9], fc[10], fc[11], fc[14], fc[15], fc[16], None, None if fc[4] is None else fc[4].data_ptr(),
+                    None if ws is None else ws.data_ptr(), nbytes, stream)
+        if rc:
+            ops.L.check(rc, "asq_linear_w8a8_forward")
+        return out
 
     def _flatten(self, x):
         if x.shape[-1] != self.in_features:
@@ -294,7 +321,19 @@ def _module_forward(mod, x, mode, qs, s_scalar, s_col):
                 if t.dtype != torch.float32 or t.numel() != mod.out_features or t.device != w.device:
                     raise ValueError(f"{name} must be float32 with {mod.out_features} elements on {w.device}")
         mod.__dict__["_checked"] = (w, bias, s_col)
-    out = ops.linear_w8a8_forward_trusted(x2, w, _ACT_CODE[mode], float(qs), float(s_scalar), s_col, bias, mod.offset_image(x2.shape[0], x.dtype), mod.out_features, mod.in_features)
+    image = mod.offset_image(x2.shape[0], x.dtype)
+    out = ops.linear_w8a8_forward_trusted(x2, w, _ACT_CODE[mode], float(qs), float(s_scalar), s_col, bias, image, mod.out_features, mod.in_features)
+    if image is None and s_col is None and x2.shape[0] <= 64 and x.is_contiguous() and type(mod)._fast_ok:
+        # decode-sized, no image: remember the derived call for _fast() (see there); host scalars by object + version, so an in-place rewrite of a scale is seen
+        try:
+            scal = tuple((n, mod._buffers[n], mod._buffers[n]._version) for n in mod._host_scalars)
+            lib = ops.L.lib()
+            mod.__dict__["_fast_state"] = (x.shape, x.dtype, x.get_device(), w, bias, scal, (*lead, mod.out_features), x.device, lib, x2.shape[0], mod.out_features, mod.in_features,
+                                           lib.asq_linear_w8a8_forward, ops._DT[x.dtype], _ACT_CODE[mode], float(qs), float(s_scalar))
+        except RuntimeError:   # (inference tensors have no version counter: no cached call)
+            mod.__dict__.pop("_fast_state", None)
+    else:
+        mod.__dict__.pop("_fast_state", None)
     return out.view(*lead, mod.out_features)
 
 
@@ -304,9 +343,14 @@ class W8A8BFP32OFP32Linear(_W8A8Base):
     norm, reference models/llama.py:326-339) -> round+clamp only.  per-token: dynamic
     absmax/127 per row (reference :83-106)."""
 
+    _fast_ok = True
+
     def forward(self, x):
         if isinstance(x, QuantizedActivation):
             return _prequantized_forward(self, x, self._scalar("dequant_scale"), None)
+        y = self._fast(x)
+        if y is not None:
+            return y
         return _module_forward(self, x, "per-token" if self.act_quant == "per-token" else "per-tensor-round", 1.0, self._scalar("dequant_scale"), None)
 
     @staticmethod
@@ -386,9 +430,14 @@ class W8A8BFP32OFP32LinearWithQuantScale(_W8A8Base):
     def _input_mode(self):
         return ("per-token", 1.0) if self.act_quant == "per-token" else ("per-tensor-div", self._scalar("quant_scale"))
 
+    _fast_ok = True
+
     def forward(self, x):
         if isinstance(x, QuantizedActivation):  # already quantised for this module (fused.silu_mul_q)
             return _prequantized_forward(self, x, self._scalar("dequant_scale"), None)
+        y = self._fast(x)
+        if y is not None:
+            return y
         mode, qs = self._input_mode()
         return _module_forward(self, x, mode, qs, self._scalar("dequant_scale"), None)
 
@@ -474,6 +523,15 @@ class FP8LinearDynamic(_FP8Base):
 
     @torch.no_grad()
     def forward(self, x):
+        if isinstance(x, QuantizedActivationFp8):   # already quantised for this module by a fused kernel (fused.silu_mul_q_fp8): no prologue launch
+            if self.act_quant != "per-token":
+                raise ValueError("a QuantizedActivationFp8 carries per-token scales; this FP8LinearDynamic is per-tensor")
+            if x.xq.shape[-1] != self.in_features:
+                raise ValueError(f"expected last dim {self.in_features}, got {tuple(x.shape)}")
+            if x.xq.numel() == 0:
+                return torch.empty(*x.lead, self.out_features, dtype=x.out_dtype, device=x.xq.device)
+            out = ops.linear_fp8(x.xq, x.scale, self.weight, float(self.weight_scale), self._bias_dev(x.xq.device), x.out_dtype)
+            return out.view(*x.lead, self.out_features)
         lead = x.shape[:-1]
         x2 = self._x2d(x)
         if x2.numel() == 0:

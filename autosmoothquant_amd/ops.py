@@ -314,12 +314,16 @@ def grouped_gate_up_supported(M, F_, K, out_dtype):
     return out_dtype in (torch.float16, torch.bfloat16) and bool(L.lib().asq_grouped_gate_up_supported(M, F_, K, _DT[out_dtype]))
 
 
-def interleave_gate_up_stack(w1, w3):
-    """[G, 2F, K] int8: every group's gate (w1[g]) and up (w3[g]) rows interleaved in blocks of 16 channels (interleave_gate_up per group)."""
+def interleave_gate_up_stack(w1, w3, out=None):
+    """[G, 2F, K] int8: every group's gate (w1[g]) and up (w3[g]) rows interleaved in blocks of 16 channels (interleave_gate_up per group).
+    out: rebuild INTO this [G, 2F, K] buffer (a hipGraph captured on it then replays the new weights)."""
     if w1.shape != w3.shape or w1.dim() != 3:
         raise ValueError("w1 / w3 must be [G, F, K] stacks of one shape")
     G, F_, K = w1.shape
-    out = torch.empty((G, 2 * F_, K), dtype=torch.int8, device=w1.device)
+    if out is None:
+        out = torch.empty((G, 2 * F_, K), dtype=torch.int8, device=w1.device)
+    elif tuple(out.shape) != (G, 2 * F_, K) or out.dtype != torch.int8 or out.device != w1.device or not out.is_contiguous():
+        raise ValueError("out must be a contiguous int8 [G, 2F, K] buffer on the stacks' device")
     for g in range(G):
         interleave_gate_up(w1[g], w3[g], out=out[g])
     return out
@@ -734,6 +738,26 @@ def quantize_act_fp8(x, mode, static_scale=1.0):
     if mode == "per-tensor":
         return xq, sc[0]
     return xq, float(static_scale)
+
+
+def silu_mul_quantize_fp8(gate, up, fast=None):
+    """e4m3(per-token quantise(silu(gate) * up)) in ONE pass (asq_silu_mul_quantize_fp8): (xq float8_e4m3fn [M,K], scale f32 [M,1]) -- what
+    quantize_act_fp8(F.silu(gate) * up, "per-token") returns from three.  fast as in silu_mul_quantize (default: the hardware-transcendental SiLU; False: the
+    fixed-operation-order form oracle/n1.py::silu_mul_quant_fp8_kernel_order repeats bit for bit).  Reference: models/mixtral.py:99-101 on FP8LinearDynamic modules."""
+    if fast is None:
+        fast = not SILU_EXACT_DEFAULT
+    _dev(gate, "gate"), _dev(up, "up")
+    if gate.dtype not in _DT or gate.dim() != 2 or up.dtype != gate.dtype or up.shape != gate.shape:
+        raise ValueError("gate and up must be 2-D float tensors of equal shape and dtype")
+    if not (gate.is_contiguous() and up.is_contiguous()):
+        raise ValueError("gate / up must be contiguous")
+    M, K = gate.shape
+    xq = torch.empty((M, K), dtype=torch.uint8, device=gate.device)
+    sc = torch.empty((M,), dtype=torch.float32, device=gate.device)
+    with _on(gate.device):
+        L.check(L.lib().asq_silu_mul_quantize_fp8(gate.data_ptr(), up.data_ptr(), _DT[gate.dtype], L.ASQ_SILU_FAST if fast else 0, xq.data_ptr(), sc.data_ptr(), M, K,
+                                                  _stream(gate)), "asq_silu_mul_quantize_fp8")
+    return xq.view(torch.float8_e4m3fn), sc.view(M, 1)
 
 
 def quantize_mxfp8(x):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ASQ_VERSION 122 /* 0.1.4: + asq_linear_w8a8_gate_up_q8 (gate || up with an int8-out epilogue for per-tensor consumers); 0.1.3: + asq_grouped_gate_up_supported, asq_linear_w8a8_grouped_gate_up (Mixtral's w1 || w3 as one grouped launch with the SiLU * up epilogue); 0.1.2: + asq_forward_fused_supported, asq_linear_w8a8_forward_fused (the one-launch forward for decode-sized inputs; asq_linear_w8a8_forward takes it
+#define ASQ_VERSION 123 /* 0.1.5: + asq_silu_mul_quantize_fp8 (SiLU * up fused with the per-token e4m3 quantiser of the FP8 linear behind it); 0.1.4: + asq_linear_w8a8_gate_up_q8 (gate || up with an int8-out epilogue for per-tensor consumers); 0.1.3: + asq_grouped_gate_up_supported, asq_linear_w8a8_grouped_gate_up (Mixtral's w1 || w3 as one grouped launch with the SiLU * up epilogue); 0.1.2: + asq_forward_fused_supported, asq_linear_w8a8_forward_fused (the one-launch forward for decode-sized inputs; asq_linear_w8a8_forward takes it
                            * by itself where it wins); ASQ_ROCTX=1 ranges.  0.1.1: + offset operand images (asq_*_off); workspace sizes include the 8 KiB header
                            * (asq_workspace_init is mandatory for a workspace handed to a GEMM entry point); asq_silu_mul_quantize's `per_token` is a bit field (bit 0
                            * per-token, ASQ_SILU_FAST) */
@@ -333,6 +333,13 @@ int asq_linear_fp8(const uint8_t *xq, const uint8_t *w, int fp8_format, void *ou
  * out[m,n] = acc_f32 * (a_scale[m] * w_scale_group[g(m)]) (+ bias[g(m)][n]).  K % 128 == 0, 16-B aligned operands. */
 int asq_linear_fp8_grouped(const uint8_t *xq, const uint8_t *w, void *out, int out_dtype, const int32_t *group_offsets, int ngroups,
                            int64_t M, int64_t N, int64_t K, const float *a_scale, const float *w_scale_group, const float *bias, void *stream);
+
+/* SiLU(gate) * up fused with the per-token e4m3 quantiser of the FP8 linear that consumes it (round 6): the reference's gated MLP on FP8LinearDynamic modules --
+ * models/mixtral.py:99-101 `w2(act_fn(w1(x)) * w3(x))`, w2's prologue per_token_quantize_fp8 (layers/functional/quantization.py:173-191, called from
+ * layers/nn/linear.py:413-427).  gate, up [M,K] of x_dtype (K a multiple of 8 / 4 (fp32), <= 16384 / 8192); xq [M,K] e4m3fn bytes; scale f32 [M] =
+ * f32(x_dtype(max_k |a| / 448)) with a = x_dtype(x_dtype(silu(gate)) * up); q = e4m3(clamp(f32(a) / scale, +-448)).  flags: 0 = the fixed-operation-order SiLU
+ * (bit-identical to oracle/n1.py::silu_mul_quant_fp8_kernel_order), ASQ_SILU_FAST = the hardware transcendentals.  Replaces three passes (silu, mul, quantiser). */
+int asq_silu_mul_quantize_fp8(const void *gate, const void *up, int x_dtype, int flags, uint8_t *xq, float *scale, int64_t M, int64_t K, void *stream);
 
 /* FP8E5M2Linear (linear.py:583-644): plain unscaled cast x -> e5m2 (round-to-nearest-even, IEEE-like
  * overflow to inf); the product then runs through asq_linear_fp8(..., ASQ_FP8_E5M2, ...) with unit scales.

@@ -144,6 +144,17 @@ def silu_mul_quant_kernel_order(gate, up, dt: str, per_token: bool = True, quant
     return O.act_quant_div(a, dt, quant_scale), None
 
 
+def silu_mul_quant_fp8_kernel_order(gate, up, dt: str):
+    """asq_silu_mul_quantize_fp8 (exact form): a = dt(dt(g / (1 + exp_det(-g))) * u) -- silu_mul_quant_kernel_order's activation -- then the reference's
+    per_token_quantize_fp8 (layers/functional/quantization.py:173-191, restated and G5-pinned in oracle/fp8.py).  Returns (e4m3fn bytes [M,K], scale f32 [M,1])."""
+    from . import fp8 as F8
+    g, u = np.asarray(gate, dtype=F32), np.asarray(up, dtype=F32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        sl = O.round_to((g / (F32(1.0) + exp_det(-g)).astype(F32)).astype(F32), dt)
+        a = O.round_to((sl * u).astype(F32), dt)
+    return F8.per_token_quantize_fp8(a, dt)
+
+
 def gate_up_silu_kernel_order(xq, w_gate, w_up, dt: str, s_gate: float, s_up: float, s_row=None) -> np.ndarray:
     """asq_linear_w8a8_gate_up with the fixed-operation-order SiLU (flags = 0): the two projections' dequantised outputs in `dt` -- exactly the epilogue of
     W8A8BFP32OFP32Linear (oracle/w8a8.py::dequant_epilogue, reference layers/nn/linear.py:93-104) -- then a = dt(dt(g / (1 + exp_det(-g))) * u)

@@ -122,3 +122,67 @@ def test_module_forward_is_one_kernel_and_matches_the_module_on_more_rows():
             big = m(x)
             for rows in (1, 4, 16):
                 assert torch.equal(m(x[:rows]), big[:rows]), (cls.__name__, aq, dt, rows)
+
+
+@pytest.mark.parametrize("cls_name,aq", [("W8A8BFP32OFP32Linear", "per-tensor"), ("W8A8BFP32OFP32Linear", "per-token"), ("W8A8BFP32OFP32LinearWithQuantScale", "per-tensor")])
+def test_cached_decode_call_follows_every_state_change(cls_name, aq):
+    """Round 6: decode-sized module forwards run a cached call (_W8A8Base._fast: same input geometry, same state OBJECTS at the same versions -> empty + one C-ABI
+    call).  It must be invisible: equal to the oracle, and every change of the module's state -- a scale rewritten in place, a new weight object, an in-place weight
+    write, a bias write, another shape, another dtype, a CPU tensor -- gives what a fresh module gives."""
+    from autosmoothquant_amd.layers.nn import linear as LN
+    cls = getattr(LN, cls_name)
+    K, N, M = 512, 768, 4
+    g = torch.Generator().manual_seed(21)
+    wq = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8)
+    bias = torch.randn(N, generator=g)
+    x = (torch.randn(2, M // 2, K, generator=g) * 30).half()
+
+    def fresh(w, b, ds, qs):
+        m = cls(K, N, True, aq)
+        m.weight, m.bias, m.dequant_scale = w.clone(), b.clone(), torch.tensor(ds)
+        if "quant_scale" in m._buffers:
+            m.quant_scale = torch.tensor(qs)
+        return m.to(DEV)
+
+    def oracle(w, b, ds, qs, xx):
+        xin = xx.float().numpy().reshape(-1, K)
+        if cls_name == "W8A8BFP32OFP32Linear":
+            return O.linear_forward(xin, "f16", w.numpy(), ds, b.numpy(), aq)
+        return O.linear_with_quant_scale_forward(xin, "f16", w.numpy(), ds, qs, b.numpy(), aq)
+    ds, qs = 1.0 / 4096, 0.37
+    m = fresh(wq, bias, ds, qs)
+    xd = x.to(DEV)
+    want = oracle(wq, bias, ds, qs, x)
+    for i in range(3):                                   # first call records, the next ones take the cached call
+        y = m(xd)
+        assert y.shape == (2, M // 2, N) and np.array_equal(y.float().cpu().numpy().reshape(M, N), want), i
+    assert "_fast_state" in m.__dict__
+    m.dequant_scale.fill_(2 * ds)                        # in place: the version counter moves
+    assert np.array_equal(m(xd).float().cpu().numpy().reshape(M, N), oracle(wq, bias, 2 * ds, qs, x))
+    m.dequant_scale = torch.tensor(ds)                   # a new object
+    assert np.array_equal(m(xd).float().cpu().numpy().reshape(M, N), want)
+    if "quant_scale" in m._buffers:
+        m.quant_scale.fill_(0.5)
+        assert np.array_equal(m(xd).float().cpu().numpy().reshape(M, N), oracle(wq, bias, ds, 0.5, x))
+        m.quant_scale.fill_(qs)
+    w2 = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8)
+    m.weight.copy_(w2.to(DEV))                           # in-place weight write: read through the pointer
+    assert np.array_equal(m(xd).float().cpu().numpy().reshape(M, N), oracle(w2, bias, ds, qs, x))
+    m.weight = wq.to(DEV)                                # a new weight object
+    assert np.array_equal(m(xd).float().cpu().numpy().reshape(M, N), want)
+    m.bias.add_(1.0)
+    assert np.array_equal(m(xd).float().cpu().numpy().reshape(M, N), oracle(wq, bias + 1.0, ds, qs, x))
+    m.bias.sub_(1.0)
+    x3 = (torch.randn(3, K, generator=g) * 30).half()   # another geometry, then back
+    assert np.array_equal(m(x3.to(DEV)).float().cpu().numpy(), oracle(wq, bias, ds, qs, x3))
+    assert np.array_equal(m(xd).float().cpu().numpy().reshape(M, N), want)
+    xb = x.bfloat16()
+    if cls_name == "W8A8BFP32OFP32Linear":
+        refb = O.linear_forward(xb.float().numpy().reshape(-1, K), "bf16", wq.numpy(), ds, bias.numpy(), aq)
+    else:
+        refb = O.linear_with_quant_scale_forward(xb.float().numpy().reshape(-1, K), "bf16", wq.numpy(), ds, qs, bias.numpy(), aq)
+    assert np.array_equal(m(xb.to(DEV)).float().cpu().numpy().reshape(M, N), refb)
+    with pytest.raises(RuntimeError):
+        m(x)                                             # a CPU tensor still fails loudly
+    xt = xd.transpose(0, 1)                              # non-contiguous: the full path flattens it
+    assert torch.equal(m(xt), m(xt.contiguous()))

@@ -122,3 +122,57 @@ def test_llama_layer_fused_path_with_and_without_the_gate_up_gemm(cfg):
         y0 = q(hh)
         assert "_wgu" in q.gate_up.__dict__        # the fused kernel really ran
     assert torch.equal(y1, y0)
+
+
+@pytest.mark.parametrize("images", [False, True])
+def test_graph_replay_follows_a_weight_update_after_refresh(images):
+    """a hipGraph captured on the fused path bakes GateUpSiLU's DERIVED buffers (the interleaved gate || up operand, its offset image) in.  They are rebuilt
+    in place: after copy_ of new weights + harness.refresh_derived_operands() a replay gives what an eager forward gives; the buffers never move."""
+    from autosmoothquant_amd import harness, ops
+    from autosmoothquant_amd.layers.nn.fused import GateUpSiLU, QuantizedActivation
+    from autosmoothquant_amd.layers.nn.linear import W8A8BFP32OFP32Linear
+    M, F, K = 4096, 2304, 512
+    wg, wu, x = _case(M, F, K, 901)
+    mods = []
+    for w, ds in ((wg, 2.1e-4), (wu, 1.7e-4)):
+        m = W8A8BFP32OFP32Linear(K, F, False, "per-tensor")
+        m.weight = w.clone()
+        m.dequant_scale = torch.tensor(ds)
+        mods.append(m.to(DEV))
+    gate, up = mods
+    gu = GateUpSiLU(gate, up)
+    root = torch.nn.ModuleDict({"gate": gate, "up": up, "gu": gu})
+    xh = x.half()
+    if images:
+        xo, s_row, row_off = ops.quantize_act_off(xh, "per-tensor-round")
+        qa = QuantizedActivation(xo, s_row, torch.float16, (M,), row_off)
+        assert gu.offset_image(M, torch.float16) is not None
+    else:
+        qa = gate.quantize_input(xh, consumers=(gu,))
+    eager_old = gu(qa).clone()
+    ptrs = (gu.__dict__["_wgu"][1].data_ptr(), gu.__dict__["_wgu_image"][0].data_ptr() if images else 0)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        gu(qa)
+    torch.cuda.current_stream().wait_stream(s)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=s):
+        out_g = gu(qa)
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_g, eager_old)
+    wg2, wu2, _ = _case(M, F, K, 902)
+    gate.weight.copy_(wg2)
+    up.weight.copy_(wu2)
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_g, eager_old)          # no refresh yet: the replay still reads the old derived operand (documented, INTEGRATION.md section 8)
+    assert harness.refresh_derived_operands(root) >= 1
+    gr.replay()
+    torch.cuda.synchronize()
+    fresh = GateUpSiLU(gate, up)(qa)             # a module that has never seen the old weights
+    assert torch.equal(out_g, fresh) and not torch.equal(fresh, eager_old)
+    assert torch.equal(gu(qa), fresh)            # and the eager path agrees
+    assert ptrs == (gu.__dict__["_wgu"][1].data_ptr(), gu.__dict__["_wgu_image"][0].data_ptr() if images else 0)

@@ -105,3 +105,56 @@ def test_mixtral_layer_opt_in_equals_the_fused_silu_composition():
                 want.index_add_(0, tok, y * wts[:, None])
                 assert torch.equal(got.reshape(-1, 256), want), (offsets, fast)
                 assert float((got - base).abs().max()) <= 0.05 * float(base.abs().max()) + 1e-3
+
+
+def test_mixtral_graph_replay_follows_a_weight_update_after_refresh():
+    """MixtralLayer's w1 || w3 operand (and its image) is rebuilt INTO its buffers when the stacks change, and refresh_offset_images() covers it: a hipGraph
+    captured on the grouped gate || up launch replays the new weights after the refresh, from the same addresses."""
+    from autosmoothquant_amd import harness, ops
+    torch.manual_seed(6)
+    fl = harness.MixtralLayer(256, 384, 4, 2, experts=4, top_k=2)
+    with torch.no_grad():
+        for p in fl.parameters():
+            if p.dim() == 2:
+                p.copy_(torch.randn(p.shape) * 0.05)
+    lay = harness.to_w8a8_mixtral(fl, {"attn_in": 0.05, "o_in": 0.05, "mlp_in": 0.05, "down_in": [0.05, 0.06, 0.07, 0.08]}).to(DEV).half()
+    lay.stack_experts()
+    lay.fuse_gate_up = True
+    E, F_, K = lay._w1_stack.shape
+    counts = [512, 0, 300, 212]
+    M = sum(counts)
+    offs = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32, device=DEV)
+    x = (torch.randn(M, K, device=DEV) * 2).half()
+    assert ops.grouped_gate_up_supported(M, F_, K, torch.float16)
+    xo, _, row_off = ops.quantize_act_off(x, "per-tensor-round")
+    xq, _ = ops.quantize_act(x, "per-tensor-round")
+    with torch.no_grad():
+        w13, img = lay._w13_operand(True)
+        assert w13 is not None and img is not None
+        ptrs = (w13.data_ptr(), img[0].data_ptr(), img[1].data_ptr())
+
+        def launch():
+            return ops.linear_w8a8_grouped_gate_up(xo, img[0], offs, lay._w1_scale, lay._w3_scale, torch.float16, True, row_off, img[1])
+        old = launch().clone()
+        torch.cuda.synchronize()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            launch()
+        torch.cuda.current_stream().wait_stream(s)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            out_g = launch()
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out_g, old)
+        for e in lay.experts:        # in-place writes into the per-expert views of the stacks
+            e.w1.weight.copy_(torch.randint(-128, 128, e.w1.weight.shape, device=DEV, dtype=torch.int8))
+            e.w3.weight.copy_(torch.randint(-128, 128, e.w3.weight.shape, device=DEV, dtype=torch.int8))
+        assert harness.refresh_derived_operands(lay) >= 1
+        w13b, imgb = lay._w13_operand(True)
+        assert ptrs == (w13b.data_ptr(), imgb[0].data_ptr(), imgb[1].data_ptr())      # same buffers: the graph's pointers stay valid
+        gr.replay()
+        torch.cuda.synchronize()
+        want = ops.linear_w8a8_grouped_gate_up(xq, ops.interleave_gate_up_stack(lay._w1_stack, lay._w3_stack), offs, lay._w1_scale, lay._w3_scale, torch.float16, True)
+        assert torch.equal(out_g, want) and not torch.equal(want, old)

@@ -1,7 +1,9 @@
-"""GPU (-m gpu): gemm_i8_p16<.., TAIL> -- the single-round 256 x 256 kernel whose last two K-tiles run m-half first so that half of every block's epilogue leaves
-under its last matrix work (asq_gemm_p16.h, "THE TAIL") -- against the SAME product from a launch the TAIL kernel cannot take: one extra activation row adds an
-edge tile row, and the whole launch then runs on the plain-ended kernel (rows of a linear are independent).  Plain operands and offset images, every epilogue
-operand set, both 2-byte dtypes, K-tile counts 4 / 6 / 8 / 32 / 86, tile counts from 144 to 256, and the oracle on a row of every tile."""
+"""GPU (-m gpu): interior-tile launches of the 256 x 256 kernel against the SAME product from a launch with an edge tile row (one extra activation row; rows of a
+linear are independent).  Written for gemm_i8_p16t (asq_gemm_p16t.h, "THE TAIL": the single-round kernel whose last two K-tiles run m-half first so that half of every
+block's epilogue leaves under its last matrix work) -- on a `-DASQ_P16_TAIL=1` build the interior launch runs on it and the edge launch on the plain-ended gemm_i8_p16,
+which is how the experimental kernel was shown bit-identical before it was measured and left out (profiles/r6_tail_overlap_ab.txt).  On the default build both launches
+run gemm_i8_p16 and the file pins that interior and edge-tile launches agree.  Plain operands and offset images, every epilogue operand set, both 2-byte dtypes,
+K-tile counts 4 / 6 / 8 / 16 / 32 / 86, tile counts from 144 to 256, the oracle on a row of every tile, int8 extremes, back-to-back launches and hipGraph replays."""
 import numpy as np
 import pytest
 import torch
