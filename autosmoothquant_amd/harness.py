@@ -9,6 +9,8 @@ Nothing in here is on the product's hot path except the seven linears.
 """
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -49,8 +51,25 @@ def _rope_tables(S, d, device, dtype, theta=10000.0):
 
 
 def _rope(x, theta=10000.0):
-    """Rotary embedding, HF "rotate_half" convention, positions 0..S-1; x [B, H, S, D].  Two fused multiply-adds per
-    half written straight into the output (no concatenation pass), tables cached per (S, D)."""
+    """Rotary embedding, HF "rotate_half" convention, positions 0..S-1; x [B, H, S, D] -- here always the transposed view of a projection's [B, S, H, D] output: that
+    case is ONE kernel (ops.rope / asq_rope, round 6: the four strided torch kernels per tensor were 8.5 % of the GPU time of BASELINE configs[2]'s forward); anything
+    else takes the torch composition, which the kernel reproduces bit for bit."""
+    d = x.shape[-1]
+    if x.is_cuda and x.dim() == 4 and d % 16 == 0 and x.dtype in (torch.float16, torch.bfloat16) and ROPE_KERNEL:
+        xb = x.transpose(1, 2)   # [B, S, H, D]: dense (a projection's own output) or a slice of the fused q || k || v GEMM's output (one row pitch)
+        st, (B_, S_, H_, _) = xb.stride(), xb.shape
+        if st[3] == 1 and st[2] == d and st[1] >= H_ * d and st[1] % 8 == 0 and st[0] == S_ * st[1] and xb.data_ptr() % 16 == 0:
+            from . import ops
+            cos, sin = _rope_tables(x.shape[-2], d, x.device, x.dtype, theta)
+            return ops.rope(xb, cos.view(-1, d // 2), sin.view(-1, d // 2)).transpose(1, 2)
+    return _rope_torch(x, theta)
+
+
+ROPE_KERNEL = os.environ.get("ASQ_ROPE_KERNEL", "1") != "0"   # 0: the torch composition everywhere (A/B)
+
+
+def _rope_torch(x, theta=10000.0):
+    """The same embedding as torch ops: two fused multiply-adds per half written straight into the output (no concatenation pass), tables cached per (S, D)."""
     d = x.shape[-1]
     cos, sin = _rope_tables(x.shape[-2], d, x.device, x.dtype, theta)
     x1, x2 = x[..., : d // 2], x[..., d // 2:]

@@ -740,6 +740,32 @@ def quantize_act_fp8(x, mode, static_scale=1.0):
     return xq, float(static_scale)
 
 
+def rope(x, cos, sin, out=None):
+    """Rotary embedding of x [B, S, H, D] in one pass (asq_rope): x is a q / k projection's output viewed per head -- dense, or a slice of a fused q || k || v output
+    (strides (S * ld, ld, D, 1) with ld >= H * D); cos / sin [S, D/2] of x's dtype, positions 0 .. S-1, rotate_half convention.  Returns a DENSE [B, S, H, D] tensor
+    (out=x rotates a dense x in place).  fp16: bit-identical to the torch composition addcmul(x1 * cos, x2, sin, value=-1) / addcmul(x2 * cos, x1, sin) it replaces
+    (harness._rope_torch); bf16: the same operations at fp32 width."""
+    _dev(cos, "cos"), _dev(sin, "sin")
+    if not isinstance(x, torch.Tensor) or not x.is_cuda:   # (x may be a strided slice: _dev's contiguity check does not apply)
+        raise RuntimeError("x must be a HIP (cuda:N) tensor; there is no CPU fallback")
+    if x.dtype not in _DT or x.dim() != 4:
+        raise ValueError("x must be a [B, S, H, D] float tensor")
+    B, S, H, D = x.shape
+    st = x.stride()
+    ld = st[1] if S > 1 else (st[0] if B > 1 else H * D)
+    if not (st[3] == 1 and st[2] == D and ld >= H * D and (B == 1 or S == 1 or st[0] == S * ld)) or (S == 1 and B > 1 and st[0] < H * D):
+        raise ValueError("x must be [B, S, H, D] with H * D contiguous and one row pitch (a projection output or a slice of a fused one)")
+    if cos.dtype != x.dtype or sin.dtype != x.dtype or cos.numel() != S * (D // 2) or sin.numel() != S * (D // 2) or not (cos.is_contiguous() and sin.is_contiguous()):
+        raise ValueError("cos / sin must be contiguous [S, D/2] tables of x's dtype")
+    if out is None:
+        out = torch.empty((B, S, H, D), dtype=x.dtype, device=x.device)
+    elif out.shape != x.shape or out.dtype != x.dtype or not out.is_contiguous() or out.device != x.device:
+        raise ValueError("out must be a dense tensor of x's shape, dtype and device")
+    with _on(x.device):
+        L.check(L.lib().asq_rope(x.data_ptr(), ld, out.data_ptr(), _DT[x.dtype], cos.data_ptr(), sin.data_ptr(), B, S, H, D, _stream(x)), "asq_rope")
+    return out
+
+
 def silu_mul_quantize_fp8(gate, up, fast=None):
     """e4m3(per-token quantise(silu(gate) * up)) in ONE pass (asq_silu_mul_quantize_fp8): (xq float8_e4m3fn [M,K], scale f32 [M,1]) -- what
     quantize_act_fp8(F.silu(gate) * up, "per-token") returns from three.  fast as in silu_mul_quantize (default: the hardware-transcendental SiLU; False: the

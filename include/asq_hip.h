@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ASQ_VERSION 123 /* 0.1.5: + asq_silu_mul_quantize_fp8 (SiLU * up fused with the per-token e4m3 quantiser of the FP8 linear behind it); 0.1.4: + asq_linear_w8a8_gate_up_q8 (gate || up with an int8-out epilogue for per-tensor consumers); 0.1.3: + asq_grouped_gate_up_supported, asq_linear_w8a8_grouped_gate_up (Mixtral's w1 || w3 as one grouped launch with the SiLU * up epilogue); 0.1.2: + asq_forward_fused_supported, asq_linear_w8a8_forward_fused (the one-launch forward for decode-sized inputs; asq_linear_w8a8_forward takes it
+#define ASQ_VERSION 124 /* 0.1.6: + asq_rope (caller-side glue: rotary embedding of a q / k projection's output in one pass); 0.1.5: + asq_silu_mul_quantize_fp8 (SiLU * up fused with the per-token e4m3 quantiser of the FP8 linear behind it); 0.1.4: + asq_linear_w8a8_gate_up_q8 (gate || up with an int8-out epilogue for per-tensor consumers); 0.1.3: + asq_grouped_gate_up_supported, asq_linear_w8a8_grouped_gate_up (Mixtral's w1 || w3 as one grouped launch with the SiLU * up epilogue); 0.1.2: + asq_forward_fused_supported, asq_linear_w8a8_forward_fused (the one-launch forward for decode-sized inputs; asq_linear_w8a8_forward takes it
                            * by itself where it wins); ASQ_ROCTX=1 ranges.  0.1.1: + offset operand images (asq_*_off); workspace sizes include the 8 KiB header
                            * (asq_workspace_init is mandatory for a workspace handed to a GEMM entry point); asq_silu_mul_quantize's `per_token` is a bit field (bit 0
                            * per-token, ASQ_SILU_FAST) */
@@ -340,6 +340,15 @@ int asq_linear_fp8_grouped(const uint8_t *xq, const uint8_t *w, void *out, int o
  * f32(x_dtype(max_k |a| / 448)) with a = x_dtype(x_dtype(silu(gate)) * up); q = e4m3(clamp(f32(a) / scale, +-448)).  flags: 0 = the fixed-operation-order SiLU
  * (bit-identical to oracle/n1.py::silu_mul_quant_fp8_kernel_order), ASQ_SILU_FAST = the hardware transcendentals.  Replaces three passes (silu, mul, quantiser). */
 int asq_silu_mul_quantize_fp8(const void *gate, const void *up, int x_dtype, int flags, uint8_t *xq, float *scale, int64_t M, int64_t K, void *stream);
+
+/* Rotary position embedding of a q / k projection's output in ONE pass (round 6; caller-side glue, not a reference-path function: the reference's model wrappers run
+ * HF's apply_rotary_pos_emb between their W8A8 q / k linears and the attention product -- models/llama.py:111, models/mixtral.py:75).  x [B, S, H, D] with H * D
+ * contiguous and x_row_pitch elements between consecutive (b, s) rows (0 = dense H * D; a slice of a fused q || k || v output passes the fused width), out [B, S, H, D]
+ * dense, cos_tab / sin_tab [S, D/2] of x_dtype, positions 0 .. S-1, "rotate_half" convention:
+ *   out[.., :D/2] = dt(f32(dt(x1 * cos)) - x2 * sin),  out[.., D/2:] = dt(f32(dt(x2 * cos)) + x1 * sin)
+ * -- fp16: bit-identical to torch.addcmul(x1 * cos, x2, sin, value=-1) / torch.addcmul(x2 * cos, x1, sin) on this platform (the sum is rounded ONCE to fp16).
+ * D % 16 == 0 (fp32: % 8); out may alias a dense x. */
+int asq_rope(const void *x, int64_t x_row_pitch, void *out, int x_dtype, const void *cos_tab, const void *sin_tab, int64_t B, int64_t S, int64_t H, int64_t D, void *stream);
 
 /* FP8E5M2Linear (linear.py:583-644): plain unscaled cast x -> e5m2 (round-to-nearest-even, IEEE-like
  * overflow to inf); the product then runs through asq_linear_fp8(..., ASQ_FP8_E5M2, ...) with unit scales.

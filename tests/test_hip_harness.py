@@ -274,3 +274,39 @@ def test_explicit_shared_input_and_no_hidden_cache():
         yi = [m(xi) for m in mods]
         qi = harness.shared_input(xi, mods[0], mods[1])
         assert torch.equal(mods[1](qi), yi[1])
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(2, 160, 32, 128), (1, 1, 8, 64), (3, 33, 4, 128), (32, 2048, 32, 128)])
+def test_rope_kernel_equals_the_torch_composition(dt, shape):
+    """Round 6: asq_rope (one pass over a q / k projection's output) against the four strided torch kernels it replaces in the harness -- bit for bit in fp16 / bf16
+    (products of 16-bit floats are exact in fp32), within an fp32 ulp in fp32 (torch may contract a + b * c); out of place and in place; theta 1e6 (Mixtral)."""
+    from autosmoothquant_amd import harness, ops
+    dev = torch.device("cuda:0")
+    B, S, H, D = shape
+    if dt == torch.float32 and B * S * H * D > (1 << 26):
+        pytest.skip("full size in the 16-bit dtypes only")
+    g = torch.Generator(device=dev).manual_seed(B + S)
+    x = (torch.randn(B, S, H, D, generator=g, device=dev) * 3).to(dt)
+    for theta in (10000.0, 1e6):
+        want = harness._rope_torch(x.transpose(1, 2), theta)          # [B, H, S, D] view, as the layers call it
+        cos, sin = harness._rope_tables(S, D, dev, dt, theta)
+        got = ops.rope(x, cos.view(-1, D // 2), sin.view(-1, D // 2)).transpose(1, 2)
+        if dt == torch.float32:
+            assert float((got - want).abs().max()) <= 2.0 ** -21 * float(want.abs().max())
+        else:
+            assert torch.equal(got, want)
+            assert torch.equal(harness._rope(x.transpose(1, 2), theta), want)       # the harness takes the kernel for this layout
+        y = x.clone()
+        ops.rope(y, cos.view(-1, D // 2), sin.view(-1, D // 2), out=y)                # in place: every thread reads both halves before it writes them
+        assert torch.equal(y.transpose(1, 2), got)
+        if B * S * H * D <= (1 << 24):                                                # a slice of a fused q || k || v output: one row pitch, three times the width
+            wide = torch.zeros(B, S, 3 * H * D, dtype=dt, device=dev)
+            wide[..., H * D: 2 * H * D] = x.view(B, S, H * D)
+            xs = wide[..., H * D: 2 * H * D].view(B, S, H, D)
+            assert not xs.is_contiguous() or B * S == 1
+            assert torch.equal(ops.rope(xs, cos.view(-1, D // 2), sin.view(-1, D // 2)).transpose(1, 2), got)
+            if dt != torch.float32:
+                assert torch.equal(harness._rope(xs.transpose(1, 2), theta), got)
+    with pytest.raises(ValueError):
+        ops.rope(x.transpose(1, 2), cos.view(-1, D // 2), sin.view(-1, D // 2))       # not the [B, S, H, D] layout
