@@ -540,7 +540,7 @@ def whole_linear_block(mods, xs, tdt, settle_ms, iters=10, batch=50):
     hidden = (torch.randn(M, K, generator=g, device=x.device)).to(tdt)
     hidden[:, torch.rand(K, generator=g, device=x.device) < 0.01] *= 20.0
     norm = RMSNormQ(K, 1e-5, per_token=False).to(x.device)
-    norm.weight = torch.full((K,), 3.0, device=x.device)
+    norm.weight = torch.full((K,), 3.0, device=x.device, dtype=tdt)   # (the activation dtype, as RMSNormQ.from_float leaves it after .half(): no per-call cast)
     t_n1 = timed(lambda: mod(norm(hidden, consumers=(mod,))))
     t_n = timed(lambda: norm(hidden, consumers=(mod,)))
     out["n1"] = entry(t_n1, {"norm_quant_us": round(t_n, 2), "gemm_us": round(t_n1 - t_n, 2), "launches": 2,
