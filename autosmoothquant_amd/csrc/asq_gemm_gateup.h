@@ -132,4 +132,82 @@ template <class Epi, class Get> __device__ __forceinline__ void epilogue_gate_up
     }
 }
 
+// ---- fp8 (round 6): the same fusion for FP8LinearDynamic experts (reference models/mixtral.py:99-101 on FP8LinearDynamic modules, layers/nn/linear.py:413-427,
+// easy_fp8_gemm :336-369): w1 || w3 of every expert ROW-INTERLEAVED in blocks of 32 channels, so that in the 32 x 32 accumulator layout of
+// v_mfma_scale_f32_32x32x64_f8f6f4 (lane = token l & 31, channels 8 g + 4 (l >> 5) .. + 3 of a 32-channel tile) a wave's two n-halves ARE gate and up of the same 32
+// output channels and a lane holds both for its (token, 4 channels):
+//     y_g = dt(acc_g * (a_scale[m] * w_scale_gate))      y_u = dt(acc_u * (a_scale[m] * w_scale_up))      exactly EpiFp8<DT>'s values for the two linears
+//     a   = dt(dt(silu(y_g)) * y_u)                                                                         asq_silu_core.h
+// Bit-identical to asq_linear_fp8_grouped (w1), (w3) and the SiLU * up of asq_silu_mul_quantize_fp8 with the same flag.  Runs on the grouped 256 x 256 kernel
+// (gemm_i8_p8<Epi, 0, true, false>); per-token activation scales.
+template <int DT> struct EpiGateUpFp8 {
+    using Mma = MmaFp8;
+    static constexpr bool kHasRow = true, kHasCol = false, kHasBias = false, kGateUp = true, kQ8 = false, kGroupable = true;
+    static constexpr int kOutBytes = 2;
+    static_assert(DT == ASQ_F16 || DT == ASQ_BF16, "2-byte activations");
+    void *out;               // [M, F]
+    int64_t N;               // F
+    const float *a_scale;    // [M] per-token activation scales
+    const float *sg_group, *su_group;   // per-group weight scales of w1 / w3 [ngroups]
+    float s_gate, s_up;
+    int fast;
+    __device__ __forceinline__ EpiGateUpFp8 rebased(int grp, int, int64_t, int64_t) const
+    {
+        EpiGateUpFp8 e = *this;
+        e.s_gate = sg_group[grp];
+        e.s_up = su_group[grp];
+        return e;
+    }
+    __device__ __forceinline__ v2u pack_gate_up(const v4f &g, const v4f &u, float sr) const
+    {
+        const float dg = __fmul_rn(sr, s_gate), du = __fmul_rn(sr, s_up);   // EpiFp8: a * (sr * sc)
+        float yg[4], yu[4];
+        uint32_t uh[2] = {0, 0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float vg = __fmul_rn(g[i], dg), vu = __fmul_rn(u[i], du);
+            asm("" : "+v"(vg), "+v"(vu));   // (the conversion below is its own rounding)
+            if constexpr (DT == ASQ_F16) {
+                const _Float16 hg = (_Float16)vg, hu = (_Float16)vu;
+                yg[i] = (float)hg;
+                uh[i >> 1] |= (uint32_t)__builtin_bit_cast(uint16_t, hu) << (16 * (i & 1));
+            } else {
+                yg[i] = bf16_bits_to_f32(f32x2_to_bf16x2_bits(vg, vg) & 0xFFFFu);   // EpiFp8's own bf16 convert
+                yu[i] = bf16_bits_to_f32(f32x2_to_bf16x2_bits(vu, vu) & 0xFFFFu);
+            }
+        }
+        uint32_t o[2];
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            const v2f sl = fast ? silu2<true>(yg[i], yg[i + 1]) : silu2<false>(yg[i], yg[i + 1]);
+            if constexpr (DT == ASQ_F16) {
+                o[i >> 1] = silu_times_up_h(sl, uh[i >> 1]);
+            } else {
+                const v2f a = silu_times_up<DT>(sl, yu[i], yu[i + 1]);
+                o[i >> 1] = (uint32_t)ElemT<DT>::store(a[0]) | ((uint32_t)ElemT<DT>::store(a[1]) << 16);
+            }
+        }
+        return (v2u){o[0], o[1]};
+    }
+};
+
+// wave tile of the grouped 256 x 256 kernel in the 32 x 32 accumulator layout: get(in, im) = n-half in (0 = gate, 1 = up), 32-token tile im; rows bounded by the group's end
+template <class Epi, class Get> __device__ __forceinline__ void epilogue_gate_up_rows32(const Epi &e, Get get, int64_t mw0, int64_t nw0, int lane, int64_t Mw)
+{
+    const int t = lane & 31, h = lane >> 5;
+    typedef __attribute__((address_space(1))) v2u *glb_v2u;
+#pragma unroll
+    for (int im = 0; im < 4; ++im) {
+        const int64_t m = mw0 + im * 32 + t;
+        if (m >= Mw) continue;
+        const float sr = e.a_scale[m];
+        const auto &G = get(0, im);
+        const auto &U = get(1, im);
+        char *const row = (char *)e.out + (m * e.N + (nw0 >> 1)) * 2 + h * 8;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(glb_v2u)(uintptr_t)(row + g * 16) = e.pack_gate_up((v4f){G[4 * g], G[4 * g + 1], G[4 * g + 2], G[4 * g + 3]}, (v4f){U[4 * g], U[4 * g + 1], U[4 * g + 2], U[4 * g + 3]}, sr);
+    }
+}
+
 }  // namespace asq

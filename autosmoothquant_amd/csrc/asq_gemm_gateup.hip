@@ -158,3 +158,55 @@ extern "C" int asq_linear_w8a8_grouped_gate_up(const int8_t *xq, const int8_t *w
     return out_dtype == ASQ_F16 ? launch_grouped_gate_up<ASQ_F16>(xq, w_gu, out, group_offsets, ngroups, M, F, K, s_gate, s_up, fast, off, workspace, workspace_bytes, s)
                                 : launch_grouped_gate_up<ASQ_BF16>(xq, w_gu, out, group_offsets, ngroups, M, F, K, s_gate, s_up, fast, off, workspace, workspace_bytes, s);
 }
+
+// ---- fp8 grouped form (round 6): FP8LinearDynamic experts' w1 || w3 (interleaved in blocks of 32 channels) as one grouped launch with the SiLU * up epilogue
+// (EpiGateUpFp8, asq_gemm_gateup.h).  Per-token activation scales, per-group weight scales.
+static bool fp8_grouped_gate_up_shape(int64_t M, int64_t F, int64_t K, int out_dtype)
+{
+    static const bool on = [] { const char *e = getenv("ASQ_GATE_UP"); return !(e && e[0] == '0'); }();
+    if (!on || !(out_dtype == ASQ_F16 || out_dtype == ASQ_BF16)) return false;
+    return M >= 1 && F >= 128 && F % 128 == 0 && K >= 128 && K % 128 == 0 && K < (int64_t(1) << 31) && M * F < (int64_t(1) << 40);
+}
+
+extern "C" int asq_fp8_grouped_gate_up_supported(int64_t M, int64_t F, int64_t K, int out_dtype) { return fp8_grouped_gate_up_shape(M, F, K, out_dtype) ? 1 : 0; }
+
+template <int DT>
+static int launch_fp8_grouped_gate_up(const int8_t *xq, const int8_t *w_gu, void *out, const int32_t *goffs, int ngroups, int64_t M, int64_t F, int64_t K, const float *a_scale,
+                                      const float *s_gate, const float *s_up, int fast, hipStream_t s)
+{
+    using Epi = EpiGateUpFp8<DT>;
+    const int64_t N = 2 * F, tn = N / 256;
+    int64_t tiles = (M / 256 + ngroups) * tn;   // upper bound on sum ceil(m_g / 256) * tn
+    if (ngroups <= P8_GROUPED_SCAN_MAX) tiles = 8 * ((tiles + 7) / 8 + 2 + P8_CUS_PER_XCD);
+    ASQ_REQUIRE(tiles < (1ll << 24), ASQ_ERR_DIM, "asq_linear_fp8_grouped_gate_up: too many tiles");
+    auto kfn = gemm_i8_p8<Epi, 0, true, false>;
+    const hipError_t e = ensure_dynamic_lds((const void *)kfn, P8_LDS_BYTES);
+    if (e != hipSuccess) {
+        asq_set_error("asq_linear_fp8_grouped_gate_up: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    const Epi epi{out, F, a_scale, s_gate, s_up, 1.0f, 1.0f, fast};
+    hipLaunchKernelGGL(kfn, dim3((unsigned)tiles), dim3(512), P8_LDS_BYTES, s, xq, w_gu, M, N, K, 0, (int)tn, 1, goffs, ngroups, (char *)nullptr, epi, OffsetArgs{});
+    return asq_after_launch(s, "asq_linear_fp8_grouped_gate_up");
+}
+
+extern "C" int asq_linear_fp8_grouped_gate_up(const uint8_t *xq, const uint8_t *w_gu, void *out, int out_dtype, const int32_t *group_offsets, int ngroups, int64_t M, int64_t F,
+                                              int64_t K, const float *a_scale, const float *s_gate, const float *s_up, int flags, void *stream)
+{
+    const AsqRange range_("asq_linear_fp8_grouped_gate_up");
+    ASQ_REQUIRE(M >= 0 && F >= 0 && K >= 0, ASQ_ERR_DIM, "asq_linear_fp8_grouped_gate_up: bad dims");
+    if (M == 0 || F == 0) return ASQ_OK;
+    ASQ_REQUIRE(xq != nullptr && w_gu != nullptr && out != nullptr && group_offsets != nullptr && a_scale != nullptr && s_gate != nullptr && s_up != nullptr, ASQ_ERR_NULL,
+                "asq_linear_fp8_grouped_gate_up: NULL xq / w_gu / out / group_offsets / a_scale / s_gate / s_up");
+    ASQ_REQUIRE(ngroups > 0 && ngroups <= 4096, ASQ_ERR_DIM, "asq_linear_fp8_grouped_gate_up: need 1 <= ngroups <= 4096");
+    ASQ_REQUIRE(out_dtype == ASQ_F16 || out_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_linear_fp8_grouped_gate_up: out_dtype must be ASQ_F16 or ASQ_BF16 (got %d)", out_dtype);
+    ASQ_REQUIRE((flags & ~ASQ_SILU_FAST) == 0, ASQ_ERR_DTYPE, "asq_linear_fp8_grouped_gate_up: flags is 0 or ASQ_SILU_FAST, got %d", flags);
+    ASQ_REQUIRE(fp8_grouped_gate_up_shape(M, F, K, out_dtype), ASQ_ERR_DIM, "asq_linear_fp8_grouped_gate_up: needs F %% 128 == 0, K %% 128 == 0 (asq_fp8_grouped_gate_up_supported)");
+    ASQ_REQUIRE((((uintptr_t)xq | (uintptr_t)w_gu | (uintptr_t)out) & 15) == 0 && ((((uintptr_t)a_scale | (uintptr_t)s_gate | (uintptr_t)s_up | (uintptr_t)group_offsets) & 3) == 0),
+                ASQ_ERR_ALIGN, "asq_linear_fp8_grouped_gate_up: xq / w_gu / out must be 16-byte aligned");
+    const int fast = (flags & ASQ_SILU_FAST) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    return out_dtype == ASQ_F16
+               ? launch_fp8_grouped_gate_up<ASQ_F16>((const int8_t *)xq, (const int8_t *)w_gu, out, group_offsets, ngroups, M, F, K, a_scale, s_gate, s_up, fast, s)
+               : launch_fp8_grouped_gate_up<ASQ_BF16>((const int8_t *)xq, (const int8_t *)w_gu, out, group_offsets, ngroups, M, F, K, a_scale, s_gate, s_up, fast, s);
+}

@@ -721,8 +721,13 @@ if constexpr (L16) {
         run(get16);
         return;
     }
-    if constexpr (IsGateUp<Epi>::value) return;   // (the gate || up epilogue exists for the 16 x 16 x 64 form only)
-    else {
+    if constexpr (IsGateUp<Epi>::value) {   // int8 gate || up runs on the 16 x 16 x 64 form above; here: fp8 groups on the 32 x 32 block-scaled instruction (EpiGateUpFp8)
+        if constexpr (GRP && !MMA::kIsInt) {
+            auto getf = [&](int in, int im) -> const acc_t & { return acc[im >> 1][in][im & 1]; };
+            epilogue_gate_up_rows32(epi, getf, m0 + wm * 128, n0 + wn * 64, lane, M);
+        }
+        return;
+    } else {
     // accumulator tile (in = n-half, im = 2*m-half + j) -> rows m0 + wm*128 + 32*im, cols n0 + wn*64 + 32*in
     auto get = [&](int in, int im) -> const acc_t & { return acc[im >> 1][in][im & 1]; };
     bool staged = false;

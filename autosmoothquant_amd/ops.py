@@ -240,16 +240,22 @@ def gate_up_supported(M, F, K, dtype):
     return dtype in _DT and bool(L.lib().asq_gate_up_supported(int(M), int(F), int(K), _DT[dtype]))
 
 
-def interleave_gate_up(w_gate, w_up, out=None):
-    """[F, K] gate and up -> the [2 F, K] operand of linear_w8a8_gate_up: blocks of 16 gate channels alternate with the same 16 channels of up (include/asq_hip.h)."""
+def interleave_gate_up(w_gate, w_up, out=None, block=None):
+    """[F, K] gate and up -> the [2 F, K] operand of the gate || up GEMMs: blocks of `block` gate channels alternate with the same channels of up (include/asq_hip.h).
+    int8 weights: block 16 (the 16 x 16 x 64 instruction's accumulator tile); float8 weights: block 32 (the 32 x 32 block-scaled instruction's)."""
     F_, K = w_gate.shape
-    if w_up.shape != w_gate.shape or w_gate.dtype != torch.int8 or w_up.dtype != torch.int8 or F_ % 16 != 0:
-        raise ValueError("gate / up must be int8 [F, K] with F % 16 == 0")
+    f8 = (torch.float8_e4m3fn, torch.float8_e5m2)
+    if w_up.shape != w_gate.shape or w_up.dtype != w_gate.dtype or w_gate.dtype not in (torch.int8,) + f8:
+        raise ValueError("gate / up must be int8 (or float8) [F, K] tensors of one shape and dtype")
+    if block is None:
+        block = 16 if w_gate.dtype == torch.int8 else 32
+    if F_ % block != 0:
+        raise ValueError(f"gate / up: F % {block} == 0 expected")
     if out is None:
-        out = torch.empty((2 * F_, K), dtype=torch.int8, device=w_gate.device)
-    v = out.view(F_ // 16, 2, 16, K)
-    v[:, 0].copy_(w_gate.view(F_ // 16, 16, K))
-    v[:, 1].copy_(w_up.view(F_ // 16, 16, K))
+        out = torch.empty((2 * F_, K), dtype=w_gate.dtype, device=w_gate.device)
+    v = out.view(torch.uint8).view(F_ // block, 2, block, K)
+    v[:, 0].copy_(w_gate.view(torch.uint8).view(F_ // block, block, K))
+    v[:, 1].copy_(w_up.view(torch.uint8).view(F_ // block, block, K))
     return out
 
 
@@ -321,9 +327,9 @@ def interleave_gate_up_stack(w1, w3, out=None):
         raise ValueError("w1 / w3 must be [G, F, K] stacks of one shape")
     G, F_, K = w1.shape
     if out is None:
-        out = torch.empty((G, 2 * F_, K), dtype=torch.int8, device=w1.device)
-    elif tuple(out.shape) != (G, 2 * F_, K) or out.dtype != torch.int8 or out.device != w1.device or not out.is_contiguous():
-        raise ValueError("out must be a contiguous int8 [G, 2F, K] buffer on the stacks' device")
+        out = torch.empty((G, 2 * F_, K), dtype=w1.dtype, device=w1.device)
+    elif tuple(out.shape) != (G, 2 * F_, K) or out.dtype != w1.dtype or out.device != w1.device or not out.is_contiguous():
+        raise ValueError("out must be a contiguous [G, 2F, K] buffer of the stacks' dtype on their device")
     for g in range(G):
         interleave_gate_up(w1[g], w3[g], out=out[g])
     return out
@@ -784,6 +790,35 @@ def silu_mul_quantize_fp8(gate, up, fast=None):
         L.check(L.lib().asq_silu_mul_quantize_fp8(gate.data_ptr(), up.data_ptr(), _DT[gate.dtype], L.ASQ_SILU_FAST if fast else 0, xq.data_ptr(), sc.data_ptr(), M, K,
                                                   _stream(gate)), "asq_silu_mul_quantize_fp8")
     return xq.view(torch.float8_e4m3fn), sc.view(M, 1)
+
+
+def fp8_grouped_gate_up_supported(M, F, K, out_dtype):
+    return out_dtype in _DT and bool(L.lib().asq_fp8_grouped_gate_up_supported(int(M), int(F), int(K), _DT[out_dtype]))
+
+
+def linear_fp8_grouped_gate_up(xq, a_scale, w_gu, group_offsets, s_gate, s_up, out_dtype, fast=None):
+    """SiLU(w1 x) * (w3 x) of ALL groups in ONE grouped fp8 launch over the interleaved stacks w_gu [G, 2F, K] (interleave_gate_up_stack of two float8_e4m3fn stacks: blocks
+    of 32 channels; asq_linear_fp8_grouped_gate_up): out [M, F], bit-identical to linear_fp8_grouped (w1), (w3) and the SiLU * up of silu_mul_quantize_fp8(fast=...).
+    xq float8_e4m3fn [M, K] + a_scale f32 [M] or [M, 1] (quantize_act_fp8 per-token); s_gate / s_up f32 [G] on the device."""
+    if fast is None:
+        fast = not SILU_EXACT_DEFAULT
+    _dev(xq, "xq"), _dev(w_gu, "w_gu"), _dev(group_offsets, "group_offsets"), _dev(s_gate, "s_gate"), _dev(s_up, "s_up"), _dev(a_scale, "a_scale")
+    if xq.dtype != torch.float8_e4m3fn or w_gu.dtype != torch.float8_e4m3fn or xq.dim() != 2 or w_gu.dim() != 3 or xq.shape[1] != w_gu.shape[2] or w_gu.shape[1] % 2:
+        raise ValueError("xq [M,K] and w_gu [G,2F,K] must be float8_e4m3fn with equal K")
+    M, K = xq.shape
+    G, F_ = w_gu.shape[0], w_gu.shape[1] // 2
+    if group_offsets.dtype != torch.int32 or group_offsets.numel() != G + 1:
+        raise ValueError("group_offsets must be int32 with G + 1 elements")
+    for name, t, n in (("a_scale", a_scale, M), ("s_gate", s_gate, G), ("s_up", s_up, G)):
+        if t.dtype != torch.float32 or t.numel() != n:
+            raise ValueError(f"{name} must be float32 with {n} elements")
+    if not fp8_grouped_gate_up_supported(M, F_, K, out_dtype):
+        raise ValueError("shape not supported by the grouped fp8 gate || up launch (fp8_grouped_gate_up_supported)")
+    out = torch.empty((M, F_), dtype=out_dtype, device=xq.device)
+    with _on(xq.device):
+        L.check(L.lib().asq_linear_fp8_grouped_gate_up(xq.data_ptr(), w_gu.data_ptr(), out.data_ptr(), _DT[out_dtype], group_offsets.data_ptr(), G, M, F_, K, a_scale.data_ptr(),
+                                                       s_gate.data_ptr(), s_up.data_ptr(), L.ASQ_SILU_FAST if fast else 0, _stream(xq)), "asq_linear_fp8_grouped_gate_up")
+    return out
 
 
 def quantize_mxfp8(x):

@@ -242,7 +242,17 @@ def make_moe_workload_fp8(device, seed, dtype):
         h3 = ops.linear_fp8_grouped(xq, sx, st["w3"], st["s3"], st["offs"], dtype)
         aq, sa = ops.silu_mul_quantize_fp8(h1, h3, fast)
         return ops.linear_fp8_grouped(aq, sa, st["w2"], st["s2"], st["offs"], dtype)
-    st["grouped_fused"] = fused
+    st["grouped_fused"] = lambda: fused(False)        # fixed-operation-order SiLU (bit-identical to oracle/n1.py::silu_mul_quant_fp8_kernel_order)
+    st["grouped_fused_fast"] = lambda: fused(True)    # hardware-transcendental SiLU (the Python layer's default)
+    if ops.fp8_grouped_gate_up_supported(R, F_, H, dtype):
+        st["w13"] = ops.interleave_gate_up_stack(w1, w3)   # blocks of 32 channels (float8 stacks)
+
+        def gate_up(fast=True):   # round 6: w1 || w3 of all experts as ONE grouped fp8 launch with the SiLU * up epilogue, then w2's per-token quantiser
+            xq, sx = ops.quantize_act_fp8(st["x"], "per-token")
+            a = ops.linear_fp8_grouped_gate_up(xq, sx, st["w13"], st["offs"], st["s1"], st["s3"], dtype, fast)
+            aq, sa = ops.quantize_act_fp8(a, "per-token")
+            return ops.linear_fp8_grouped(aq, sa, st["w2"], st["s2"], st["offs"], dtype)
+        st["grouped_gate_up"] = gate_up
 
     s1h, s3h, s2h = st["s1"].tolist(), st["s3"].tolist(), st["s2"].tolist()
 
@@ -725,10 +735,13 @@ def other_configs_block(device, tdt):
         cfg5["fp8_grouped"] = {"ms": round(t8 / 1e3, 4), "TFLOPS": round(ops_ / t8 / 1e6, 1), "frac_of_fp8_dense_peak": round(ops_ / t8 / 1e6 / PEAK_FP8_TFLOPS, 4),
                                "peak_TFLOPS": PEAK_FP8_TFLOPS, "tokens_per_s": round(4096 / t8 * 1e6, 1),
                                "step": "quantise (per-token e4m3) + grouped w1, w3 + SiLU*mul (torch) + quantise + grouped w2"}
-        if "grouped_fused" in st8:
-            host, dev = _time_calls(st8["grouped_fused"], 20, 5)
-            t8f = max(host, dev)
-            cfg5["fp8_grouped_fused_silu"] = {"ms": round(t8f / 1e3, 4), "TFLOPS": round(ops_ / t8f / 1e6, 1), "frac_of_fp8_dense_peak": round(ops_ / t8f / 1e6 / PEAK_FP8_TFLOPS, 4)}
+        for key8, tag8 in (("grouped_fused_fast", "fp8_grouped_fused_silu"), ("grouped_gate_up", "fp8_grouped_gate_up_gemm")):
+            if key8 in st8:
+                if key8 == "grouped_gate_up":   # the same e4m3 codes into w2 as the fused SiLU kernel's path, bit for bit
+                    assert torch.equal(st8["grouped_gate_up"](), st8["grouped_fused_fast"]()), "fp8 grouped gate || up launch != w1, w3 launches + fused SiLU quantiser"
+                host, dev = _time_calls(st8[key8], 20, 5)
+                t8f = max(host, dev)
+                cfg5[tag8] = {"ms": round(t8f / 1e3, 4), "TFLOPS": round(ops_ / t8f / 1e6, 1), "frac_of_fp8_dense_peak": round(ops_ / t8f / 1e6 / PEAK_FP8_TFLOPS, 4)}
         del st8, grouped8, _seq8
     except Exception as e:
         cfg5["fp8_grouped"] = {"error": f"{type(e).__name__}: {e}"[:200]}

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ASQ_VERSION 124 /* 0.1.6: + asq_rope (caller-side glue: rotary embedding of a q / k projection's output in one pass); 0.1.5: + asq_silu_mul_quantize_fp8 (SiLU * up fused with the per-token e4m3 quantiser of the FP8 linear behind it); 0.1.4: + asq_linear_w8a8_gate_up_q8 (gate || up with an int8-out epilogue for per-tensor consumers); 0.1.3: + asq_grouped_gate_up_supported, asq_linear_w8a8_grouped_gate_up (Mixtral's w1 || w3 as one grouped launch with the SiLU * up epilogue); 0.1.2: + asq_forward_fused_supported, asq_linear_w8a8_forward_fused (the one-launch forward for decode-sized inputs; asq_linear_w8a8_forward takes it
+#define ASQ_VERSION 125 /* 0.1.7: + asq_fp8_grouped_gate_up_supported, asq_linear_fp8_grouped_gate_up (FP8LinearDynamic experts' w1 || w3 as one grouped launch with the SiLU * up epilogue); 0.1.6: + asq_rope (caller-side glue: rotary embedding of a q / k projection's output in one pass); 0.1.5: + asq_silu_mul_quantize_fp8 (SiLU * up fused with the per-token e4m3 quantiser of the FP8 linear behind it); 0.1.4: + asq_linear_w8a8_gate_up_q8 (gate || up with an int8-out epilogue for per-tensor consumers); 0.1.3: + asq_grouped_gate_up_supported, asq_linear_w8a8_grouped_gate_up (Mixtral's w1 || w3 as one grouped launch with the SiLU * up epilogue); 0.1.2: + asq_forward_fused_supported, asq_linear_w8a8_forward_fused (the one-launch forward for decode-sized inputs; asq_linear_w8a8_forward takes it
                            * by itself where it wins); ASQ_ROCTX=1 ranges.  0.1.1: + offset operand images (asq_*_off); workspace sizes include the 8 KiB header
                            * (asq_workspace_init is mandatory for a workspace handed to a GEMM entry point); asq_silu_mul_quantize's `per_token` is a bit field (bit 0
                            * per-token, ASQ_SILU_FAST) */
@@ -349,6 +349,16 @@ int asq_silu_mul_quantize_fp8(const void *gate, const void *up, int x_dtype, int
  * -- fp16: bit-identical to torch.addcmul(x1 * cos, x2, sin, value=-1) / torch.addcmul(x2 * cos, x1, sin) on this platform (the sum is rounded ONCE to fp16).
  * D % 16 == 0 (fp32: % 8); out may alias a dense x. */
 int asq_rope(const void *x, int64_t x_row_pitch, void *out, int x_dtype, const void *cos_tab, const void *sin_tab, int64_t B, int64_t S, int64_t H, int64_t D, void *stream);
+
+/* FP8LinearDynamic experts' w1 || w3 as ONE grouped launch whose epilogue writes SiLU(w1 x) * (w3 x) (round 6; reference models/mixtral.py:99-101,142-145 with every expert
+ * linear an FP8LinearDynamic, layers/nn/linear.py:413-427, easy_fp8_gemm :336-369): the fp8 counterpart of asq_linear_w8a8_grouped_gate_up.
+ *   xq e4m3fn [M, K] rows sorted by group + a_scale f32 [M] (asq_quantize_act_fp8 per-token); w_gu e4m3fn [ngroups][2 F][K]: every group's w1 and w3 ROW-INTERLEAVED in
+ *   blocks of 32 channels (rows 64 j .. 64 j + 31 = w1 channels 32 j .. + 31, rows 64 j + 32 .. 64 j + 63 = the same channels of w3); s_gate / s_up f32 [ngroups]: the two
+ *   stacks' per-expert weight scales; out [M, F] (ASQ_F16 / ASQ_BF16) = dt(dt(silu(y_1)) * y_3) with y = dt(acc * (a_scale[m] * w_scale)) -- bit-identical to
+ *   asq_linear_fp8_grouped (w1), (w3) and the SiLU * up of asq_silu_mul_quantize_fp8 with the same flags.  F % 128 == 0, K % 128 == 0. */
+int asq_fp8_grouped_gate_up_supported(int64_t M, int64_t F, int64_t K, int out_dtype);
+int asq_linear_fp8_grouped_gate_up(const uint8_t *xq, const uint8_t *w_gu, void *out, int out_dtype, const int32_t *group_offsets, int ngroups, int64_t M, int64_t F, int64_t K,
+                                   const float *a_scale, const float *s_gate, const float *s_up, int flags, void *stream);
 
 /* FP8E5M2Linear (linear.py:583-644): plain unscaled cast x -> e5m2 (round-to-nearest-even, IEEE-like
  * overflow to inf); the product then runs through asq_linear_fp8(..., ASQ_FP8_E5M2, ...) with unit scales.

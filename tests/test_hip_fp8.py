@@ -241,3 +241,63 @@ def test_silu_mul_quantize_fp8_feeds_the_fp8_linear(dev):
         FP8LinearDynamic(F_, N, "per-tensor").to(dev)(qa)
     with pytest.raises(ValueError):
         ops.silu_mul_quantize_fp8(gate.reshape(M, F_), up.reshape(M, F_)[:, :512])
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("counts", [[300, 0, 129, 512, 70], [1024, 1000], [256]])
+def test_fp8_grouped_gate_up_equals_the_composition(dt, counts, dev):
+    """asq_linear_fp8_grouped_gate_up (round 6): FP8LinearDynamic experts' w1 || w3 as one grouped launch with the SiLU * up epilogue == asq_linear_fp8_grouped (w1), (w3)
+    and the SiLU * up of asq_silu_mul_quantize_fp8, compared through w2's per-token e4m3 quantiser (codes and scales bit for bit), both SiLU forms, ragged groups
+    (empty, < 128 rows, not a multiple of 256), repeated launches."""
+    from autosmoothquant_amd import ops
+    G, M, F_, K = len(counts), sum(counts), 384, 512
+    g = torch.Generator(device=dev).manual_seed(41 + M)
+    w1 = (torch.randn(G, F_, K, generator=g, device=dev) * 0.5).to(torch.float8_e4m3fn)
+    w3 = (torch.randn(G, F_, K, generator=g, device=dev) * 0.5).to(torch.float8_e4m3fn)
+    s1 = torch.rand(G, generator=g, device=dev) * 0.02 + 0.01
+    s3 = torch.rand(G, generator=g, device=dev) * 0.02 + 0.01
+    x = (torch.randn(M, K, generator=g, device=dev) * 2).to(TDT[dt])
+    offs = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32, device=dev)
+    assert ops.fp8_grouped_gate_up_supported(M, F_, K, TDT[dt])
+    w13 = ops.interleave_gate_up_stack(w1, w3)
+    assert w13.dtype == torch.float8_e4m3fn and tuple(w13.shape) == (G, 2 * F_, K)
+    assert torch.equal(w13.view(torch.uint8).view(G, F_ // 32, 2, 32, K)[:, :, 0].reshape(G, F_, K), w1.view(torch.uint8))
+    xq, sx = ops.quantize_act_fp8(x, "per-token")
+    h1 = ops.linear_fp8_grouped(xq, sx, w1, s1, offs, TDT[dt])
+    h3 = ops.linear_fp8_grouped(xq, sx, w3, s3, offs, TDT[dt])
+    for fast in (False, True):
+        want_q, want_s = ops.silu_mul_quantize_fp8(h1, h3, fast=fast)
+        for rep in range(2):
+            a = ops.linear_fp8_grouped_gate_up(xq, sx, w13, offs, s1, s3, TDT[dt], fast)
+            got_q, got_s = ops.quantize_act_fp8(a, "per-token")
+            assert torch.equal(got_s, want_s), (dt, counts, fast, rep)
+            assert np.array_equal(F8.e4m3fn_to_f32(u8(got_q)), F8.e4m3fn_to_f32(u8(want_q)), equal_nan=True), (dt, counts, fast, rep)
+    with pytest.raises(ValueError):
+        ops.linear_fp8_grouped_gate_up(xq, sx, w13[:, : 2 * F_ - 2], offs, s1, s3, TDT[dt])
+
+
+def test_fp8_grouped_gate_up_at_mixtral_size(dev):
+    """8 experts, F = 14336, K = 4096, the bench's routing: the grouped fp8 gate || up launch against the two grouped launches + the fused SiLU quantiser (codes, scales)."""
+    from autosmoothquant_amd import ops
+    G, F_, K = 8, 14336, 4096
+    counts = [983, 1034, 1090, 1052, 1002, 1028, 995, 1008]
+    M = sum(counts)
+    g = torch.Generator(device=dev).manual_seed(77)
+    w1 = torch.randint(0, 256, (G, F_, K), generator=g, device=dev, dtype=torch.uint8)
+    w3 = torch.randint(0, 256, (G, F_, K), generator=g, device=dev, dtype=torch.uint8)
+    for w in (w1, w3):
+        w[(w & 0x7F) == 0x7F] = 0x38        # no NaN codes in the weights; magnitudes up to 448 are fine with the small scales below
+    w1, w3 = w1.view(torch.float8_e4m3fn), w3.view(torch.float8_e4m3fn)
+    s1 = torch.full((G,), 3e-4, device=dev) + torch.arange(G, device=dev) * 1e-5
+    s3 = torch.full((G,), 2e-4, device=dev) + torch.arange(G, device=dev) * 1e-5
+    x = torch.randn(M, K, generator=g, device=dev).half()
+    offs = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32, device=dev)
+    xq, sx = ops.quantize_act_fp8(x, "per-token")
+    h1 = ops.linear_fp8_grouped(xq, sx, w1, s1, offs, torch.float16)
+    h3 = ops.linear_fp8_grouped(xq, sx, w3, s3, offs, torch.float16)
+    want_q, want_s = ops.silu_mul_quantize_fp8(h1, h3, fast=True)
+    del h1, h3
+    a = ops.linear_fp8_grouped_gate_up(xq, sx, ops.interleave_gate_up_stack(w1, w3), offs, s1, s3, torch.float16, True)
+    got_q, got_s = ops.quantize_act_fp8(a, "per-token")
+    assert torch.equal(got_s, want_s)
+    assert torch.equal(got_q.view(torch.uint8), want_q.view(torch.uint8)) or np.array_equal(F8.e4m3fn_to_f32(u8(got_q)), F8.e4m3fn_to_f32(u8(want_q)), equal_nan=True)
