@@ -1250,7 +1250,7 @@ def main():
             M_k = M
             if M >= 2304 and not args.no_plain_compare and not args.graph:
                 operand_table = by_operands(mods, xs, tdt, args.settle_ms)
-            if M >= 2304 and not args.graph and args.workload == "llama7b_attn_linears":
+            if M >= 2304 and not args.graph and not args.no_plain_compare and args.workload == "llama7b_attn_linears":   # (not in the rocprofv3 passes: its launches carry the dominant kernel's name)
                 try:
                     whole_linear = whole_linear_block(mods, xs, tdt, args.settle_ms)
                 except Exception as e:   # (never at the cost of the line)
