@@ -110,6 +110,78 @@ __global__ void __launch_bounds__(256) fp8_quant_per_token(const void *__restric
     else emit(F8Tok<DT>{s});
 }
 
+// ---- one WAVE per row (round 6; the int8 side's quant_rows_wave, asq_quant.hip): the block kernel above reads every row twice behind two block-wide reductions -- at
+// Mixtral's w2 input (8192 x 14336 fp16) that is the slowest non-GEMM launch of the fp8 expert step.  Here a wave owns a row: NV non-temporal 16-byte loads per lane in
+// flight (inline asm, waits counted by hand: hipcc does not count asm memory operations), the maximum a wave butterfly, the row quantised from registers -- one HBM read,
+// no LDS, no barrier, 4 rows per block.  Same arithmetic, same functors as fp8_quant_per_token: bit-identical outputs.  Rows of up to 64 * 28 vectors (14336 fp16 elements).
+__device__ __forceinline__ void f8_load16_nt_async(v4i &dst, const void *p) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(dst) : "v"(p) : "memory"); }
+template <int DT, int NV>
+__global__ void __launch_bounds__(256) fp8_quant_rows_wave(const void *__restrict__ xv, uint8_t *__restrict__ xq, float *__restrict__ scale, int M, int K)
+{
+    constexpr int VEC = ElemT<DT>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (row >= M) return;   // (wave-uniform; nothing below synchronises across waves)
+    const int nvec = K / VEC;
+    const char *xrow = (const char *)xv + row * (int64_t)K * (16 / VEC);
+    v4i v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {   // a lane past the end of the row re-reads the row's last vector (a duplicate changes no maximum; its store is skipped)
+        const int idx = i * 64 + lane;
+        f8_load16_nt_async(v[i], xrow + (int64_t)(idx < nvec ? idx : nvec - 1) * 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AbsMax<DT> am;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        asm volatile("" : "+v"(v[i]));   // (uses of v[i] stay below the wait)
+        am.add(v[i]);
+    }
+    uint32_t mb = am.f32bits();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mb = umax32(mb, (uint32_t)__shfl_xor((int)mb, off, 64));
+    const float m = __uint_as_float(mb);
+    const float s = ElemT<DT>::round(m / 448.0f);  // rowabsmax.div(finfo.max) in x's dtype, then .to(float32)
+    if (lane == 0) scale[row] = s;
+    uint8_t *orow = xq + row * (int64_t)K;
+    auto emit = [&](auto q) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = i * 64 + lane;
+            uint32_t o[2];
+            f8_quant_vec<DT>(v[i], q, o);
+            if (idx < nvec) {
+                if constexpr (DT == ASQ_F32) *(uint32_t *)(orow + (int64_t)idx * 4) = o[0];
+                else *(uint2 *)(orow + (int64_t)idx * 8) = make_uint2(o[0], o[1]);
+            }
+        }
+    };
+    const RowDivisor d(s, m);
+    if (d.fast) emit(F8TokFast{QRowFast{d.s, d.y}});
+    else emit(F8Tok<DT>{s});
+}
+
+template <int DT> static bool launch_fp8_rows_wave(const void *x, uint8_t *xq, float *scale, int64_t M, int64_t K, hipStream_t s)
+{
+    constexpr int VEC = ElemT<DT>::VEC;
+    static const bool on = [] { const char *e = getenv("ASQ_FP8_ROWS_WAVE"); return !(e && e[0] == '0'); }();   // 0: the block kernel everywhere (A/B)
+    const int64_t nvec = K / VEC;
+    if (!on || nvec > 64 * 28 || nvec < 1 || M >= (1ll << 31)) return false;
+    const int nv = (int)((nvec + 63) / 64);
+    dim3 grid((unsigned)((M + 3) / 4)), block(256);
+#define ASQ_F8RW(NV) hipLaunchKernelGGL((fp8_quant_rows_wave<DT, NV>), grid, block, 0, s, x, xq, scale, (int)M, (int)K)
+    if (nv <= 1) ASQ_F8RW(1);
+    else if (nv <= 2) ASQ_F8RW(2);
+    else if (nv <= 4) ASQ_F8RW(4);
+    else if (nv <= 8) ASQ_F8RW(8);
+    else if (nv <= 12) ASQ_F8RW(12);
+    else if (nv <= 16) ASQ_F8RW(16);
+    else if (nv <= 22) ASQ_F8RW(22);
+    else ASQ_F8RW(28);
+#undef ASQ_F8RW
+    return true;
+}
+
 // dynamic per-tensor, pass 1: absmax into a device word (non-negative floats order like their bit patterns,
 // NaN patterns above +inf: the integer atomicMax propagates NaN as torch's aminmax does)
 template <int DT> __global__ void __launch_bounds__(256) fp8_absmax(const void *__restrict__ xv, int64_t n, bool vec, unsigned *__restrict__ amax_bits)
@@ -175,6 +247,7 @@ int fp8_quantize_dt(const void *x, int mode, float static_scale, uint8_t *xq, fl
     const int64_t n = M * K;
     if (mode == ASQ_FP8_PER_TOKEN) {
         const bool vec = (K % VEC == 0) && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)xq) & 7) == 0);
+        if (vec && launch_fp8_rows_wave<DT>(x, xq, scale_out, M, K, s)) return asq_after_launch(s, "asq_quantize_act_fp8(per-token)");
         hipLaunchKernelGGL((fp8_quant_per_token<DT>), dim3((unsigned)M), dim3(256), 0, s, x, xq, scale_out, K, vec);
         return asq_after_launch(s, "asq_quantize_act_fp8(per-token)");
     }
