@@ -12,7 +12,7 @@ ASQ_EPI_SCALE_FIRST, ASQ_EPI_ACC_FIRST = 0, 1
 ASQ_SILU_FAST = 2   # bit 1 of asq_silu_mul_quantize's per_token / asq_linear_w8a8_gate_up's flags
 ASQ_FP8_PER_TOKEN, ASQ_FP8_PER_TENSOR, ASQ_FP8_STATIC = 0, 1, 2
 
-ASQ_VERSION = 125   # include/asq_hip.h: the C-ABI this loader was written against
+ASQ_VERSION = 126   # include/asq_hip.h: the C-ABI this loader was written against
 _lock = threading.Lock()
 _lib = None
 
@@ -33,6 +33,8 @@ SIGNATURES = {
     "asq_silu_mul_quantize": (_int, [_vp, _vp, _int, _int, _f32, _vp, _vp, _i64, _i64, _vp]),
     "asq_silu_mul_quantize_fp8": (_int, [_vp, _vp, _int, _int, _vp, _vp, _i64, _i64, _vp]),
     "asq_rope": (_int, [_vp, _i64, _vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "asq_rmsnorm": (_int, [_vp, _int, _vp, _f32, _vp, _i64, _i64, _vp]),
+    "asq_silu_mul": (_int, [_vp, _vp, _int, _int, _vp, _i64, _vp]),
     "asq_fp8_grouped_gate_up_supported": (_int, [_i64, _i64, _i64, _int]),
     "asq_linear_fp8_grouped_gate_up": (_int, [_vp, _vp, _vp, _int, _vp, _int, _i64, _i64, _i64, _vp, _vp, _vp, _int, _vp]),
     "asq_linear_w8a8": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _int, _vp, _sz, _vp]),

@@ -691,6 +691,72 @@ __global__ void __launch_bounds__(256) norm_quant_cached(const void *xv, const v
     }
 }
 
+// ---- the same two operations WITHOUT the quantiser (round 6): caller-side glue for the reference's module composition, where the norm and the activation are modules of
+// their own between the W8A8 linears (models/llama.py:27-37 QuantizedLlamaRMSNorm with the folded weight -> a floating tensor each linear quantises itself; :206-211 /
+// HF LlamaMLP act_fn(gate) * up).  As torch ops they are 7 + 2 elementwise / reduction kernels per use (14.6 % + 6.3 % of the GPU time of BASELINE configs[2]'s forward
+// in that composition, profiles/r6_cfg3_kernel_stats.txt); here one pass each.  Arithmetic: norm_quant_cached's y / silu_mul_quant_cached's a, i.e. HF's roundings
+// (n = dt(f32(x) * rsqrt(var + eps)), y = dt(w * n); a = dt(dt(silu(g)) * u)) in this file's fixed operation order (oracle/n1.py repeats it bit for bit).
+template <int DT, int NV> __global__ void __launch_bounds__(256) rmsnorm_rows(const void *__restrict__ xv, const void *__restrict__ wv, float eps, void *__restrict__ yv, int K)
+{
+    constexpr int VEC = ElemT<DT>::VEC;
+    __shared__ float red[4];
+    const int64_t rowoff = (int64_t)blockIdx.x * (int64_t)K * (16 / VEC);
+    const int nvec = K / VEC;
+    float f[NV][VEC];
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = i * 256 + threadIdx.x;
+        if (idx < nvec) {
+            vec_unpack<DT>(*(const v4i *)((const char *)xv + rowoff + (int64_t)idx * 16), f[i]);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) sq = __fadd_rn(sq, __fmul_rn(f[i][j], f[i][j]));
+        }
+    }
+    const float var = __fdiv_rn(block_sum_256(sq, red), (float)K);
+    const float rs = rsqrt_exact(__fadd_rn(var, eps));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = i * 256 + threadIdx.x;
+        if (idx < nvec) {
+            float wf[VEC];
+            vec_unpack<DT>(*(const v4i *)((const char *)wv + (int64_t)idx * 16), wf);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float n = ElemT<DT>::round(__fmul_rn(f[i][j], rs));  // hidden_states.to(input_dtype)
+                f[i][j] = ElemT<DT>::round(__fmul_rn(wf[j], n));           // self.weight * ...
+            }
+            *(v4i *)((char *)yv + rowoff + (int64_t)idx * 16) = vec_pack<DT>(f[i]);
+        }
+    }
+}
+
+template <int DT, bool FAST> __global__ void __launch_bounds__(256) silu_mul_flat(const void *__restrict__ gv, const void *__restrict__ uv, void *__restrict__ ov, int64_t nvec)
+{
+    constexpr int VEC = ElemT<DT>::VEC;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (int64_t)gridDim.x * 256) {
+        float g[VEC];
+        vec_unpack<DT>(*((const v4i *)gv + idx), g);
+        const v4i uw = *((const v4i *)uv + idx);
+        v4i o;
+        if constexpr (DT == ASQ_F16) {
+#pragma unroll
+            for (int j = 0; j < VEC; j += 2) o[j / 2] = (int)silu_times_up_h(silu2<FAST>(g[j], g[j + 1]), (uint32_t)uw[j / 2]);
+        } else {
+            float u[VEC], a[VEC];
+            vec_unpack<DT>(uw, u);
+#pragma unroll
+            for (int j = 0; j < VEC; j += 2) {
+                const v2f pr = silu_times_up<DT>(silu2<FAST>(g[j], g[j + 1]), u[j], u[j + 1]);
+                a[j] = pr[0];
+                a[j + 1] = pr[1];
+            }
+            o = vec_pack<DT>(a);
+        }
+        *((v4i *)ov + idx) = o;
+    }
+}
+
 template <int DT, bool LN, bool PT, bool ADD = false>
 int launch_norm_quant(const void *x, const void *w, const void *b, float eps, int8_t *xq, float *s_row, int64_t M, int64_t K, hipStream_t s,
                       const void *res = nullptr, void *hout = nullptr, int32_t *row_off = nullptr, int C = 0)
@@ -1036,4 +1102,56 @@ extern "C" int asq_silu_mul_quantize_off(const void *gate, const void *up, int x
     ASQ_REQUIRE(M == 0 || (row_off != nullptr && ((uintptr_t)row_off & 7) == 0), ASQ_ERR_NULL, "asq_silu_mul_quantize_off: row_off NULL or not 8-B aligned");
     ASQ_REQUIRE(K <= 65536, ASQ_ERR_DIM, "asq_silu_mul_quantize_off: K <= 65536");
     return silu_mul_quantize_impl(gate, up, x_dtype, per_token, quant_scale, xq, s_row, row_off, M, K, stream);
+}
+
+extern "C" int asq_rmsnorm(const void *x, int x_dtype, const void *weight, float eps, void *y, int64_t M, int64_t K, void *stream)
+{
+    const AsqRange range_("asq_rmsnorm");
+    ASQ_REQUIRE(M >= 0 && K > 0 && M < (1ll << 31), ASQ_ERR_DIM, "asq_rmsnorm: bad dims");
+    ASQ_REQUIRE(x_dtype == ASQ_F32 || x_dtype == ASQ_F16 || x_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_rmsnorm: bad x_dtype %d", x_dtype);
+    if (M == 0) return ASQ_OK;
+    ASQ_REQUIRE(x && weight && y, ASQ_ERR_NULL, "asq_rmsnorm: NULL pointer");
+    const int vec = x_dtype == ASQ_F32 ? 4 : 8;
+    ASQ_REQUIRE(K % vec == 0 && K / vec <= 256 * 8, ASQ_ERR_DIM, "asq_rmsnorm: K must be a multiple of %d and <= %d", vec, 256 * 8 * vec);
+    ASQ_REQUIRE(((((uintptr_t)x) | ((uintptr_t)weight) | ((uintptr_t)y)) & 15) == 0, ASQ_ERR_ALIGN, "asq_rmsnorm: x / weight / y must be 16-B aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nvec = K / vec;
+    dim3 grid((unsigned)M), block(256);
+#define ASQ_RN(DT_, NV) hipLaunchKernelGGL((rmsnorm_rows<DT_, NV>), grid, block, 0, s, x, weight, eps, y, (int)K)
+#define ASQ_RN_DT(DT_) do { if (nvec <= 256) ASQ_RN(DT_, 1); else if (nvec <= 512) ASQ_RN(DT_, 2); else if (nvec <= 1024) ASQ_RN(DT_, 4); else ASQ_RN(DT_, 8); } while (0)
+    switch (x_dtype) {
+    case ASQ_F32: ASQ_RN_DT(ASQ_F32); break;
+    case ASQ_F16: ASQ_RN_DT(ASQ_F16); break;
+    default: ASQ_RN_DT(ASQ_BF16); break;
+    }
+#undef ASQ_RN_DT
+#undef ASQ_RN
+    return asq_after_launch(s, "asq_rmsnorm");
+}
+
+extern "C" int asq_silu_mul(const void *gate, const void *up, int x_dtype, int flags, void *out, int64_t n, void *stream)
+{
+    const AsqRange range_("asq_silu_mul");
+    ASQ_REQUIRE(n >= 0, ASQ_ERR_DIM, "asq_silu_mul: bad size");
+    ASQ_REQUIRE(x_dtype == ASQ_F32 || x_dtype == ASQ_F16 || x_dtype == ASQ_BF16, ASQ_ERR_DTYPE, "asq_silu_mul: bad x_dtype %d", x_dtype);
+    ASQ_REQUIRE((flags & ~ASQ_SILU_FAST) == 0, ASQ_ERR_DTYPE, "asq_silu_mul: flags is 0 or ASQ_SILU_FAST, got %d", flags);
+    if (n == 0) return ASQ_OK;
+    ASQ_REQUIRE(gate && up && out, ASQ_ERR_NULL, "asq_silu_mul: NULL pointer");
+    const int vec = x_dtype == ASQ_F32 ? 4 : 8;
+    ASQ_REQUIRE(n % vec == 0, ASQ_ERR_DIM, "asq_silu_mul: the element count must be a multiple of %d", vec);
+    ASQ_REQUIRE(((((uintptr_t)gate) | ((uintptr_t)up) | ((uintptr_t)out)) & 15) == 0, ASQ_ERR_ALIGN, "asq_silu_mul: gate / up / out must be 16-B aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nvec = n / vec;
+    int64_t blocks = (nvec + 255) / 256;
+    blocks = blocks > 256 * 64 ? 256 * 64 : blocks;
+    const bool fast = (flags & ASQ_SILU_FAST) != 0;
+#define ASQ_SM_DT(DT_) do { if (fast) hipLaunchKernelGGL((silu_mul_flat<DT_, true>), dim3((unsigned)blocks), dim3(256), 0, s, gate, up, out, nvec); \
+                            else hipLaunchKernelGGL((silu_mul_flat<DT_, false>), dim3((unsigned)blocks), dim3(256), 0, s, gate, up, out, nvec); } while (0)
+    switch (x_dtype) {
+    case ASQ_F32: ASQ_SM_DT(ASQ_F32); break;
+    case ASQ_F16: ASQ_SM_DT(ASQ_F16); break;
+    default: ASQ_SM_DT(ASQ_BF16); break;
+    }
+#undef ASQ_SM_DT
+    return asq_after_launch(s, "asq_silu_mul");
 }

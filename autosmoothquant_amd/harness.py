@@ -25,6 +25,16 @@ class RMSNorm(torch.nn.Module):
         self.eps = eps
 
     def forward(self, x):
+        w = self.weight
+        if (GLUE_KERNELS and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and w.dtype == x.dtype and x.shape[-1] % 8 == 0 and x.shape[-1] <= 16384
+                and not torch.is_grad_enabled()):
+            # one pass instead of seven torch kernels (round 6: 14.6 % of the GPU time of BASELINE configs[2]'s forward in the reference's module composition); HF
+            # LlamaRMSNorm's roundings, this library's summation order (bit-identical to oracle/n1.py, within an ulp of the torch ops below)
+            from . import ops
+            x2 = x.reshape(-1, x.shape[-1])
+            x2 = x2 if x2.is_contiguous() else x2.contiguous()
+            if x2.data_ptr() % 16 == 0 and w.is_contiguous() and w.data_ptr() % 16 == 0:
+                return ops.rmsnorm(x2, w.detach(), self.eps).view(x.shape)
         v = x.float()
         v = v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + self.eps)
         return self.weight * v.to(x.dtype)
@@ -66,6 +76,16 @@ def _rope(x, theta=10000.0):
 
 
 ROPE_KERNEL = os.environ.get("ASQ_ROPE_KERNEL", "1") != "0"   # 0: the torch composition everywhere (A/B)
+GLUE_KERNELS = os.environ.get("ASQ_GLUE_KERNELS", "1") != "0"  # 0: RMSNorm / SiLU * up of the reference composition as torch ops (A/B)
+
+
+def _silu_mul(gate, up):
+    """F.silu(gate) * up; on the device in the 16-bit dtypes one pass (ops.silu_mul, round 6) instead of two torch kernels"""
+    if (GLUE_KERNELS and gate.is_cuda and gate.dtype in (torch.float16, torch.bfloat16) and gate.shape == up.shape and gate.is_contiguous() and up.is_contiguous()
+            and gate.numel() % 8 == 0 and gate.data_ptr() % 16 == 0 and up.data_ptr() % 16 == 0 and not torch.is_grad_enabled()):
+        from . import ops
+        return ops.silu_mul(gate, up)
+    return F.silu(gate) * up
 
 
 def _rope_torch(x, theta=10000.0):
@@ -221,7 +241,7 @@ class LlamaLayer(torch.nn.Module):
             from .layers.nn.fused import silu_mul_q
             d = self.down_proj(silu_mul_q(gate, up, self.down_proj, fast=getattr(self, "fast_silu", None)))
             return DeferredResidual(h, d) if getattr(self, "defer_residual", False) else h + d
-        g = F.silu(gate) * up
+        g = _silu_mul(gate, up)
         if record is not None:
             record["down_in"] = g
         return h + self.down_proj(g)

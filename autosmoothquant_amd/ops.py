@@ -746,6 +746,33 @@ def quantize_act_fp8(x, mode, static_scale=1.0):
     return xq, float(static_scale)
 
 
+def rmsnorm(x, weight, eps=1e-5):
+    """y = weight * dt(f32(x) * rsqrt(mean(x^2) + eps)) in ONE pass (asq_rmsnorm): HF LlamaRMSNorm's arithmetic with a floating output -- the norm as a module of its own, as
+    the reference's composition has it (models/llama.py:27-37); the N1 form norm_quantize emits int8 instead.  x [M,K], weight [K] of x's dtype."""
+    _dev(x, "x"), _dev(weight, "weight")
+    if x.dtype not in _DT or x.dim() != 2 or weight.dtype != x.dtype or weight.numel() != x.shape[1]:
+        raise ValueError("x must be 2-D float and weight a [K] tensor of the same dtype")
+    M, K = x.shape
+    y = torch.empty_like(x)
+    with _on(x.device):
+        L.check(L.lib().asq_rmsnorm(x.data_ptr(), _DT[x.dtype], weight.data_ptr(), float(eps), y.data_ptr(), M, K, _stream(x)), "asq_rmsnorm")
+    return y
+
+
+def silu_mul(gate, up, fast=None):
+    """silu(gate) * up in the activation dtype in ONE pass (asq_silu_mul): dt(dt(silu(g)) * u), the two roundings of F.silu(gate) * up -- the gated activation as an op of
+    its own, as the reference's composition has it (HF LlamaMLP); the N1 form silu_mul_quantize emits int8 instead.  gate / up: contiguous tensors of one shape and dtype."""
+    if fast is None:
+        fast = not SILU_EXACT_DEFAULT
+    _dev(gate, "gate"), _dev(up, "up")
+    if gate.dtype not in _DT or up.dtype != gate.dtype or up.shape != gate.shape:
+        raise ValueError("gate and up must be float tensors of equal shape and dtype")
+    out = torch.empty_like(gate)
+    with _on(gate.device):
+        L.check(L.lib().asq_silu_mul(gate.data_ptr(), up.data_ptr(), _DT[gate.dtype], L.ASQ_SILU_FAST if fast else 0, out.data_ptr(), gate.numel(), _stream(gate)), "asq_silu_mul")
+    return out
+
+
 def rope(x, cos, sin, out=None):
     """Rotary embedding of x [B, S, H, D] in one pass (asq_rope): x is a q / k projection's output viewed per head -- dense, or a slice of a fused q || k || v output
     (strides (S * ld, ld, D, 1) with ld >= H * D); cos / sin [S, D/2] of x's dtype, positions 0 .. S-1, rotate_half convention.  Returns a DENSE [B, S, H, D] tensor

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ASQ_VERSION 125 /* 0.1.7: + asq_fp8_grouped_gate_up_supported, asq_linear_fp8_grouped_gate_up (FP8LinearDynamic experts' w1 || w3 as one grouped launch with the SiLU * up epilogue); 0.1.6: + asq_rope (caller-side glue: rotary embedding of a q / k projection's output in one pass); 0.1.5: + asq_silu_mul_quantize_fp8 (SiLU * up fused with the per-token e4m3 quantiser of the FP8 linear behind it); 0.1.4: + asq_linear_w8a8_gate_up_q8 (gate || up with an int8-out epilogue for per-tensor consumers); 0.1.3: + asq_grouped_gate_up_supported, asq_linear_w8a8_grouped_gate_up (Mixtral's w1 || w3 as one grouped launch with the SiLU * up epilogue); 0.1.2: + asq_forward_fused_supported, asq_linear_w8a8_forward_fused (the one-launch forward for decode-sized inputs; asq_linear_w8a8_forward takes it
+#define ASQ_VERSION 126 /* 0.1.8: + asq_rmsnorm, asq_silu_mul (caller-side glue of the reference's module composition: the norm and the gated activation as one pass each, floating outputs); 0.1.7: + asq_fp8_grouped_gate_up_supported, asq_linear_fp8_grouped_gate_up (FP8LinearDynamic experts' w1 || w3 as one grouped launch with the SiLU * up epilogue); 0.1.6: + asq_rope (caller-side glue: rotary embedding of a q / k projection's output in one pass); 0.1.5: + asq_silu_mul_quantize_fp8 (SiLU * up fused with the per-token e4m3 quantiser of the FP8 linear behind it); 0.1.4: + asq_linear_w8a8_gate_up_q8 (gate || up with an int8-out epilogue for per-tensor consumers); 0.1.3: + asq_grouped_gate_up_supported, asq_linear_w8a8_grouped_gate_up (Mixtral's w1 || w3 as one grouped launch with the SiLU * up epilogue); 0.1.2: + asq_forward_fused_supported, asq_linear_w8a8_forward_fused (the one-launch forward for decode-sized inputs; asq_linear_w8a8_forward takes it
                            * by itself where it wins); ASQ_ROCTX=1 ranges.  0.1.1: + offset operand images (asq_*_off); workspace sizes include the 8 KiB header
                            * (asq_workspace_init is mandatory for a workspace handed to a GEMM entry point); asq_silu_mul_quantize's `per_token` is a bit field (bit 0
                            * per-token, ASQ_SILU_FAST) */
@@ -359,6 +359,14 @@ int asq_rope(const void *x, int64_t x_row_pitch, void *out, int x_dtype, const v
 int asq_fp8_grouped_gate_up_supported(int64_t M, int64_t F, int64_t K, int out_dtype);
 int asq_linear_fp8_grouped_gate_up(const uint8_t *xq, const uint8_t *w_gu, void *out, int out_dtype, const int32_t *group_offsets, int ngroups, int64_t M, int64_t F, int64_t K,
                                    const float *a_scale, const float *s_gate, const float *s_up, int flags, void *stream);
+
+/* Caller-side glue for the reference's MODULE composition (round 6; not reference-path functions): the modules that sit between the W8A8 linears there -- the folded
+ * RMSNorm (models/llama.py:27-37, HF LlamaRMSNorm's arithmetic) and the gated activation act_fn(gate) * up (models/llama.py:206-211) -- each as ONE pass with a floating
+ * output that the next linear quantises itself; the fused (N1) forms above emit int8 instead.
+ *   asq_rmsnorm:  y = dt(weight * dt(f32(x) * rsqrt(mean(f32(x)^2) + eps)));  x, y [M,K], weight [K] of x_dtype; K % 8 == 0 (fp32: % 4), K <= 16384 (8192).
+ *   asq_silu_mul: out = dt(dt(silu(gate)) * up) over n elements (n % 8 == 0; fp32: % 4); flags: 0 = fixed-operation-order SiLU (oracle/n1.py), ASQ_SILU_FAST. */
+int asq_rmsnorm(const void *x, int x_dtype, const void *weight, float eps, void *y, int64_t M, int64_t K, void *stream);
+int asq_silu_mul(const void *gate, const void *up, int x_dtype, int flags, void *out, int64_t n, void *stream);
 
 /* FP8E5M2Linear (linear.py:583-644): plain unscaled cast x -> e5m2 (round-to-nearest-even, IEEE-like
  * overflow to inf); the product then runs through asq_linear_fp8(..., ASQ_FP8_E5M2, ...) with unit scales.

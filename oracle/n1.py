@@ -144,6 +144,19 @@ def silu_mul_quant_kernel_order(gate, up, dt: str, per_token: bool = True, quant
     return O.act_quant_div(a, dt, quant_scale), None
 
 
+def rmsnorm_kernel_order(x, dt: str, weight, eps: float = 1e-5) -> np.ndarray:
+    """asq_rmsnorm: y = dt(w * dt(x * rsqrt(mean(x^2) + eps))) with the block kernel's summation order (the fp-out twin of norm_quant_kernel_order)."""
+    return _norm_y_kernel_order(x, dt, weight, None, eps)
+
+
+def silu_mul_kernel_order(gate, up, dt: str) -> np.ndarray:
+    """asq_silu_mul (exact form): a = dt(dt(g / (1 + exp_det(-g))) * u) -- silu_mul_quant_kernel_order's activation without the quantiser."""
+    g, u = np.asarray(gate, dtype=F32), np.asarray(up, dtype=F32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        sl = O.round_to((g / (F32(1.0) + exp_det(-g)).astype(F32)).astype(F32), dt)
+        return O.round_to((sl * u).astype(F32), dt)
+
+
 def silu_mul_quant_fp8_kernel_order(gate, up, dt: str):
     """asq_silu_mul_quantize_fp8 (exact form): a = dt(dt(g / (1 + exp_det(-g))) * u) -- silu_mul_quant_kernel_order's activation -- then the reference's
     per_token_quantize_fp8 (layers/functional/quantization.py:173-191, restated and G5-pinned in oracle/fp8.py).  Returns (e4m3fn bytes [M,K], scale f32 [M,1])."""

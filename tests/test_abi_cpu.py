@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(h, n), f"libasq_hip.so lacks {n}"
         assert n in _lib.SIGNATURES, f"_lib.SIGNATURES lacks {n}"
     assert sorted(_lib.SIGNATURES) == names
-    assert h.asq_version() == _lib.ASQ_VERSION == 125
+    assert h.asq_version() == _lib.ASQ_VERSION == 126
 
 
 def test_argument_errors_without_gpu():

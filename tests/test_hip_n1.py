@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+import detrng
 import goldenio
 from oracle import n1, w8a8 as O
 
@@ -219,3 +220,48 @@ def test_opt_mlp_fused_chain_equals_unfused():
         assert float((fused.float() - ref).norm() / ref.norm()) < 5e-2
     with pytest.raises(ValueError):
         fc1.forward_q(qa, W8A8BFP32OFP32LinearWithQuantScale(F, H, False, "per-token").to(DEV))
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("shape", [(5, 64), (33, 4096), (7, 5120), (3, 11008), (2, 8192)])
+def test_rmsnorm_and_silu_mul_fp_out_vs_oracle_and_torch(dt, shape):
+    """Round 6 glue kernels for the reference's MODULE composition: asq_rmsnorm (fp out) == oracle/n1.py::rmsnorm_kernel_order bit for bit and within an ulp of the
+    torch ops of HF's LlamaRMSNorm; asq_silu_mul exact form == oracle/n1.py::silu_mul_kernel_order bit for bit, both forms within an ulp or two of F.silu(g) * u."""
+    from autosmoothquant_amd import ops
+    M, K = shape
+    if dt == "f32" and K > 8192:
+        pytest.skip("fp32 rows up to 8192")
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    x = O.round_to(detrng.act_like(701, M + K, (M, K), scale=2.0), dt)
+    w = O.round_to((detrng.act_like(702, K, (1, K), scale=0.3)[0] + 1.0), dt)
+    xt, wt = torch.from_numpy(x).to(tdt).to(DEV), torch.from_numpy(w).to(tdt).to(DEV)
+    y = ops.rmsnorm(xt, wt, 1e-5)
+    assert np.array_equal(y.float().cpu().numpy(), n1.rmsnorm_kernel_order(x, dt, w, 1e-5))
+    v = xt.float()
+    ref = wt * (v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-5)).to(tdt)
+    ulp = {"f32": 2.0 ** -22, "f16": 2.0 ** -10, "bf16": 2.0 ** -7}[dt]
+    assert float(((y.float() - ref.float()).abs() / ref.float().abs().clamp_min(1e-3)).max()) <= 2 * ulp
+    g = O.round_to(detrng.act_like(703, M * 3 + K, (M, K), scale=2.5), dt)
+    u = O.round_to(detrng.act_like(704, M * 5 + K, (M, K), scale=1.5), dt)
+    gt, ut = torch.from_numpy(g).to(tdt).to(DEV), torch.from_numpy(u).to(tdt).to(DEV)
+    a = ops.silu_mul(gt, ut, fast=False)
+    assert np.array_equal(a.float().cpu().numpy(), n1.silu_mul_kernel_order(g, u, dt))
+    want = (torch.nn.functional.silu(gt) * ut).float()
+    for fast in (False, True):
+        got = ops.silu_mul(gt, ut, fast=fast).float()
+        assert float(((got - want).abs() / want.abs().clamp_min(1e-2)).max()) <= 4 * ulp, (dt, shape, fast)
+    with pytest.raises(ValueError):
+        ops.silu_mul(gt, ut[:, : K // 2])
+
+
+def test_harness_rmsnorm_module_takes_the_kernel():
+    from autosmoothquant_amd import harness
+    n = harness.RMSNorm(4096, 1e-5).to(DEV).half()
+    with torch.no_grad():
+        n.weight.copy_(torch.rand(4096, device=DEV) + 0.5)
+        x = (torch.randn(2, 33, 4096, device=DEV) * 2).half()
+        y = n(x)
+        v = x.float()
+        ref = n.weight * (v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-5)).half()
+    assert y.shape == x.shape and float((y.float() - ref.float()).abs().max()) <= 2.0 ** -9 * float(ref.float().abs().max())
+    assert torch.equal(y, __import__("autosmoothquant_amd").ops.rmsnorm(x.view(-1, 4096), n.weight.detach(), 1e-5).view(x.shape))
