@@ -555,6 +555,11 @@ def whole_linear_block(mods, xs, tdt, settle_ms, iters=10, batch=50):
     t_n = timed(lambda: norm(hidden, consumers=(mod,)))
     out["n1"] = entry(t_n1, {"norm_quant_us": round(t_n, 2), "gemm_us": round(t_n1 - t_n, 2), "launches": 2,
                              "note": "RMSNorm + quantise is ONE pass over the hidden state (asq_norm_quantize[_off]); the model runs the norm anyway, so the quantiser costs no extra pass"})
+    # what the N1 composition replaces in a decoder: the norm as a module of its own (floating output, asq_rmsnorm) followed by the stand-alone module forward
+    from autosmoothquant_amd import ops as _ops
+    wn = norm.weight
+    t_ref = timed(lambda: mod(_ops.rmsnorm(hidden, wn, 1e-5)))
+    out["norm_then_standalone"] = entry(t_ref, {"launches": 3, "note": "RMSNorm (fp out) + quantiser + GEMM: the reference's module composition around the same linear; n1 is this minus one pass over the activation"})
     return out
 
 

@@ -143,6 +143,8 @@ def test_graph_replay_follows_a_weight_update_after_refresh(images):
     gu = GateUpSiLU(gate, up)
     root = torch.nn.ModuleDict({"gate": gate, "up": up, "gu": gu})
     xh = x.half()
+    if images and not ops.offsets_supported(M, 2 * F, K, torch.float16):
+        pytest.skip("offset operand images are switched off in this process (ASQ_OFFSETS=0)")
     if images:
         xo, s_row, row_off = ops.quantize_act_off(xh, "per-tensor-round")
         qa = QuantizedActivation(xo, s_row, torch.float16, (M,), row_off)
