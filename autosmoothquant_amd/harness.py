@@ -722,7 +722,7 @@ class MixtralLayer(LlamaLayer):
             except torch.cuda.OutOfMemoryError:
                 return hit[1], None
             hit[2], hit[3] = (img.view(E, N2, K), col), True
-        return hit[1], (hit[2] if hit[3] else None)
+        return hit[1], (hit[2] if (want_image and hit[3]) else None)
 
     def build_offset_images(self):
         """Build the three stacks' images (and, with fuse_gate_up, the w1 || w3 operand and its image) now -- load time -- instead of inside the first grouped forward,
@@ -782,7 +782,7 @@ class MixtralLayer(LlamaLayer):
                 # offset operand images (include/asq_hip.h): same products, less matrix-core energy; the stacks' images are built once and follow the stacks
                 i1, i3, i2 = (self._stack_image(n) for n in ("w1", "w3", "w2"))
             else:
-                i1 = None
+                i1 = i3 = i2 = None
             F2 = self._w1_stack.shape[1]
             gate_up = (getattr(self, "fuse_gate_up", False) and mode != "per-token" and ops.grouped_gate_up_supported(R, F2, H, x.dtype))
             if gate_up:

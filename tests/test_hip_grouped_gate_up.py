@@ -158,3 +158,43 @@ def test_mixtral_graph_replay_follows_a_weight_update_after_refresh():
         torch.cuda.synchronize()
         want = ops.linear_w8a8_grouped_gate_up(xq, ops.interleave_gate_up_stack(lay._w1_stack, lay._w3_stack), offs, lay._w1_scale, lay._w3_scale, torch.float16, True)
         assert torch.equal(out_g, want) and not torch.equal(want, old)
+
+
+def test_mixtral_stacks_without_a_version_counter_get_images_only_on_request():
+    """a MixtralLayer built under torch.inference_mode() has stacks without a version counter -- writes into them cannot be seen, so by default the grouped
+    launches run on plain operands and the grouped gate || up launch is off; MixtralLayer.build_offset_images() is the opt-in (the caller then owns the refresh), after
+    which the same forward runs on images + the fused launch and gives the same expert outputs as the fused-SiLU composition on plain operands; GateUpSiLU.build() likewise."""
+    from autosmoothquant_amd import harness
+    from autosmoothquant_amd.layers.nn.fused import GateUpSiLU
+    from autosmoothquant_amd.layers.nn.linear import W8A8BFP32OFP32Linear
+    torch.manual_seed(8)
+    fl = harness.MixtralLayer(256, 384, 4, 2, experts=4, top_k=2)
+    with torch.no_grad():
+        for p in fl.parameters():
+            if p.dim() == 2:
+                p.copy_(torch.randn(p.shape) * 0.05)
+    x = (torch.randn(2, 320, 256) * 2).half()
+    with torch.inference_mode():
+        lay = harness.to_w8a8_mixtral(fl, {"attn_in": 0.05, "o_in": 0.05, "mlp_in": 0.05, "down_in": [0.05, 0.06, 0.07, 0.08]}).to(DEV).half()
+        lay.stack_experts()
+        lay.fuse_gate_up, lay.fast_silu = True, True
+        xd = x.to(DEV)
+        assert lay._stack_image("w1") is None and lay._w13_operand(True) == (None, None)
+        y_plain = lay.moe(xd)
+        assert lay.build_offset_images()
+        assert lay._stack_image("w1") is not None and lay._w13_operand(True)[1] is not None
+        y_img = lay.moe(xd)
+        lay.fuse_gate_up = False                       # grouped w1, w3 + the fused SiLU quantiser on images: the composition the gate || up launch replaces
+        y_comp = lay.moe(xd)
+        assert torch.equal(y_img, y_comp)
+        assert float((y_img.float() - y_plain.float()).abs().max()) <= 0.05 * float(y_plain.float().abs().max()) + 1e-3   # (plain path: torch SiLU, a few int8 steps apart)
+        g = torch.Generator().manual_seed(3)
+        mods = []
+        for _ in range(2):
+            m = W8A8BFP32OFP32Linear(512, 2304, False, "per-tensor")
+            m.weight = torch.randint(-100, 100, (2304, 512), generator=g, dtype=torch.int8)
+            m.dequant_scale = torch.tensor(2e-4)
+            mods.append(m.to(DEV))
+        gu = GateUpSiLU(*mods)
+        assert gu._operand() is None                   # no version counter, nobody promised to refresh
+        assert gu.build(4096, torch.float16) and gu._operand() is not None
