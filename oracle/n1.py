@@ -157,6 +157,27 @@ def silu_mul_kernel_order(gate, up, dt: str) -> np.ndarray:
         return O.round_to((sl * u).astype(F32), dt)
 
 
+def rope_kernel_order(x, cos, sin, dt: str) -> np.ndarray:
+    """asq_rope: x [B, S, H, D], cos / sin [S, D/2] (values of dtype dt), rotate_half convention, positions 0 .. S-1.
+        out[.., :D/2] = dt(dt(x1 * cos) - x2 * sin)      out[.., D/2:] = dt(dt(x2 * cos) + x1 * sin)
+    fp16: the sum is rounded ONCE to fp16 (the kernel's v_fma_mixlo/hi_f16; the product of two fp16 values and its sum with an fp16 value are exact in float64);
+    bf16 / fp32: product and sum each rounded to fp32, then the result to dt (the kernel's fp32 path)."""
+    x = np.asarray(x, dtype=F32)
+    B, S, H, D = x.shape
+    c = np.asarray(cos, dtype=F32).reshape(1, S, 1, D // 2)
+    sn = np.asarray(sin, dtype=F32).reshape(1, S, 1, D // 2)
+    x1, x2 = x[..., : D // 2], x[..., D // 2:]
+    t1, t2 = O.round_to((x1 * c).astype(F32), dt), O.round_to((x2 * c).astype(F32), dt)
+    out = np.empty_like(x)
+    if dt == O.F16:
+        out[..., : D // 2] = (t1.astype(np.float64) - x2.astype(np.float64) * sn.astype(np.float64)).astype(np.float16).astype(F32)
+        out[..., D // 2:] = (t2.astype(np.float64) + x1.astype(np.float64) * sn.astype(np.float64)).astype(np.float16).astype(F32)
+    else:
+        out[..., : D // 2] = O.round_to((t1 + ((-x2) * sn).astype(F32)).astype(F32), dt)
+        out[..., D // 2:] = O.round_to((t2 + (x1 * sn).astype(F32)).astype(F32), dt)
+    return out
+
+
 def silu_mul_quant_fp8_kernel_order(gate, up, dt: str):
     """asq_silu_mul_quantize_fp8 (exact form): a = dt(dt(g / (1 + exp_det(-g))) * u) -- silu_mul_quant_kernel_order's activation -- then the reference's
     per_token_quantize_fp8 (layers/functional/quantization.py:173-191, restated and G5-pinned in oracle/fp8.py).  Returns (e4m3fn bytes [M,K], scale f32 [M,1])."""

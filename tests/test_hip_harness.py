@@ -1,6 +1,7 @@
 """GPU (-m gpu): the LLaMA-architecture layer harness composes the W8A8 linears the way the reference's
 QuantizedLlamaDecoderLayer does (models/llama.py:289-339) and stays within quantisation error of the
 float layer (SURVEY 8c observed ~1-2e-2 relative error for the reference's own block at hidden=256)."""
+import numpy as np
 import pytest
 import torch
 
@@ -297,6 +298,11 @@ def test_rope_kernel_equals_the_torch_composition(dt, shape):
         else:
             assert torch.equal(got, want)
             assert torch.equal(harness._rope(x.transpose(1, 2), theta), want)       # the harness takes the kernel for this layout
+        if B * S * H * D <= (1 << 22):   # the oracle's statement of the same arithmetic (fp16: ONE rounding of the sum), bit for bit
+            from oracle import n1 as N1
+            dtn = {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}[dt]
+            ref = N1.rope_kernel_order(x.float().cpu().numpy(), cos.view(-1, D // 2).float().cpu().numpy(), sin.view(-1, D // 2).float().cpu().numpy(), dtn)
+            assert np.array_equal(got.transpose(1, 2).float().cpu().numpy(), ref), (dt, shape, theta)
         y = x.clone()
         ops.rope(y, cos.view(-1, D // 2), sin.view(-1, D // 2), out=y)                # in place: every thread reads both halves before it writes them
         assert torch.equal(y.transpose(1, 2), got)
