@@ -88,6 +88,26 @@ def _silu_mul(gate, up):
     return F.silu(gate) * up
 
 
+def _rope_qk(q, k, theta=10000.0):
+    """_rope of q and k [B, H, S, D]; when both are adjacent slices of ONE fused q || k || v output (the QKV linear) the two rotations are one kernel launch over the
+    [B, S, Hq + Hk, D] view of that buffer (a decode step saves a launch per layer; same bytes at prefill sizes)."""
+    d = q.shape[-1]
+    if (ROPE_KERNEL and q.is_cuda and q.dtype in (torch.float16, torch.bfloat16) and d % 16 == 0 and q.dim() == 4 and k.dim() == 4 and q.dtype == k.dtype
+            and q.shape[0] == k.shape[0] and q.shape[2] == k.shape[2] and k.shape[3] == d):
+        qb, kb = q.transpose(1, 2), k.transpose(1, 2)      # [B, S, H, D] views of the projection output
+        B_, S_, Hq, _ = qb.shape
+        Hk = kb.shape[2]
+        st = qb.stride()
+        if (st == kb.stride() and st[3] == 1 and st[2] == d and st[1] >= (Hq + Hk) * d and st[1] % 8 == 0 and st[0] == S_ * st[1]
+                and kb.data_ptr() == qb.data_ptr() + Hq * d * q.element_size() and qb.data_ptr() % 16 == 0):
+            from . import ops
+            cos, sin = _rope_tables(S_, d, q.device, q.dtype, theta)
+            both = torch.as_strided(qb, (B_, S_, Hq + Hk, d), st)
+            out = ops.rope(both, cos.view(-1, d // 2), sin.view(-1, d // 2))
+            return out[:, :, :Hq].transpose(1, 2), out[:, :, Hq:].transpose(1, 2)
+    return _rope(q, theta), _rope(k, theta)
+
+
 def _rope_torch(x, theta=10000.0):
     """The same embedding as torch ops: two fused multiply-adds per half written straight into the output (no concatenation pass), tables cached per (S, D)."""
     d = x.shape[-1]
@@ -194,7 +214,7 @@ class LlamaLayer(torch.nn.Module):
         q = q.view(B, S, self.heads, self.hd).transpose(1, 2)
         k = k.view(B, S, self.kv_heads, self.hd).transpose(1, 2)
         v = v.view(B, S, self.kv_heads, self.hd).transpose(1, 2)
-        q, k = _rope(q, self.rope_theta), _rope(k, self.rope_theta)
+        q, k = _rope_qk(q, k, self.rope_theta)
         if self.kv_heads != self.heads:
             r = self.heads // self.kv_heads
             k, v = k.repeat_interleave(r, dim=1), v.repeat_interleave(r, dim=1)

@@ -316,3 +316,21 @@ def test_rope_kernel_equals_the_torch_composition(dt, shape):
                 assert torch.equal(harness._rope(xs.transpose(1, 2), theta), got)
     with pytest.raises(ValueError):
         ops.rope(x.transpose(1, 2), cos.view(-1, D // 2), sin.view(-1, D // 2))       # not the [B, S, H, D] layout
+
+
+def test_rope_of_q_and_k_slices_is_one_launch_and_equal_to_two():
+    """harness._rope_qk: q and k as adjacent slices of a fused q || k || v output are rotated by ONE asq_rope launch over the [B, S, Hq + Hk, D] view (GQA: Hk < Hq too);
+    equal to the two separate rotations bit for bit; anything else falls back to them."""
+    from autosmoothquant_amd import harness
+    dev = torch.device("cuda:0")
+    for (B, S, Hq, Hk, D) in ((2, 33, 8, 8, 128), (1, 1, 32, 8, 128), (3, 5, 4, 2, 64)):
+        qkv = (torch.randn(B, S, (Hq + 2 * Hk) * D, device=dev) * 2).half()
+        q, k, _ = qkv.split([Hq * D, Hk * D, Hk * D], dim=-1)
+        q, k = q.view(B, S, Hq, D).transpose(1, 2), k.view(B, S, Hk, D).transpose(1, 2)
+        rq, rk = harness._rope_qk(q, k, 1e4)
+        assert rq.shape == q.shape and rk.shape == k.shape
+        assert torch.equal(rq, harness._rope(q, 1e4)) and torch.equal(rk, harness._rope(k, 1e4))
+        assert rq.data_ptr() + Hq * D * 2 == rk.data_ptr() or S * B == 0      # one output buffer: the single-launch path ran
+    q2, k2 = (torch.randn(2, 4, 9, 128, device=dev)).half(), (torch.randn(2, 4, 9, 128, device=dev)).half()   # unrelated tensors: two launches
+    rq, rk = harness._rope_qk(q2, k2, 1e4)
+    assert torch.equal(rq, harness._rope_torch(q2, 1e4)) and torch.equal(rk, harness._rope_torch(k2, 1e4))
