@@ -97,12 +97,19 @@ def _rope_qk(q, k, theta=10000.0):
         qb, kb = q.transpose(1, 2), k.transpose(1, 2)      # [B, S, H, D] views of the projection output
         B_, S_, Hq, _ = qb.shape
         Hk = kb.shape[2]
-        st = qb.stride()
-        if (st == kb.stride() and st[3] == 1 and st[2] == d and st[1] >= (Hq + Hk) * d and st[1] % 8 == 0 and st[0] == S_ * st[1]
+        st, sk = qb.stride(), kb.stride()
+        # the row pitch of the fused buffer (strides of size-1 dimensions carry no information: a [1, 1, H, D] view of a slice reports a dense pitch)
+        if S_ > 1:
+            ld, ok = st[1], (sk[1] == st[1] and (B_ == 1 or (st[0] == S_ * st[1] and sk[0] == st[0])))
+        elif B_ > 1:
+            ld, ok = st[0], sk[0] == st[0]
+        else:
+            ld, ok = (Hq + Hk) * d, True
+        if (ok and st[3] == 1 and sk[3] == 1 and st[2] == d and sk[2] == d and ld >= (Hq + Hk) * d and ld % 8 == 0
                 and kb.data_ptr() == qb.data_ptr() + Hq * d * q.element_size() and qb.data_ptr() % 16 == 0):
             from . import ops
             cos, sin = _rope_tables(S_, d, q.device, q.dtype, theta)
-            both = torch.as_strided(qb, (B_, S_, Hq + Hk, d), st)
+            both = torch.as_strided(qb, (B_, S_, Hq + Hk, d), (S_ * ld, ld, d, 1))
             out = ops.rope(both, cos.view(-1, d // 2), sin.view(-1, d // 2))
             return out[:, :, :Hq].transpose(1, 2), out[:, :, Hq:].transpose(1, 2)
     return _rope(q, theta), _rope(k, theta)

@@ -323,7 +323,7 @@ def test_rope_of_q_and_k_slices_is_one_launch_and_equal_to_two():
     equal to the two separate rotations bit for bit; anything else falls back to them."""
     from autosmoothquant_amd import harness
     dev = torch.device("cuda:0")
-    for (B, S, Hq, Hk, D) in ((2, 33, 8, 8, 128), (1, 1, 32, 8, 128), (3, 5, 4, 2, 64)):
+    for (B, S, Hq, Hk, D) in ((2, 33, 8, 8, 128), (1, 1, 32, 8, 128), (3, 5, 4, 2, 64), (4, 1, 8, 8, 128), (1, 7, 8, 2, 128)):
         qkv = (torch.randn(B, S, (Hq + 2 * Hk) * D, device=dev) * 2).half()
         q, k, _ = qkv.split([Hq * D, Hk * D, Hk * D], dim=-1)
         q, k = q.view(B, S, Hq, D).transpose(1, 2), k.view(B, S, Hk, D).transpose(1, 2)
